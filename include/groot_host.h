@@ -1,0 +1,122 @@
+/*
+ * groot_host.h -- C ABI of libgroot_host.so: the host-side (no GPU) pieces either side of the
+ * `groot align` hot path.  Plain C types only, so that a cgo / ctypes binding is a direct
+ * transliteration (INTEGRATION.md shows the cgo stub).
+ *
+ *   index side   : what `groot index` produces and `groot align` loads
+ *                  (cmd/index.go:57-133, src/pipeline/index.go:37-211, src/graph/graph.go:37-396)
+ *   output side  : graph weighting / pruning / GFA + BAM writing after the device path returns
+ *                  (src/graph/graph.go:401-525, src/graph/graphio.go:19-154, src/pipeline/boss.go:45-105)
+ *
+ * Every function returns 0 on success or a negative GROOT_E_* code; groot_host_last_error() gives
+ * the message for the calling thread.
+ */
+#ifndef GROOT_HOST_H
+#define GROOT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "groot_index.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GROOT_OK 0
+#define GROOT_E_INVALID (-1)   /* bad argument                                                    */
+#define GROOT_E_IO (-2)        /* file could not be read / written                                */
+#define GROOT_E_FORMAT (-3)    /* malformed MSA / GFA / FASTQ / index file                        */
+#define GROOT_E_NOMEM (-4)
+#define GROOT_E_DEVICE (-5)    /* HIP runtime error (device library only)                         */
+#define GROOT_E_NOSPACE (-6)   /* caller buffer too small; the needed size is reported            */
+#define GROOT_E_SHORT_READ (-7) /* read shorter than k: the reference panics (boss.go:164-166)    */
+#define GROOT_E_REVCOMP (-8)   /* read byte > 'T' reached RevComplement: reference panics (seqio.go:126) */
+#define GROOT_E_STATE (-9)     /* call sequence error (collect without submit, ...)               */
+#define GROOT_E_UNSUPPORTED (-10)
+
+typedef struct groot_index groot_index; /* owning handle; groot_index_view() borrows from it */
+
+const char *groot_host_last_error(void);
+const char *groot_host_version(void); /* "1.1.2": must equal Info.Version (cmd/align.go:96) */
+
+/* ---- index: `groot index` (cmd/index.go:44-52 defaults k=31 s=21 w=100 x=8 y=4) ---------------- */
+typedef struct groot_index_params {
+    uint32_t kmer_size;       /* -k */
+    uint32_t sketch_size;     /* -s */
+    uint32_t window_size;     /* -w */
+    uint32_t num_part;        /* -x */
+    uint32_t max_k;           /* -y */
+    uint32_t max_sketch_span; /* --maxSketchSpan (never enforced by the reference: graph.go:33,225) */
+    uint32_t n_threads;       /* -p ; 0 = all cores */
+    uint32_t reserved;
+} groot_index_params;
+
+void groot_index_params_default(groot_index_params *p);
+
+/* MSAconverter + GraphSketcher + SketchIndexer (src/pipeline/index.go:37-211) over every
+ * cluster*.msa in msa_dir, graph ids = position in the lexically sorted file list
+ * (filepath.Glob, cmd/index.go:143). */
+int groot_index_build_msa_dir(const char *msa_dir, const groot_index_params *p, groot_index **out);
+int groot_index_build_msa_files(const char *const *files, uint32_t n_files, const groot_index_params *p,
+                                groot_index **out);
+/* same pipeline starting from GFA files (graph.LoadGFA + CreateGrootGraph, graphio.go:115-138,
+ * graph.go:37-147); used with the reference's src/graph/test.gfa fixture */
+int groot_index_build_gfa_files(const char *const *files, uint32_t n_files, const groot_index_params *p,
+                                groot_index **out);
+int groot_index_save(const groot_index *idx, const char *path);   /* flat little-endian .gidx file */
+int groot_index_load(const char *path, groot_index **out);
+void groot_index_get_view(const groot_index *idx, groot_index_view *view);
+void groot_index_free(groot_index *idx);
+
+/* fine-grained mirror of Sequence.RunMinHash(k, s, false, nil) (src/seqio/seqio.go:40-68) used by
+ * the index builder for graph windows (graph.go:292-296).  Host arithmetic; the align path uses
+ * the device kernels in libgroot_hip.so instead. */
+int groot_host_window_sketch(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t s, uint64_t *sketch);
+
+/* ---- graph weighting after alignment ------------------------------------------------------------ */
+/* Replays GrootGraph.IncrementSubPath (graph.go:401-451) from the exact per-(kmerCount, window)
+ * call counts the device accumulated: attempts[q * n_windows + w], q in [0, n_q).  Canonical order:
+ * window ascending, kmerCount ascending, one floating-point add per call. */
+int groot_host_weights(const groot_index_view *idx, const uint32_t *attempts, uint32_t n_q,
+                       double *node_kmer_freq /*[n_nodes]*/, uint64_t *graph_kmer_total /*[n_graphs]*/);
+/* GrootGraph.Prune (graph.go:455-525) over every graph */
+int groot_host_prune(const groot_index_view *idx, const double *node_kmer_freq, double min_kmer_cov,
+                     uint8_t *graph_kept /*[n_graphs]*/, uint8_t *path_kept /*[n_paths]*/,
+                     uint8_t *node_removed /*[n_nodes]*/);
+/* GrootGraph.SaveGraphAsGFA (graphio.go:19-112) for graph g after pruning; writes nothing and sets
+ * *written=0 if no node has KmerFreq>0.  timestamp may be NULL (uses now). */
+int groot_host_save_gfa(const groot_index_view *idx, uint32_t graph, const double *node_kmer_freq,
+                        const uint8_t *path_kept, const uint8_t *node_removed, uint64_t total_kmers,
+                        const char *timestamp, const char *file_name, int *written);
+
+/* ---- FASTQ in (src/pipeline/sketch.go:41-77,175-238; seqio.go:173-188) -------------------------- */
+typedef struct groot_fastq groot_fastq;
+/* paths may end in .gz (sketch.go:60-68); n_files==0 reads stdin */
+int groot_fastq_open(const char *const *files, uint32_t n_files, groot_fastq **out);
+/* Fills caller buffers with up to max_reads reads: seq/qual/name are concatenations with offsets
+ * (n+1 entries each).  Returns the number of reads (0 at end of input) or a negative error. */
+int64_t groot_fastq_next_batch(groot_fastq *fq, uint32_t max_reads, uint8_t *seq, uint8_t *qual, uint64_t *seq_off,
+                               uint64_t seq_cap, char *names, uint64_t *name_off, uint64_t name_cap);
+void groot_fastq_close(groot_fastq *fq);
+
+/* ---- BAM out (src/pipeline/boss.go:45-105,225-240; alignment.go:113-156) ------------------------ */
+typedef struct groot_bam groot_bam;
+typedef struct groot_aln_record {  /* one sam.Record of alignment.go:118-155 */
+    const char *name; uint32_t name_len;        /* read.ID[1:]                                   */
+    const uint8_t *seq; const uint8_t *qual;    /* read.Seq[0:seq_len], read.Qual[0:seq_len] raw  */
+    uint32_t seq_len;
+    uint32_t ref_id;                            /* index into the @SQ list (global path index)    */
+    uint32_t pos;                               /* 0-based                                        */
+    uint8_t start_clip, end_clip, reverse, secondary;
+} groot_aln_record;
+/* header: @HD VN:1.5, one @SQ per path (graphio.go:141-154), @PG ID:1 PN:groot CL:"groot align"
+ * VN:1.1.2, @RG ID:readsID ... (boss.go:55-84).  path NULL or "-" = stdout.  date NULL = now. */
+int groot_bam_open(const char *path, const groot_index_view *idx, const char *date, groot_bam **out);
+int groot_bam_write(groot_bam *bam, const groot_aln_record *recs, uint64_t n);
+int groot_bam_close(groot_bam *bam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
