@@ -1,0 +1,786 @@
+// groot_hip.hip -- libgroot_hip.so: ctx management + the C ABI of include/groot_hip.h.
+// gfx950 only; no CPU fallback anywhere in this library.
+#include <cstring>   // before rocprim: its texture iterator calls host memset
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace groot;
+
+// ---------------------------------------------------------------------------------------------
+// ctx
+// ---------------------------------------------------------------------------------------------
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct groot_ctx {
+    int device = 0;
+    std::string err;
+    groot_params prm{};
+    uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[6]{};
+    bool profiling = false;
+    groot_stage_ms ms{};
+
+    // index in HBM
+    DevBuf<uint32_t> node_seq_off, node_edge_off, edges, win_graph, win_node, win_offset, win_merge_span, win_cn_off, cn_node,
+        band_keys, band_ids;
+    DevBuf<uint8_t> bases, q_k, q_l;
+    DevBuf<uint16_t> q_min_eq;
+    DevBuf<uint64_t> node_mask, win_sketch;
+    DevBuf<ExactEntry> exact;
+    DeviceIndex dix{};
+
+    // batch state
+    DevBuf<uint8_t> seq;
+    DevBuf<uint64_t> seq_off;
+    const uint8_t *cur_seq = nullptr;
+    const uint64_t *cur_off = nullptr;
+    uint32_t n_reads = 0, first_read_id = 0, batch_max_len = 0;
+    bool submitted = false, finished = false;
+    uint32_t seed_slots = 0;
+    DevBuf<uint32_t> seed_count, seed_win;
+    DevBuf<uint64_t> sketches;
+    DevBuf<DeviceCounters> ctr;
+    DeviceCounters hctr{};
+    // traversal output
+    uint32_t trav_cap = 0;
+    DevBuf<groot_trav> trav, trav_sorted;
+    DevBuf<uint64_t> trav_mask, trav_mask_sorted, trav_key, trav_key_sorted;
+    DevBuf<uint32_t> trav_perm, trav_perm_sorted;
+    DevBuf<char> sort_tmp;
+    uint32_t n_trav = 0;
+    // DFS stacks
+    uint32_t align_threads = 0, stk_depth = 0;
+    DevBuf<uint64_t> stk_hdr, stk_mask;
+    // weights
+    DevBuf<uint32_t> attempts;
+};
+
+static thread_local std::string g_open_err;
+
+static int fail(groot_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_open_err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                             \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) return fail(ctx, GROOT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+template <class T> static hipError_t upload(DevBuf<T> &d, const T *src, size_t n, size_t pad = 0)
+{
+    hipError_t e = d.alloc(n + pad);
+    if (e != hipSuccess) return e;
+    if (pad) {
+        e = hipMemset(d.p, 0, (n + pad) * sizeof(T));
+        if (e != hipSuccess) return e;
+    }
+    if (n) e = hipMemcpy(d.p, src, n * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSH Ensemble parameters (github.com/ekzhu/lshensemble v1.1.0: OptimalKL, Containment), computed
+// once per possible kmerCount at open -- the reference caches them per (x, q, t) at query time.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct KLProb {
+    int x, q, l, k;
+    double p(double t) const { return 1.0 - std::pow(1.0 - std::pow(t / (1.0 + double(x) / double(q) - t), double(k)), double(l)); }
+};
+
+template <class F> double integrate(F f, double a, double b, double precision)
+{
+    double area = 0.0;
+    for (double x = a; x < b; x += precision) area += f(x + 0.5 * precision) * precision;
+    return area;
+}
+
+void optimal_kl(int max_k, int max_l, int x, int q, double t, int &opt_k, int &opt_l)
+{
+    const double prec = 0.01;
+    double min_err = 1.7976931348623157e308;
+    opt_k = 0; opt_l = 0;
+    const double xq = double(x) / double(q);
+    for (int l = 1; l <= max_l; l++)
+        for (int k = 1; k <= max_k; k++) {
+            KLProb pr{x, q, l, k};
+            double fp = 0.0, fn = 0.0;
+            if (xq >= 1.0) {
+                fp = integrate([&](double v) { return pr.p(v); }, 0.0, t, prec);
+                fn = integrate([&](double v) { return 1.0 - pr.p(v); }, t, 1.0, prec);
+            } else if (xq >= t) {
+                fp = integrate([&](double v) { return pr.p(v); }, 0.0, t, prec);
+                fn = integrate([&](double v) { return 1.0 - pr.p(v); }, t, xq, prec);
+            }
+            const double err = fn + fp;
+            if (min_err > err) { min_err = err; opt_k = k; opt_l = l; }
+        }
+}
+
+// smallest eq in [1, s] with Containment(eq) > t (monotone in eq); s+1 if none
+uint32_t min_equal_slots(uint32_t s, int q_size, int x_size, double t)
+{
+    if (q_size == 0 || x_size == 0) return s + 1;
+    for (uint32_t eq = 1; eq <= s; eq++) {
+        const double jaccard = double(eq) / double(s);
+        const double c = (double(x_size) / double(q_size) + 1.0) * jaccard / (1.0 + jaccard);
+        if (c > t) return eq;
+    }
+    return s + 1;
+}
+
+uint32_t round_pw(uint32_t pw)
+{
+    for (uint32_t c : {1u, 2u, 3u, 4u, 6u, 8u})
+        if (pw <= c) return c;
+    return 0;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// kernel dispatch by (sketch size, maxK) and path words
+// ---------------------------------------------------------------------------------------------
+template <int S, int MAXK> static void launch_seed_sm(const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (dump) hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, true>), grid, dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, false>), grid, dim3(kBlock), lds, st, a);
+}
+
+static bool seed_supported(uint32_t s, uint32_t max_k)
+{
+    if (max_k != 4) return false;
+    switch (s) {
+    case 8: case 10: case 16: case 20: case 21: case 24: case 30: case 32: case 42: case 64: return true;
+    default: return false;
+    }
+}
+
+static void launch_seed(uint32_t s, const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
+{
+    switch (s) {
+    case 8: launch_seed_sm<8, 4>(a, dump, grid, lds, st); break;
+    case 10: launch_seed_sm<10, 4>(a, dump, grid, lds, st); break;
+    case 16: launch_seed_sm<16, 4>(a, dump, grid, lds, st); break;
+    case 20: launch_seed_sm<20, 4>(a, dump, grid, lds, st); break;
+    case 21: launch_seed_sm<21, 4>(a, dump, grid, lds, st); break;
+    case 24: launch_seed_sm<24, 4>(a, dump, grid, lds, st); break;
+    case 30: launch_seed_sm<30, 4>(a, dump, grid, lds, st); break;
+    case 32: launch_seed_sm<32, 4>(a, dump, grid, lds, st); break;
+    case 42: launch_seed_sm<42, 4>(a, dump, grid, lds, st); break;
+    case 64: launch_seed_sm<64, 4>(a, dump, grid, lds, st); break;
+    default: break;
+    }
+}
+
+static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
+{
+    switch (pw) {
+    case 1: hipLaunchKernelGGL((align_kernel<1>), grid, dim3(kBlock), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((align_kernel<2>), grid, dim3(kBlock), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((align_kernel<3>), grid, dim3(kBlock), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((align_kernel<4>), grid, dim3(kBlock), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((align_kernel<6>), grid, dim3(kBlock), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((align_kernel<8>), grid, dim3(kBlock), 0, st, a); break;
+    default: break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch execution
+// ---------------------------------------------------------------------------------------------
+static constexpr uint32_t kMaxLdsReadBytes = 64 * 1024;
+
+static int alloc_seed_slots(groot_ctx *c, uint32_t slots)
+{
+    c->seed_slots = slots;
+    HIP_TRY(c, c->seed_win.alloc((size_t)slots * c->prm.max_batch_reads));
+    return GROOT_OK;
+}
+
+static int alloc_trav(groot_ctx *c, uint32_t cap)
+{
+    c->trav_cap = cap;
+    HIP_TRY(c, c->trav.alloc(cap));
+    HIP_TRY(c, c->trav_sorted.alloc(cap));
+    HIP_TRY(c, c->trav_mask.alloc((size_t)cap * c->pw));
+    HIP_TRY(c, c->trav_mask_sorted.alloc((size_t)cap * c->pw_view));
+    HIP_TRY(c, c->trav_key.alloc(cap));
+    HIP_TRY(c, c->trav_key_sorted.alloc(cap));
+    HIP_TRY(c, c->trav_perm.alloc(cap));
+    HIP_TRY(c, c->trav_perm_sorted.alloc(cap));
+    return GROOT_OK;
+}
+
+static int launch_seed_stage(groot_ctx *c)
+{
+    SeedArgs a{};
+    a.ix = c->dix;
+    a.seq = c->cur_seq;
+    a.seq_off = c->cur_off;
+    a.n_reads = c->n_reads;
+    a.max_read_len = c->prm.max_read_len;
+    const uint64_t want = (uint64_t)kBlock * c->batch_max_len + 32;
+    a.lds_read_bytes = (uint32_t)std::min<uint64_t>(want, kMaxLdsReadBytes);
+    a.seed_slots = c->seed_slots;
+    a.seed_count = c->seed_count.p;
+    a.seed_win = c->seed_win.p;
+    a.sketch_out = c->prm.keep_sketches ? c->sketches.p : nullptr;
+    a.ctr = c->ctr.p;
+    const dim3 grid((c->n_reads + kBlock - 1) / kBlock);
+    const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
+    launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GROOT_OK;
+}
+
+static int launch_align_stage(groot_ctx *c, bool update_weights)
+{
+    AlignArgs a{};
+    a.ix = c->dix;
+    a.seq = c->cur_seq;
+    a.seq_off = c->cur_off;
+    a.n_reads = c->n_reads;
+    a.first_read_id = c->first_read_id;
+    a.seed_slots = c->seed_slots;
+    a.seed_count = c->seed_count.p;
+    a.seed_win = c->seed_win.p;
+    a.no_align = c->prm.no_exact_align;
+    a.update_weights = update_weights ? 1 : 0;
+    a.attempts = c->attempts.p;
+    a.trav = c->trav.p;
+    a.trav_mask = c->trav_mask.p;
+    a.trav_key = c->trav_key.p;
+    a.trav_cap = c->trav_cap;
+    a.stk_hdr = c->stk_hdr.p;
+    a.stk_mask = c->stk_mask.p;
+    const uint32_t blocks = std::min<uint32_t>((c->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
+    a.n_threads = blocks * kBlock;
+    a.stk_depth = c->stk_depth;
+    a.ctr = c->ctr.p;
+    launch_align(c->pw, a, dim3(blocks), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GROOT_OK;
+}
+
+static int run_batch_async(groot_ctx *c)
+{
+    HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (int rc = launch_seed_stage(c)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (int rc = launch_align_stage(c, true)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    return GROOT_OK;
+}
+
+static int sort_travs(groot_ctx *c)
+{
+    const uint32_t n = c->n_trav;
+    if (!n) return GROOT_OK;
+    hipLaunchKernelGGL(iota_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav_perm.p, n);
+    // key = (local read index << 16) | ord : 32 + 16 significant bits
+    unsigned end_bit = 16;
+    for (uint64_t v = c->n_reads ? c->n_reads - 1 : 0; v; v >>= 1) end_bit++;
+    end_bit = std::min(64u, end_bit + 1);
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->trav_key.p, c->trav_key_sorted.p, c->trav_perm.p,
+                                         c->trav_perm_sorted.p, n, 0, end_bit, c->stream));
+    if (tmp_bytes > c->sort_tmp.n) HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes));
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->trav_key.p, c->trav_key_sorted.p, c->trav_perm.p,
+                                         c->trav_perm_sorted.p, n, 0, end_bit, c->stream));
+    // gather converts the device mask width (pw) to the view's path_words
+    hipLaunchKernelGGL(gather_trav_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav.p,
+                       c->trav_mask.p, c->trav_perm_sorted.p, c->trav_sorted.p, c->trav_mask_sorted.p, n, c->pw, c->pw_view);
+    HIP_TRY(c, hipGetLastError());
+    return GROOT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+void groot_params_default(groot_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->containment_threshold = 0.99;   // cmd/align.go:47
+    p->max_read_len = 256;
+    p->max_batch_reads = 1u << 20;
+    p->max_seeds_per_read = 8;
+}
+
+int groot_hip_device_count(int *n)
+{
+    if (!n) return GROOT_E_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(nullptr, GROOT_E_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return GROOT_OK;
+}
+
+const char *groot_hip_last_error(const groot_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_err.c_str(); }
+
+void groot_hip_close(groot_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, const groot_params *p)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(c, GROOT_E_DEVICE, "no HIP device available (libgroot_hip has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(c, GROOT_E_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    if (!v) return fail(c, GROOT_E_INVALID, "null index view");
+    c->device = device_id;
+    HIP_TRY(c, hipSetDevice(device_id));
+    groot_params d;
+    groot_params_default(&d);
+    c->prm = p ? *p : d;
+    if (!c->prm.max_read_len) c->prm.max_read_len = d.max_read_len;
+    if (!c->prm.max_batch_reads) c->prm.max_batch_reads = d.max_batch_reads;
+    if (!c->prm.max_seeds_per_read) c->prm.max_seeds_per_read = d.max_seeds_per_read;
+    if (!c->prm.max_batch_bases) c->prm.max_batch_bases = (uint64_t)c->prm.max_batch_reads * c->prm.max_read_len;
+    if (c->prm.max_read_len > 65535) return fail(c, GROOT_E_UNSUPPORTED, "max_read_len must be <= 65535");
+    if (v->kmer_size == 0 || v->kmer_size > 64) return fail(c, GROOT_E_UNSUPPORTED, "k-mer size %u not in [1,64]", v->kmer_size);
+    if (c->prm.max_read_len < v->kmer_size) return fail(c, GROOT_E_INVALID, "max_read_len smaller than the k-mer size");
+    if (!seed_supported(v->sketch_size, v->max_k))
+        return fail(c, GROOT_E_UNSUPPORTED, "sketch size %u with maxK %u has no compiled kernel (see launch_seed)", v->sketch_size, v->max_k);
+    c->s = v->sketch_size; c->k = v->kmer_size; c->max_k = v->max_k; c->l_max = v->sketch_size / v->max_k;
+    c->pw_view = v->path_words; c->pw = round_pw(v->path_words);
+    if (!c->pw) return fail(c, GROOT_E_UNSUPPORTED, "graphs with more than 512 paths are not supported (path_words=%u)", v->path_words);
+    c->n_windows = v->n_windows;
+    c->max_q = c->prm.max_read_len - c->k + 1;
+
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+
+    // ---- graphs + windows -> HBM ----
+    HIP_TRY(c, upload(c->node_seq_off, v->node_seq_off, (size_t)v->n_nodes + 1));
+    HIP_TRY(c, upload(c->node_edge_off, v->node_edge_off, (size_t)v->n_nodes + 1));
+    HIP_TRY(c, upload(c->edges, v->edges, v->n_edges));
+    HIP_TRY(c, upload(c->bases, v->bases, v->n_bases, 16));
+    {
+        std::vector<uint64_t> nm((size_t)v->n_nodes * c->pw, 0);
+        for (size_t n = 0; n < v->n_nodes; n++)
+            for (uint32_t w = 0; w < v->path_words; w++) nm[n * c->pw + w] = v->node_mask[n * v->path_words + w];
+        HIP_TRY(c, upload(c->node_mask, nm.data(), nm.size()));
+    }
+    HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
+    HIP_TRY(c, upload(c->win_node, v->win_node, v->n_windows));
+    HIP_TRY(c, upload(c->win_offset, v->win_offset, v->n_windows));
+    HIP_TRY(c, upload(c->win_merge_span, v->win_merge_span, v->n_windows));
+    HIP_TRY(c, upload(c->win_cn_off, v->win_cn_off, (size_t)v->n_windows + 1));
+    HIP_TRY(c, upload(c->cn_node, v->cn_node, v->n_cn));
+    HIP_TRY(c, upload(c->win_sketch, v->win_sketch, (size_t)v->n_windows * v->sketch_size, 2));
+
+    // ---- lookup structures (the reference bootstraps its LSH forests at load too, lshe.go:95-147) ----
+    const uint32_t n = v->n_windows, s = v->sketch_size;
+    {   // exact-match table
+        uint32_t cap = 16;
+        while (cap < 2 * (uint64_t)n) cap <<= 1;
+        std::vector<ExactEntry> tab(cap, ExactEntry{0, kEmpty});
+        for (uint32_t w = 0; w < n; w++) {
+            uint64_t h = GROOT_SKETCH_HASH_INIT;
+            for (uint32_t i = 0; i < s; i++) h = sketch_hash_step(h, v->win_sketch[(size_t)w * s + i]);
+            uint32_t slot = (uint32_t)h & (cap - 1);
+            while (tab[slot].id != kEmpty) slot = (slot + 1) & (cap - 1);
+            tab[slot] = ExactEntry{(uint32_t)(h >> 32), w};
+        }
+        HIP_TRY(c, upload(c->exact, tab.data(), tab.size()));
+        c->dix.exact_mask = cap - 1;
+    }
+    {   // LSH forest band tables: per band the low-32 hash values of its max_k slots, sorted
+        const uint32_t mk = v->max_k, lmax = c->l_max;
+        std::vector<uint32_t> keys((size_t)lmax * n * mk), ids((size_t)lmax * n), order(n);
+        for (uint32_t b = 0; b < lmax; b++) {
+            std::iota(order.begin(), order.end(), 0u);
+            const uint64_t *sk = v->win_sketch;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                for (uint32_t j = 0; j < mk; j++) {
+                    const uint32_t a = (uint32_t)sk[(size_t)x * s + b * mk + j], bb = (uint32_t)sk[(size_t)y * s + b * mk + j];
+                    if (a != bb) return a < bb;
+                }
+                return x < y;
+            });
+            for (uint32_t e = 0; e < n; e++) {
+                ids[(size_t)b * n + e] = order[e];
+                for (uint32_t j = 0; j < mk; j++)
+                    keys[((size_t)b * n + e) * mk + j] = (uint32_t)sk[(size_t)order[e] * s + b * mk + j];
+            }
+        }
+        HIP_TRY(c, upload(c->band_keys, keys.data(), keys.size()));
+        HIP_TRY(c, upload(c->band_ids, ids.data(), ids.size()));
+    }
+    {   // per kmerCount: (K, L) of the partitions (all have Upper = NumWindowKmers) and min #equal slots
+        std::vector<uint8_t> qk(c->max_q + 1, 0), ql(c->max_q + 1, 0);
+        std::vector<uint16_t> qm(c->max_q + 1, (uint16_t)(s + 1));
+        for (uint32_t q = 1; q <= c->max_q; q++) {
+            int K, L;
+            optimal_kl((int)v->max_k, (int)c->l_max, (int)v->num_window_kmers, (int)q, c->prm.containment_threshold, K, L);
+            qk[q] = (uint8_t)K; ql[q] = (uint8_t)L;
+            qm[q] = (uint16_t)min_equal_slots(s, (int)q, (int)v->num_window_kmers, c->prm.containment_threshold);
+        }
+        HIP_TRY(c, upload(c->q_k, qk.data(), qk.size()));
+        HIP_TRY(c, upload(c->q_l, ql.data(), ql.size()));
+        HIP_TRY(c, upload(c->q_min_eq, qm.data(), qm.size()));
+    }
+    DeviceIndex &x = c->dix;
+    x.k = v->kmer_size; x.s = s; x.w = v->window_size; x.num_window_kmers = v->num_window_kmers;
+    x.n_windows = n; x.n_nodes = v->n_nodes; x.pw = c->pw;
+    x.node_seq_off = c->node_seq_off.p; x.node_edge_off = c->node_edge_off.p; x.edges = c->edges.p; x.bases = c->bases.p;
+    x.node_mask = c->node_mask.p; x.win_graph = c->win_graph.p; x.win_node = c->win_node.p; x.win_offset = c->win_offset.p;
+    x.win_merge_span = c->win_merge_span.p; x.win_cn_off = c->win_cn_off.p; x.cn_node = c->cn_node.p;
+    x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
+    x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
+
+    // ---- batch buffers ----
+    const uint32_t R = c->prm.max_batch_reads;
+    HIP_TRY(c, c->seq.alloc(c->prm.max_batch_bases + 64));
+    HIP_TRY(c, c->seq_off.alloc((size_t)R + 1));
+    HIP_TRY(c, c->seed_count.alloc(R));
+    if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
+    if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
+    HIP_TRY(c, c->ctr.alloc(1));
+    if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 2))) return rc;
+    c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, 256u * 8u * kBlock);
+    c->stk_depth = c->prm.max_read_len;
+    HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
+    HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
+    HIP_TRY(c, c->attempts.alloc((size_t)(c->max_q + 1) * n));
+    HIP_TRY(c, hipMemset(c->attempts.p, 0, (size_t)(c->max_q + 1) * n * sizeof(uint32_t)));
+    HIP_TRY(c, hipDeviceSynchronize());
+    return GROOT_OK;
+}
+
+int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p)
+{
+    if (!out) return fail(nullptr, GROOT_E_INVALID, "null out pointer");
+    *out = nullptr;
+    groot_ctx *c = new groot_ctx();
+    int rc = open_impl(c, device_id, idx, p);
+    if (rc) {
+        g_open_err = c->err;
+        groot_hip_close(c);
+        return rc;
+    }
+    *out = c;
+    return GROOT_OK;
+}
+
+int groot_hip_set_stream(groot_ctx *c, void *hip_stream)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "cannot change stream while a batch is in flight");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GROOT_OK;
+}
+
+int groot_hip_set_profiling(groot_ctx *c, int enable)
+{
+    if (!c) return GROOT_E_INVALID;
+    c->profiling = enable != 0;
+    return GROOT_OK;
+}
+
+static int begin_batch(groot_ctx *c, uint32_t n_reads, uint32_t first_read_id)
+{
+    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "previous batch not collected: call groot_hip_wait first");
+    if (n_reads > c->prm.max_batch_reads) return fail(c, GROOT_E_NOSPACE, "batch of %u reads exceeds max_batch_reads=%u", n_reads, c->prm.max_batch_reads);
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->n_reads = n_reads; c->first_read_id = first_read_id;
+    c->submitted = true; c->finished = false; c->n_trav = 0;
+    memset(&c->hctr, 0, sizeof c->hctr);
+    memset(&c->ms, 0, sizeof c->ms);
+    return GROOT_OK;
+}
+
+int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n_reads, uint32_t first_read_id)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (n_reads && (!seq_concat || !seq_off)) return fail(c, GROOT_E_INVALID, "null read buffers");
+    if (int rc = begin_batch(c, n_reads, first_read_id)) { return rc; }
+    if (!n_reads) return GROOT_OK;
+    const uint64_t total = seq_off[n_reads] - seq_off[0];
+    if (seq_off[0] != 0) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0"); }
+    if (total > c->prm.max_batch_bases) { c->submitted = false; return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)total, (unsigned long long)c->prm.max_batch_bases); }
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        if (seq_off[i + 1] < seq_off[i]) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off not monotone at read %u", i); }
+        max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(seq_off[i + 1] - seq_off[i], 0xFFFFFFFFu));
+    }
+    c->batch_max_len = std::min(max_len, c->prm.max_read_len);
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    c->cur_seq = c->seq.p; c->cur_off = c->seq_off.p;
+    return run_batch_async(c);
+}
+
+int groot_hip_submit_device(groot_ctx *c, const void *d_seq, const void *d_seq_off, uint32_t n_reads, uint32_t first_read_id,
+                            uint32_t max_len)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (n_reads && (!d_seq || !d_seq_off)) return fail(c, GROOT_E_INVALID, "null device buffers");
+    if (((uintptr_t)d_seq & 15) != 0) return fail(c, GROOT_E_INVALID, "d_seq must be 16-byte aligned");
+    if (int rc = begin_batch(c, n_reads, first_read_id)) return rc;
+    if (!n_reads) return GROOT_OK;
+    c->batch_max_len = max_len ? std::min(max_len, c->prm.max_read_len) : c->prm.max_read_len;
+    c->cur_seq = (const uint8_t *)d_seq; c->cur_off = (const uint64_t *)d_seq_off;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    return run_batch_async(c);
+}
+
+static void fill_counts(groot_ctx *c, groot_counts *out)
+{
+    if (!out) return;
+    out->received = c->n_reads;           // boss.go:194 receivedReads++ for every read
+    out->mapped = c->hctr.mapped;
+    out->multimapped = c->hctr.multimapped;
+    out->alignments = c->hctr.alignments;
+    out->seeds = c->hctr.seeds;
+    out->travs = c->n_trav;
+    out->revcomp_panics = c->hctr.revcomp_panics;
+    out->short_reads = c->hctr.short_reads;
+}
+
+int groot_hip_wait(groot_ctx *c, groot_counts *counts)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (!c->submitted) return fail(c, GROOT_E_STATE, "no batch submitted");
+    if (c->finished) { fill_counts(c, counts); return GROOT_OK; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_reads == 0) { c->finished = true; fill_counts(c, counts); return GROOT_OK; }
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(c, hipMemcpyAsync(&c->hctr, c->ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const uint32_t flags = c->hctr.flags;
+        if (flags & kFlagSeedOverflow) {
+            // a read had more seeds than slots; the align stage saw the flag and did nothing.  Grow and redo.
+            if (attempt > 4) return fail(c, GROOT_E_NOSPACE, "seed slots overflow persists (%u seeds for one read)", c->hctr.max_seeds);
+            if (int rc = alloc_seed_slots(c, c->hctr.max_seeds + 4)) return rc;
+            if (int rc = run_batch_async(c)) return rc;
+            continue;
+        }
+        if (flags & kFlagTravOverflow) {
+            if (attempt > 4) return fail(c, GROOT_E_NOSPACE, "traversal buffer overflow persists");
+            // enlarge and re-emit traversals only (weights and counters of the first pass stand)
+            const DeviceCounters first = c->hctr;
+            if (int rc = alloc_trav(c, c->hctr.n_trav + 1024)) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
+            if (int rc = launch_align_stage(c, false)) return rc;
+            HIP_TRY(c, hipMemcpyAsync(&c->hctr, c->ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const uint32_t nt = c->hctr.n_trav, fl = c->hctr.flags;
+            const unsigned long long al = c->hctr.alignments;
+            c->hctr = first;
+            c->hctr.n_trav = nt; c->hctr.alignments = al;
+            c->hctr.flags = (first.flags & ~kFlagTravOverflow) | fl;
+            if (c->hctr.flags & kFlagTravOverflow) continue;
+        }
+        break;
+    }
+    c->n_trav = c->hctr.n_trav;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    if (int rc = sort_travs(c)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        (void)hipEventElapsedTime(&c->ms.h2d, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&c->ms.sketch_seed, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->ms.align, c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&c->ms.sort, c->ev[4], c->ev[5]);
+        (void)hipEventElapsedTime(&c->ms.total, c->ev[0], c->ev[5]);
+    }
+    c->finished = true;
+    fill_counts(c, counts);
+    if (c->hctr.flags & kFlagLongRead) return fail(c, GROOT_E_NOSPACE, "a read is longer than max_read_len=%u", c->prm.max_read_len);
+    if (c->hctr.flags & kFlagOrdOverflow) return fail(c, GROOT_E_NOSPACE, "a read produced more than 65535 traversals");
+    if (c->hctr.flags & kFlagShortRead)
+        return fail(c, GROOT_E_SHORT_READ, "k size is greater than sequence length for %llu read(s) (the reference panics: boss.go:164-166)", c->hctr.short_reads);
+    if (c->hctr.revcomp_panics)
+        return fail(c, GROOT_E_REVCOMP, "%llu read(s) hold a byte > 'T' and reached RevComplement (the reference panics: seqio.go:126)", c->hctr.revcomp_panics);
+    return GROOT_OK;
+}
+
+int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *n)
+{
+    if (!c || !n) return GROOT_E_INVALID;
+    if (!c->finished) return fail(c, GROOT_E_STATE, "no finished batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t R = c->n_reads;
+    std::vector<uint32_t> cnt(R), win((size_t)c->seed_slots * R);
+    if (R) {
+        HIP_TRY(c, hipMemcpy(cnt.data(), c->seed_count.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < c->seed_slots; j++)
+            HIP_TRY(c, hipMemcpy(win.data() + (size_t)j * R, c->seed_win.p + (size_t)j * R, (size_t)R * 4, hipMemcpyDeviceToHost));
+    }
+    uint64_t total = 0;
+    std::vector<uint32_t> tmp;
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t m = std::min(cnt[r], c->seed_slots);
+        tmp.clear();
+        for (uint32_t j = 0; j < m; j++) tmp.push_back(win[(size_t)j * R + r]);
+        std::sort(tmp.begin(), tmp.end());
+        for (uint32_t w : tmp) {
+            if (out && total < cap) out[total] = groot_seed{c->first_read_id + r, w};
+            total++;
+        }
+    }
+    *n = total;
+    return GROOT_OK;
+}
+
+int groot_hip_read_travs(groot_ctx *c, groot_trav *out, uint64_t *masks, uint64_t cap, uint64_t *n)
+{
+    if (!c || !n) return GROOT_E_INVALID;
+    if (!c->finished) return fail(c, GROOT_E_STATE, "no finished batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    *n = c->n_trav;
+    const uint64_t m = std::min<uint64_t>(cap, c->n_trav);
+    if (m && out) HIP_TRY(c, hipMemcpy(out, c->trav_sorted.p, m * sizeof(groot_trav), hipMemcpyDeviceToHost));
+    if (m && masks) HIP_TRY(c, hipMemcpy(masks, c->trav_mask_sorted.p, m * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return GROOT_OK;
+}
+
+int groot_hip_read_sketches(groot_ctx *c, uint64_t *out, uint64_t cap_reads, uint64_t *n_reads)
+{
+    if (!c || !n_reads) return GROOT_E_INVALID;
+    if (!c->finished) return fail(c, GROOT_E_STATE, "no finished batch");
+    if (!c->prm.keep_sketches) return fail(c, GROOT_E_STATE, "ctx was opened without keep_sketches");
+    HIP_TRY(c, hipSetDevice(c->device));
+    *n_reads = c->n_reads;
+    const uint64_t m = std::min<uint64_t>(cap_reads, c->n_reads);
+    if (m && out) HIP_TRY(c, hipMemcpy(out, c->sketches.p, m * c->s * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return GROOT_OK;
+}
+
+int groot_hip_stage_ms(groot_ctx *c, groot_stage_ms *out)
+{
+    if (!c || !out) return GROOT_E_INVALID;
+    *out = c->ms;
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_shape(groot_ctx *c, uint32_t *n_q, uint32_t *n_windows)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (n_q) *n_q = c->max_q + 1;
+    if (n_windows) *n_windows = c->n_windows;
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_device(groot_ctx *c, void **d_counts, uint64_t *n_elems)
+{
+    if (!c || !d_counts) return GROOT_E_INVALID;
+    *d_counts = c->attempts.p;
+    if (n_elems) *n_elems = (uint64_t)(c->max_q + 1) * c->n_windows;
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_read(groot_ctx *c, uint32_t *out, uint64_t n_elems)
+{
+    if (!c || !out) return GROOT_E_INVALID;
+    const uint64_t have = (uint64_t)(c->max_q + 1) * c->n_windows;
+    if (n_elems < have) return fail(c, GROOT_E_NOSPACE, "need room for %llu counts", (unsigned long long)have);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (have) HIP_TRY(c, hipMemcpy(out, c->attempts.p, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_reset(groot_ctx *c)
+{
+    if (!c) return GROOT_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->attempts.p, 0, (size_t)(c->max_q + 1) * c->n_windows * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GROOT_OK;
+}
+
+int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n, uint64_t *out)
+{
+    if (!c || !out || (n && (!seq_concat || !seq_off))) return GROOT_E_INVALID;
+    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "a batch is in flight");
+    if (!n) return GROOT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > c->prm.max_batch_reads) return fail(c, GROOT_E_NOSPACE, "more sequences than max_batch_reads");
+    const uint64_t total = seq_off[n];
+    if (total > c->prm.max_batch_bases) return fail(c, GROOT_E_NOSPACE, "more bases than max_batch_bases");
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; i++) max_len = std::max<uint32_t>(max_len, (uint32_t)(seq_off[i + 1] - seq_off[i]));
+    DevBuf<uint64_t> sk;
+    HIP_TRY(c, sk.alloc((size_t)n * c->s));
+    HIP_TRY(c, hipMemcpyAsync(c->seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    SeedArgs a{};
+    a.ix = c->dix;
+    a.ix.max_q = 0;   // no lookup: every read gets min_eq = S+1
+    a.seq = c->seq.p; a.seq_off = c->seq_off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
+    a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
+    a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
+    a.sketch_out = sk.p; a.ctr = c->ctr.p;
+    launch_seed(c->s, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    DeviceCounters h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, sk.p, (size_t)n * c->s * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h.flags & kFlagShortRead) return fail(c, GROOT_E_SHORT_READ, "k size is greater than sequence length");
+    if (h.flags & kFlagLongRead) return fail(c, GROOT_E_NOSPACE, "a sequence is longer than max_read_len=%u", c->prm.max_read_len);
+    return GROOT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,213 @@
+"""Python mirror of libgroot_hip.so (include/groot_hip.h): the MI355X device path of `groot align`.
+
+Fails loudly when the HIP library or a GPU is missing -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi, host
+from ._ffi import IndexView
+from .host import GrootError
+
+TRAV_DTYPE = np.dtype([("read_id", "<u4"), ("graph_id", "<u4"), ("node", "<u4"), ("offset", "<u4"), ("ord", "<u2"),
+                       ("flags", "u1"), ("reserved", "u1")])
+ALN_DTYPE = np.dtype([("read_id", "<u4"), ("graph_id", "<u4"), ("path_id", "<u4"), ("ref_id", "<u4"), ("pos", "<u4"),
+                      ("start_clip", "u1"), ("end_clip", "u1"), ("rc", "u1"), ("secondary", "u1")])
+SEED_DTYPE = np.dtype([("read_id", "<u4"), ("window_id", "<u4")])
+TRAV_RC, TRAV_START_CLIP, TRAV_END_CLIP, TRAV_FIRST = 1, 2, 4, 8
+
+
+class Params(C.Structure):
+    _fields_ = [("containment_threshold", C.c_double), ("no_exact_align", C.c_uint32), ("max_read_len", C.c_uint32),
+                ("max_batch_reads", C.c_uint32), ("max_seeds_per_read", C.c_uint32), ("max_batch_bases", C.c_uint64),
+                ("keep_sketches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("received", "mapped", "multimapped", "alignments", "seeds", "travs",
+                                            "revcomp_panics", "short_reads")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class StageMs(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _ffi.lib_path("libgroot_hip.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} missing: the HIP extension was not built (python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(path)
+        L.groot_hip_last_error.restype = C.c_char_p
+        L.groot_hip_last_error.argtypes = [C.c_void_p]
+        L.groot_hip_close.argtypes = [C.c_void_p]
+        L.groot_hip_close.restype = None
+        _lib = L
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().groot_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def expand_alns(index, travs, masks):
+    """groot_host_expand_alns: traversal records -> one tuple per sam.Record."""
+    travs = np.ascontiguousarray(travs, dtype=TRAV_DTYPE)
+    masks = np.ascontiguousarray(masks, dtype=np.uint64)
+    n = C.c_uint64(0)
+    H = host.lib()
+    rc = H.groot_host_expand_alns(C.byref(index.view), travs.ctypes.data_as(C.c_void_p), _ffi.as_ptr(masks, C.c_uint64),
+                                  C.c_uint64(len(travs)), None, C.c_uint64(0), C.byref(n))
+    host._check(rc)
+    out = np.zeros(n.value, dtype=ALN_DTYPE)
+    rc = H.groot_host_expand_alns(C.byref(index.view), travs.ctypes.data_as(C.c_void_p), _ffi.as_ptr(masks, C.c_uint64),
+                                  C.c_uint64(len(travs)), out.ctypes.data_as(C.c_void_p), C.c_uint64(len(out)), C.byref(n))
+    host._check(rc)
+    return out
+
+
+class Aligner:
+    """One groot_ctx: the replacement for theBoss.mapReads (src/pipeline/boss.go:108-242) on one GPU."""
+
+    def __init__(self, index, device=0, threshold=0.99, no_align=False, max_read_len=256, max_batch_reads=1 << 20,
+                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0):
+        self.index = index
+        self.params = Params(threshold, 1 if no_align else 0, max_read_len, max_batch_reads, max_seeds_per_read,
+                             max_batch_bases, 1 if keep_sketches else 0, 0)
+        self._h = C.c_void_p()
+        rc = lib().groot_hip_open(C.byref(self._h), C.c_int(device), C.byref(index.view), C.byref(self.params))
+        if rc:
+            raise GrootError(rc, lib().groot_hip_last_error(None).decode(errors="replace"))
+        self.s = index.view.sketch_size
+        self.path_words = index.view.path_words
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.groot_hip_close(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GrootError(rc, lib().groot_hip_last_error(self._h).decode(errors="replace"))
+        return rc
+
+    # ---- batch API ----------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._check(lib().groot_hip_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_profiling(self, on=True):
+        self._check(lib().groot_hip_set_profiling(self._h, C.c_int(1 if on else 0)))
+
+    def submit(self, seq_concat, seq_off, first_read_id=0):
+        seq = np.ascontiguousarray(seq_concat, dtype=np.uint8)
+        off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        self._keep = (seq, off)
+        self._check(lib().groot_hip_submit(self._h, _ffi.as_ptr(seq, C.c_uint8), _ffi.as_ptr(off, C.c_uint64),
+                                           C.c_uint32(len(off) - 1), C.c_uint32(first_read_id)))
+
+    def submit_device(self, d_seq_ptr, d_off_ptr, n_reads, first_read_id=0, max_len=0):
+        self._check(lib().groot_hip_submit_device(self._h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), C.c_uint32(n_reads),
+                                                  C.c_uint32(first_read_id), C.c_uint32(max_len)))
+
+    def wait(self, check=True):
+        c = Counts()
+        rc = lib().groot_hip_wait(self._h, C.byref(c))
+        self.last_rc = rc
+        if check:
+            self._check(rc)
+        return c.as_dict()
+
+    def seeds(self):
+        n = C.c_uint64(0)
+        self._check(lib().groot_hip_read_seeds(self._h, None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros(n.value, dtype=SEED_DTYPE)
+        self._check(lib().groot_hip_read_seeds(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint64(len(out)), C.byref(n)))
+        return out
+
+    def travs(self):
+        n = C.c_uint64(0)
+        self._check(lib().groot_hip_read_travs(self._h, None, None, C.c_uint64(0), C.byref(n)))
+        t = np.zeros(n.value, dtype=TRAV_DTYPE)
+        m = np.zeros((n.value, self.path_words), dtype=np.uint64)
+        self._check(lib().groot_hip_read_travs(self._h, t.ctypes.data_as(C.c_void_p), _ffi.as_ptr(m, C.c_uint64),
+                                               C.c_uint64(len(t)), C.byref(n)))
+        return t, m
+
+    def alns(self):
+        t, m = self.travs()
+        return expand_alns(self.index, t, m)
+
+    def sketches(self):
+        n = C.c_uint64(0)
+        self._check(lib().groot_hip_read_sketches(self._h, None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros((n.value, self.s), dtype=np.uint64)
+        self._check(lib().groot_hip_read_sketches(self._h, _ffi.as_ptr(out, C.c_uint64), C.c_uint64(n.value), C.byref(n)))
+        return out
+
+    def stage_ms(self):
+        m = StageMs()
+        self._check(lib().groot_hip_stage_ms(self._h, C.byref(m)))
+        return {n: float(getattr(m, n)) for n, _ in StageMs._fields_}
+
+    # ---- weights ------------------------------------------------------------------------------
+    def attempts_shape(self):
+        nq, nw = C.c_uint32(), C.c_uint32()
+        self._check(lib().groot_hip_attempts_shape(self._h, C.byref(nq), C.byref(nw)))
+        return nq.value, nw.value
+
+    def attempts_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(lib().groot_hip_attempts_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def attempts(self):
+        nq, nw = self.attempts_shape()
+        out = np.zeros((nq, nw), dtype=np.uint32)
+        self._check(lib().groot_hip_attempts_read(self._h, _ffi.as_ptr(out, C.c_uint32), C.c_uint64(out.size)))
+        return out
+
+    def attempts_reset(self):
+        self._check(lib().groot_hip_attempts_reset(self._h))
+
+    # ---- fine-grained mirror of Sequence.RunMinHash ------------------------------------------
+    def sketch(self, seq_concat, seq_off):
+        seq = np.ascontiguousarray(seq_concat, dtype=np.uint8)
+        off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        out = np.zeros((len(off) - 1, self.s), dtype=np.uint64)
+        self._check(lib().groot_hip_sketch(self._h, _ffi.as_ptr(seq, C.c_uint8), _ffi.as_ptr(off, C.c_uint64),
+                                           C.c_uint32(len(off) - 1), _ffi.as_ptr(out, C.c_uint64)))
+        return out
+
+
+def weights(index, attempts):
+    """groot_host_weights: canonical replay of IncrementSubPath from the call counts."""
+    att = np.ascontiguousarray(attempts, dtype=np.uint32)
+    v = index.view
+    kf = np.zeros(v.n_nodes, dtype=np.float64)
+    kt = np.zeros(v.n_graphs, dtype=np.uint64)
+    host._check(host.lib().groot_host_weights(C.byref(v), _ffi.as_ptr(att, C.c_uint32), C.c_uint32(att.shape[0]),
+                                              _ffi.as_ptr(kf, C.c_double), _ffi.as_ptr(kt, C.c_uint64)))
+    return kf, kt
+
+
+def prune(index, kmer_freq, min_cov=1.0):
+    v = index.view
+    gk = np.zeros(v.n_graphs, dtype=np.uint8)
+    pk = np.zeros(v.n_paths, dtype=np.uint8)
+    nr = np.zeros(v.n_nodes, dtype=np.uint8)
+    kf = np.ascontiguousarray(kmer_freq, dtype=np.float64)
+    host._check(host.lib().groot_host_prune(C.byref(v), _ffi.as_ptr(kf, C.c_double), C.c_double(min_cov), _ffi.as_ptr(gk, C.c_uint8),
+                                            _ffi.as_ptr(pk, C.c_uint8), _ffi.as_ptr(nr, C.c_uint8)))
+    return gk, pk, nr

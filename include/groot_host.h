@@ -74,6 +74,41 @@ void groot_index_free(groot_index *idx);
  * the device kernels in libgroot_hip.so instead. */
 int groot_host_window_sketch(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t s, uint64_t *sketch);
 
+/* One successful traversal of performAlignment (alignment.go:162-193) together with the path ids
+ * processTraversal (alignment.go:263-317) assigns to it: bit p of mask = local path id p.
+ * AlignRead emits one sam.Record per set bit, ascending p, traversals in `ord` order; the record's
+ * Pos = Position[p] of `node` + offset.  groot_host_expand_alns() does that expansion. */
+typedef struct groot_trav {
+    uint32_t read_id;
+    uint32_t graph_id;
+    uint32_t node;    /* global node index of the first node of the traversal            */
+    uint32_t offset;  /* offset in that node where the alignment starts                   */
+    uint16_t ord;     /* emission order within the read (graphs ascending, DFS order)     */
+    uint8_t  flags;   /* GROOT_TRAV_* */
+    uint8_t  reserved;
+} groot_trav;
+#define GROOT_TRAV_RC 1u          /* read.RC: the reverse complement aligned (sam.Reverse)           */
+#define GROOT_TRAV_START_CLIP 2u  /* 1H before the M op (alignment.go:72-85)                          */
+#define GROOT_TRAV_END_CLIP 4u    /* 1H after the M op (alignment.go:87-103)                          */
+#define GROOT_TRAV_FIRST 8u       /* first traversal of its (read, graph) AlignRead call              */
+
+/* one sam.Record of AlignRead in id form (alignment.go:114-156) */
+typedef struct groot_aln {
+    uint32_t read_id;
+    uint32_t graph_id;
+    uint32_t path_id;   /* local path id: record.Ref = references[ID]                      */
+    uint32_t ref_id;    /* global path index = position of its @SQ line (graph order)       */
+    uint32_t pos;       /* record.Pos, 0-based                                              */
+    uint8_t start_clip, end_clip, rc, secondary;
+} groot_aln;
+
+/* ---- traversal records -> alignment records ----------------------------------------------------- */
+/* For every traversal, ascending set bit p of its mask: one record with Pos = Position[p] of the
+ * traversal's first node + offset (alignment.go:296); Secondary on all but the first record of each
+ * AlignRead call (alignment.go:147-149).  *n_out = records available; at most cap are written. */
+int groot_host_expand_alns(const groot_index_view *idx, const groot_trav *travs, const uint64_t *masks, uint64_t n_trav,
+                           groot_aln *out, uint64_t cap, uint64_t *n_out);
+
 /* ---- graph weighting after alignment ------------------------------------------------------------ */
 /* Replays GrootGraph.IncrementSubPath (graph.go:401-451) from the exact per-(kmerCount, window)
  * call counts the device accumulated: attempts[q * n_windows + w], q in [0, n_q).  Canonical order:
