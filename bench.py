@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s aligned on MI355X for BASELINE.json's workload.
+
+A step = one pass of the whole `groot align` hot path (sketch -> LSH-Ensemble seed -> graph DFS
+alignment -> canonical ordering of the traversal records) over one batch of synthetic 100 bp
+reads that is already resident in HBM.  Reads shard across GPUs (one process per GPU, index
+replicated); the only exchange is one RCCL all-reduce of the IncrementSubPath call counts after the
+last step (inside the timed region).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import tarfile
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+READ_LEN = 100
+HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
+
+
+def load_index():
+    """arg-annot.90, k=31 s=21 w=100 x=8 y=4 (cmd/index.go:45-49 defaults), cached under build/"""
+    from groot_amd import host
+
+    cache = os.path.join(REPO, "build", "arg-annot.90.k31.s21.w100.gidx")
+    if os.path.exists(cache):
+        try:
+            return host.Index.load(cache)
+        except Exception:
+            pass
+    with tempfile.TemporaryDirectory() as td:
+        with tarfile.open(os.path.join(REPO, "tests", "golden", "data", "arg-annot.90.tar.gz")) as tf:
+            members = [m for m in tf.getmembers() if os.path.basename(m.name).startswith("cluster") and m.name.endswith(".msa")]
+            tf.extractall(td, members=members)
+        index = host.Index.from_msa_dir(os.path.join(td, "arg-annot.90"))
+    try:
+        tmp = cache + ".%d.tmp" % os.getpid()
+        index.save(tmp)
+        os.replace(tmp, cache)
+    except Exception:
+        pass
+    return index
+
+
+def cpu_baseline(index, n_sample):
+    """the oracle (single-thread C port of the reference path) timed on this box's host cores"""
+    from groot_amd import synth
+    from oracle import oracle_py as O
+
+    cat, off, lens = synth.reference_sequences(index)
+    seq, seq_off, _ = synth.reads_np(cat, off, lens, n_sample, READ_LEN)
+    run = O.Run(index, 0.99)
+    t0 = time.perf_counter()
+    run.batch(seq, seq_off)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} reads of the same synthetic stream, oracle/groot_oracle.c single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-align", action="store_true", help="diagnostic: --noAlign mode (weights only, no BAM records)")
+    args = ap.parse_args()
+
+    import torch
+
+    from groot_amd import device, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if rank == 0:
+        index = load_index()
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        index = load_index()
+
+    # ---- synthetic reads of this rank's shard, generated straight into HBM ----
+    cat, off, lens = synth.reference_sequences(index)
+    cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, off, lens))
+    R = args.reads
+    chunks, CH = [], 1_000_000
+    for c0 in range(0, R, CH):
+        n = min(CH, R - c0)
+        p, _, _ = synth.reads_torch(cat_t, off_t, lens_t, n, READ_LEN, first=rank * R + c0)
+        chunks.append(p[: n * READ_LEN])
+    d_seq = torch.zeros(R * READ_LEN + 64, dtype=torch.uint8, device=dev)
+    d_seq[: R * READ_LEN] = torch.cat(chunks)
+    del chunks
+    d_off = torch.arange(0, R + 1, dtype=torch.int64, device=dev) * READ_LEN
+    torch.cuda.synchronize()
+
+    al = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
+                        no_align=args.no_align)
+    stream = torch.cuda.current_stream(dev)
+    al.set_stream(stream.cuda_stream)
+    al.set_profiling(True)
+    n_q, n_w = al.attempts_shape()
+    d_att = torch.zeros(n_q * n_w, dtype=torch.int32, device=dev)
+    al.attempts_bind(d_att.data_ptr(), d_att.numel())
+
+    def step():
+        al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), R, first_read_id=0, max_len=READ_LEN)
+        return al.wait()
+
+    for _ in range(args.warmup):
+        counts = step()
+    d_att.zero_()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_ms, a_ms, s_ms = [], [], []
+    for _ in range(args.steps):
+        counts = step()
+        ms = al.stage_ms()
+        k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"])
+    if dist is not None:
+        dist.all_reduce(d_att)  # per-(kmerCount, window) IncrementSubPath counts: the only exchange
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_reads = world * R * args.steps
+        value = total_reads / dt / 1e6
+        kern_ms = float(np.mean(k_ms))
+        # algorithmic bytes of one sketch_seed launch: read bases + u64 offset in, u32 seed count + u32 per seed out
+        alg_bytes = R * (READ_LEN + 8 + 4) + 4 * counts["seeds"]
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mreads/s aligned", "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[2]: full pipeline incl. on-GPU graph-traversal alignment, 100 bp error-free reads sampled from arg-annot.90, index k=31 s=21 w=100 x=8 y=4, t=0.99",
+                       "reads_per_gpu_per_step": R, "read_len": READ_LEN, "parallelism": f"reads sharded x{world}, index replicated",
+                       "per_step_counts": counts,
+                       "stage_ms": {"sketch_seed": kern_ms, "align": float(np.mean(a_ms)), "sort": float(np.mean(s_ms))}},
+            "roofline": {"bound": "hbm", "kernel": "sketch_seed_kernel<21,4,false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(index, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    al.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,10 @@ enum : uint32_t {
     kFlagSeedOverflow = 4u,   // a read produced more seeds than max_seeds_per_read slots
     kFlagTravOverflow = 8u,   // more traversal records than the output buffer holds
     kFlagOrdOverflow = 16u,   // > 65535 traversals for one read
+    kFlagOvfOverflow = 32u,   // a shard of the overflow traversal list is full
 };
+
+constexpr uint32_t kOvfShards = 256;  // overflow traversal lists, picked by workgroup id: spreads the atomics
 
 struct DeviceCounters {
     unsigned long long mapped, multimapped, alignments, seeds, revcomp_panics, short_reads;
@@ -25,7 +28,22 @@ struct DeviceCounters {
     unsigned int max_seeds;     // largest per-read seed count seen
     unsigned int flags;
     unsigned int pad;
+    unsigned long long dbg[4];  // work counters (only with -DGROOT_WORK_COUNTERS): prefix checks, DFS calls, nodes, pushes
 };
+
+// Everything a DFS step needs about one graph node in one aligned record (64 B for PW<=3, 128 B for PW=11):
+// GrootGraphNode{SegmentLength, Sequence[:8], OutEdges, PathIDs} (src/graph/node.go:13-22).
+template <int PW> struct alignas(16) NodeRec {
+    uint32_t seq_off;          // into DeviceIndex::bases
+    uint32_t seq_len;
+    uint32_t deg;              // out-degree; > 4: edges[0] is the offset into DeviceIndex::edges, child_first unused
+    uint8_t child_first[4];    // first base of each embedded neighbour
+    uint64_t first8;           // first 8 bases of the node (bytes past seq_len are don't-care)
+    uint32_t edges[4];         // OutEdges order (global node indices)
+    uint64_t mask[PW];         // path ids through the node
+};
+static_assert(sizeof(NodeRec<3>) == 64, "node record must be one 64-byte line");
+static_assert(sizeof(NodeRec<11>) == 128, "wide node record must be 128 bytes");
 
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
@@ -33,9 +51,8 @@ struct ExactEntry { uint32_t tag; uint32_t id; };
 // graph + window arrays resident in HBM (replicated per GPU)
 struct DeviceIndex {
     uint32_t k, s, w, num_window_kmers, n_windows, n_nodes, pw; // pw = path words on the device (>= view.path_words)
-    const uint32_t *node_seq_off, *node_edge_off, *edges;
+    const uint32_t *edges;          // only for nodes with more than 4 OutEdges (NodeRec embeds the rest)
     const uint8_t *bases;
-    const uint64_t *node_mask;      // [n_nodes*pw]
     const uint32_t *win_graph, *win_node, *win_offset, *win_merge_span, *win_cn_off, *cn_node;
     const uint64_t *win_sketch;     // [n_windows*s]
     // lookup structures
@@ -72,12 +89,17 @@ struct AlignArgs {
     const uint32_t *seed_count;
     const uint32_t *seed_win;
     uint32_t no_align, update_weights;
+    const void *node_rec;        // NodeRec<pw>[n_nodes]
     uint32_t *attempts;          // [(max_q+1)*n_windows]
-    // traversal output (unsorted; sorted by key afterwards)
-    groot_trav *trav;
-    uint64_t *trav_mask;         // [cap*pw]
-    uint64_t *trav_key;          // (local read index << 16) | ord
-    uint32_t trav_cap;
+    // traversal output: traversal 0 of read r goes to slot r; later ones (ord >= 1, ~4% of them)
+    // to a sharded overflow list.  order_* kernels then compact both into (read, ord) order.
+    groot_trav *trav_first;      // [n_reads]
+    uint64_t *mask_first;        // [n_reads*pw]
+    uint32_t *trav_cnt;          // [n_reads] traversals emitted for read r
+    groot_trav *ovf_trav;        // [kOvfShards][ovf_cap]
+    uint64_t *ovf_mask;          // [kOvfShards*ovf_cap*pw]
+    uint32_t *ovf_cnt;           // [kOvfShards]
+    uint32_t ovf_cap;
     // DFS stacks: entry d of thread t lives at [d*n_threads + t]
     uint64_t *stk_hdr;
     uint64_t *stk_mask;          // [(d*n_threads + t)*pw + word]

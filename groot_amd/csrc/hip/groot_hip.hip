@@ -49,11 +49,12 @@ struct groot_ctx {
     groot_stage_ms ms{};
 
     // index in HBM
-    DevBuf<uint32_t> node_seq_off, node_edge_off, edges, win_graph, win_node, win_offset, win_merge_span, win_cn_off, cn_node,
+    DevBuf<uint32_t> edges, win_graph, win_node, win_offset, win_merge_span, win_cn_off, cn_node,
         band_keys, band_ids;
     DevBuf<uint8_t> bases, q_k, q_l;
     DevBuf<uint16_t> q_min_eq;
-    DevBuf<uint64_t> node_mask, win_sketch;
+    DevBuf<uint64_t> win_sketch;
+    DevBuf<unsigned char> node_rec;
     DevBuf<ExactEntry> exact;
     DeviceIndex dix{};
 
@@ -70,17 +71,18 @@ struct groot_ctx {
     DevBuf<DeviceCounters> ctr;
     DeviceCounters hctr{};
     // traversal output
-    uint32_t trav_cap = 0;
-    DevBuf<groot_trav> trav, trav_sorted;
-    DevBuf<uint64_t> trav_mask, trav_mask_sorted, trav_key, trav_key_sorted;
-    DevBuf<uint32_t> trav_perm, trav_perm_sorted;
-    DevBuf<char> sort_tmp;
+    uint32_t trav_cap = 0, ovf_cap = 0;
+    DevBuf<groot_trav> trav_first, ovf_trav, trav_sorted;
+    DevBuf<uint64_t> mask_first, ovf_mask, trav_mask_sorted;
+    DevBuf<uint32_t> trav_cnt, trav_off, ovf_cnt;
+    DevBuf<char> scan_tmp;
     uint32_t n_trav = 0;
     // DFS stacks
     uint32_t align_threads = 0, stk_depth = 0;
     DevBuf<uint64_t> stk_hdr, stk_mask;
     // weights
     DevBuf<uint32_t> attempts;
+    uint32_t *attempts_ptr = nullptr;   // own buffer or a caller-bound one
 };
 
 static thread_local std::string g_open_err;
@@ -169,9 +171,35 @@ uint32_t min_equal_slots(uint32_t s, int q_size, int x_size, double t)
 
 uint32_t round_pw(uint32_t pw)
 {
-    for (uint32_t c : {1u, 2u, 3u, 4u, 6u, 8u})
+    for (uint32_t c : {3u, 11u})   // NodeRec<3> = 64 B, NodeRec<11> = 128 B
         if (pw <= c) return c;
     return 0;
+}
+
+template <int PW> void build_node_records(const groot_index_view *v, std::vector<unsigned char> &out)
+{
+    std::vector<NodeRec<PW>> recs(v->n_nodes);
+    for (uint32_t n = 0; n < v->n_nodes; n++) {
+        NodeRec<PW> &r = recs[n];
+        memset(&r, 0, sizeof r);
+        r.seq_off = v->node_seq_off[n];
+        r.seq_len = v->node_seq_off[n + 1] - v->node_seq_off[n];
+        const uint32_t e0 = v->node_edge_off[n], deg = v->node_edge_off[n + 1] - e0;
+        r.deg = deg;
+        if (deg <= 4) {
+            for (uint32_t e = 0; e < deg; e++) {
+                const uint32_t c = v->edges[e0 + e];
+                r.edges[e] = c;
+                r.child_first[e] = v->bases[v->node_seq_off[c]];
+            }
+        } else {
+            r.edges[0] = e0;
+        }
+        for (uint32_t i = 0; i < 8 && i < r.seq_len; i++) r.first8 |= (uint64_t)v->bases[r.seq_off + i] << (8 * i);
+        for (uint32_t w = 0; w < v->path_words; w++) r.mask[w] = v->node_mask[(size_t)n * v->path_words + w];
+    }
+    out.resize(recs.size() * sizeof(NodeRec<PW>));
+    if (!recs.empty()) memcpy(out.data(), recs.data(), out.size());
 }
 
 } // namespace
@@ -214,12 +242,8 @@ static void launch_seed(uint32_t s, const SeedArgs &a, bool dump, dim3 grid, siz
 static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
 {
     switch (pw) {
-    case 1: hipLaunchKernelGGL((align_kernel<1>), grid, dim3(kBlock), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((align_kernel<2>), grid, dim3(kBlock), 0, st, a); break;
     case 3: hipLaunchKernelGGL((align_kernel<3>), grid, dim3(kBlock), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((align_kernel<4>), grid, dim3(kBlock), 0, st, a); break;
-    case 6: hipLaunchKernelGGL((align_kernel<6>), grid, dim3(kBlock), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((align_kernel<8>), grid, dim3(kBlock), 0, st, a); break;
+    case 11: hipLaunchKernelGGL((align_kernel<11>), grid, dim3(kBlock), 0, st, a); break;
     default: break;
     }
 }
@@ -239,14 +263,16 @@ static int alloc_seed_slots(groot_ctx *c, uint32_t slots)
 static int alloc_trav(groot_ctx *c, uint32_t cap)
 {
     c->trav_cap = cap;
-    HIP_TRY(c, c->trav.alloc(cap));
     HIP_TRY(c, c->trav_sorted.alloc(cap));
-    HIP_TRY(c, c->trav_mask.alloc((size_t)cap * c->pw));
     HIP_TRY(c, c->trav_mask_sorted.alloc((size_t)cap * c->pw_view));
-    HIP_TRY(c, c->trav_key.alloc(cap));
-    HIP_TRY(c, c->trav_key_sorted.alloc(cap));
-    HIP_TRY(c, c->trav_perm.alloc(cap));
-    HIP_TRY(c, c->trav_perm_sorted.alloc(cap));
+    return GROOT_OK;
+}
+
+static int alloc_ovf(groot_ctx *c, uint32_t cap_per_shard)
+{
+    c->ovf_cap = cap_per_shard;
+    HIP_TRY(c, c->ovf_trav.alloc((size_t)kOvfShards * cap_per_shard));
+    HIP_TRY(c, c->ovf_mask.alloc((size_t)kOvfShards * cap_per_shard * c->pw));
     return GROOT_OK;
 }
 
@@ -285,18 +311,42 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     a.seed_win = c->seed_win.p;
     a.no_align = c->prm.no_exact_align;
     a.update_weights = update_weights ? 1 : 0;
-    a.attempts = c->attempts.p;
-    a.trav = c->trav.p;
-    a.trav_mask = c->trav_mask.p;
-    a.trav_key = c->trav_key.p;
-    a.trav_cap = c->trav_cap;
+    a.attempts = c->attempts_ptr;
+    a.node_rec = c->node_rec.p;
+    a.trav_first = c->trav_first.p;
+    a.mask_first = c->mask_first.p;
+    a.trav_cnt = c->trav_cnt.p;
+    a.ovf_trav = c->ovf_trav.p;
+    a.ovf_mask = c->ovf_mask.p;
+    a.ovf_cnt = c->ovf_cnt.p;
+    a.ovf_cap = c->ovf_cap;
     a.stk_hdr = c->stk_hdr.p;
     a.stk_mask = c->stk_mask.p;
     const uint32_t blocks = std::min<uint32_t>((c->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     a.ctr = c->ctr.p;
+    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, kOvfShards * sizeof(uint32_t), c->stream));
     launch_align(c->pw, a, dim3(blocks), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GROOT_OK;
+}
+
+// traversal records -> (read, ord) order: exclusive scan of the per-read counts, then two scatters
+static int launch_order_stage(groot_ctx *c)
+{
+    const uint32_t n = c->n_reads;
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
+    if (tmp_bytes > c->scan_tmp.n) HIP_TRY(c, c->scan_tmp.alloc(tmp_bytes));
+    HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, c->ctr.p);
+    hipLaunchKernelGGL(order_first_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav_first.p,
+                       c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, c->trav_sorted.p, c->trav_mask_sorted.p, c->trav_cap, c->pw,
+                       c->pw_view, c->ctr.p);
+    hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->stream,
+                       c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, c->first_read_id, c->trav_sorted.p,
+                       c->trav_mask_sorted.p, c->trav_cap, c->pw, c->pw_view, c->ctr.p);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
@@ -309,28 +359,8 @@ static int run_batch_async(groot_ctx *c)
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     if (int rc = launch_align_stage(c, true)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
-    return GROOT_OK;
-}
-
-static int sort_travs(groot_ctx *c)
-{
-    const uint32_t n = c->n_trav;
-    if (!n) return GROOT_OK;
-    hipLaunchKernelGGL(iota_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav_perm.p, n);
-    // key = (local read index << 16) | ord : 32 + 16 significant bits
-    unsigned end_bit = 16;
-    for (uint64_t v = c->n_reads ? c->n_reads - 1 : 0; v; v >>= 1) end_bit++;
-    end_bit = std::min(64u, end_bit + 1);
-    size_t tmp_bytes = 0;
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->trav_key.p, c->trav_key_sorted.p, c->trav_perm.p,
-                                         c->trav_perm_sorted.p, n, 0, end_bit, c->stream));
-    if (tmp_bytes > c->sort_tmp.n) HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes));
-    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->trav_key.p, c->trav_key_sorted.p, c->trav_perm.p,
-                                         c->trav_perm_sorted.p, n, 0, end_bit, c->stream));
-    // gather converts the device mask width (pw) to the view's path_words
-    hipLaunchKernelGGL(gather_trav_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav.p,
-                       c->trav_mask.p, c->trav_perm_sorted.p, c->trav_sorted.p, c->trav_mask_sorted.p, n, c->pw, c->pw_view);
-    HIP_TRY(c, hipGetLastError());
+    if (int rc = launch_order_stage(c)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
     return GROOT_OK;
 }
 
@@ -398,7 +428,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         return fail(c, GROOT_E_UNSUPPORTED, "sketch size %u with maxK %u has no compiled kernel (see launch_seed)", v->sketch_size, v->max_k);
     c->s = v->sketch_size; c->k = v->kmer_size; c->max_k = v->max_k; c->l_max = v->sketch_size / v->max_k;
     c->pw_view = v->path_words; c->pw = round_pw(v->path_words);
-    if (!c->pw) return fail(c, GROOT_E_UNSUPPORTED, "graphs with more than 512 paths are not supported (path_words=%u)", v->path_words);
+    if (!c->pw) return fail(c, GROOT_E_UNSUPPORTED, "graphs with more than 704 paths are not supported (path_words=%u)", v->path_words);
     c->n_windows = v->n_windows;
     c->max_q = c->prm.max_read_len - c->k + 1;
 
@@ -407,15 +437,13 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
 
     // ---- graphs + windows -> HBM ----
-    HIP_TRY(c, upload(c->node_seq_off, v->node_seq_off, (size_t)v->n_nodes + 1));
-    HIP_TRY(c, upload(c->node_edge_off, v->node_edge_off, (size_t)v->n_nodes + 1));
     HIP_TRY(c, upload(c->edges, v->edges, v->n_edges));
-    HIP_TRY(c, upload(c->bases, v->bases, v->n_bases, 16));
+    HIP_TRY(c, upload(c->bases, v->bases, v->n_bases, 64));   // kernels read 8-byte windows up to 24 bytes past a node start
     {
-        std::vector<uint64_t> nm((size_t)v->n_nodes * c->pw, 0);
-        for (size_t n = 0; n < v->n_nodes; n++)
-            for (uint32_t w = 0; w < v->path_words; w++) nm[n * c->pw + w] = v->node_mask[n * v->path_words + w];
-        HIP_TRY(c, upload(c->node_mask, nm.data(), nm.size()));
+        std::vector<unsigned char> recs;
+        if (c->pw == 3) build_node_records<3>(v, recs);
+        else build_node_records<11>(v, recs);
+        HIP_TRY(c, upload(c->node_rec, recs.data(), recs.size()));
     }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
     HIP_TRY(c, upload(c->win_node, v->win_node, v->n_windows));
@@ -479,8 +507,8 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     DeviceIndex &x = c->dix;
     x.k = v->kmer_size; x.s = s; x.w = v->window_size; x.num_window_kmers = v->num_window_kmers;
     x.n_windows = n; x.n_nodes = v->n_nodes; x.pw = c->pw;
-    x.node_seq_off = c->node_seq_off.p; x.node_edge_off = c->node_edge_off.p; x.edges = c->edges.p; x.bases = c->bases.p;
-    x.node_mask = c->node_mask.p; x.win_graph = c->win_graph.p; x.win_node = c->win_node.p; x.win_offset = c->win_offset.p;
+    x.edges = c->edges.p; x.bases = c->bases.p;
+    x.win_graph = c->win_graph.p; x.win_node = c->win_node.p; x.win_offset = c->win_offset.p;
     x.win_merge_span = c->win_merge_span.p; x.win_cn_off = c->win_cn_off.p; x.cn_node = c->cn_node.p;
     x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
@@ -493,13 +521,20 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
     if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
     HIP_TRY(c, c->ctr.alloc(1));
-    if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 2))) return rc;
+    HIP_TRY(c, c->trav_first.alloc(R));
+    HIP_TRY(c, c->mask_first.alloc((size_t)R * c->pw));
+    HIP_TRY(c, c->trav_cnt.alloc(R));
+    HIP_TRY(c, c->trav_off.alloc(R));
+    HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards));
+    if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 4))) return rc;
+    if (int rc = alloc_ovf(c, std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, 256u * 8u * kBlock);
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
     HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
     HIP_TRY(c, c->attempts.alloc((size_t)(c->max_q + 1) * n));
     HIP_TRY(c, hipMemset(c->attempts.p, 0, (size_t)(c->max_q + 1) * n * sizeof(uint32_t)));
+    c->attempts_ptr = c->attempts.p;
     HIP_TRY(c, hipDeviceSynchronize());
     return GROOT_OK;
 }
@@ -602,46 +637,59 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
     if (c->finished) { fill_counts(c, counts); return GROOT_OK; }
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->n_reads == 0) { c->finished = true; fill_counts(c, counts); return GROOT_OK; }
-    for (int attempt = 0;; attempt++) {
-        HIP_TRY(c, hipMemcpyAsync(&c->hctr, c->ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
+    auto fetch = [&](DeviceCounters &dst) -> int {
+        HIP_TRY(c, hipMemcpyAsync(&dst, c->ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const uint32_t flags = c->hctr.flags;
-        if (flags & kFlagSeedOverflow) {
+        return GROOT_OK;
+    };
+    if (int rc = fetch(c->hctr)) return rc;
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 8) return fail(c, GROOT_E_NOSPACE, "output buffers keep overflowing (flags=0x%x)", c->hctr.flags);
+        if (c->hctr.flags & kFlagSeedOverflow) {
             // a read had more seeds than slots; the align stage saw the flag and did nothing.  Grow and redo.
-            if (attempt > 4) return fail(c, GROOT_E_NOSPACE, "seed slots overflow persists (%u seeds for one read)", c->hctr.max_seeds);
             if (int rc = alloc_seed_slots(c, c->hctr.max_seeds + 4)) return rc;
             if (int rc = run_batch_async(c)) return rc;
+            if (int rc = fetch(c->hctr)) return rc;
             continue;
         }
-        if (flags & kFlagTravOverflow) {
-            if (attempt > 4) return fail(c, GROOT_E_NOSPACE, "traversal buffer overflow persists");
-            // enlarge and re-emit traversals only (weights and counters of the first pass stand)
+        if (c->hctr.flags & kFlagOvfOverflow) {
+            // a shard of the overflow traversal list filled up: enlarge and re-emit traversals only
+            // (weights and read counters of the first pass stand)
             const DeviceCounters first = c->hctr;
-            if (int rc = alloc_trav(c, c->hctr.n_trav + 1024)) return rc;
+            if (int rc = alloc_ovf(c, c->ovf_cap * 4)) return rc;
             HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
             if (int rc = launch_align_stage(c, false)) return rc;
-            HIP_TRY(c, hipMemcpyAsync(&c->hctr, c->ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            const uint32_t nt = c->hctr.n_trav, fl = c->hctr.flags;
-            const unsigned long long al = c->hctr.alignments;
+            if (int rc = launch_order_stage(c)) return rc;
+            DeviceCounters second{};
+            if (int rc = fetch(second)) return rc;
             c->hctr = first;
-            c->hctr.n_trav = nt; c->hctr.alignments = al;
-            c->hctr.flags = (first.flags & ~kFlagTravOverflow) | fl;
-            if (c->hctr.flags & kFlagTravOverflow) continue;
+            c->hctr.n_trav = second.n_trav; c->hctr.alignments = second.alignments;
+            c->hctr.flags = (first.flags & ~(kFlagOvfOverflow | kFlagTravOverflow)) | second.flags;
+            continue;
+        }
+        if (c->hctr.flags & kFlagTravOverflow) {
+            // the ordered output buffer is too small: the raw records are intact, only the ordering is redone
+            if (int rc = alloc_trav(c, c->hctr.n_trav + c->hctr.n_trav / 8 + 1024)) return rc;
+            HIP_TRY(c, hipMemsetAsync(&c->ctr.p->flags, 0, sizeof(unsigned int), c->stream));
+            if (int rc = launch_order_stage(c)) return rc;
+            DeviceCounters again{};
+            if (int rc = fetch(again)) return rc;
+            c->hctr.flags = (c->hctr.flags & ~kFlagTravOverflow) | again.flags;
+            continue;
         }
         break;
     }
     c->n_trav = c->hctr.n_trav;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
-    if (int rc = sort_travs(c)) return rc;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+#ifdef GROOT_WORK_COUNTERS
+    fprintf(stderr, "[groot work] prefix_checks=%llu dfs_calls=%llu dfs_nodes=%llu pushes=%llu\n", c->hctr.dbg[0], c->hctr.dbg[1],
+            c->hctr.dbg[2], c->hctr.dbg[3]);
+#endif
     if (c->profiling) {
         (void)hipEventElapsedTime(&c->ms.h2d, c->ev[0], c->ev[1]);
         (void)hipEventElapsedTime(&c->ms.sketch_seed, c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&c->ms.align, c->ev[2], c->ev[3]);
-        (void)hipEventElapsedTime(&c->ms.sort, c->ev[4], c->ev[5]);
-        (void)hipEventElapsedTime(&c->ms.total, c->ev[0], c->ev[5]);
+        (void)hipEventElapsedTime(&c->ms.sort, c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&c->ms.total, c->ev[0], c->ev[4]);
     }
     c->finished = true;
     fill_counts(c, counts);
@@ -669,7 +717,7 @@ int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *
     uint64_t total = 0;
     std::vector<uint32_t> tmp;
     for (uint32_t r = 0; r < R; r++) {
-        const uint32_t m = std::min(cnt[r], c->seed_slots);
+        const uint32_t m = std::min(cnt[r] & 0x7FFFFFFFu, c->seed_slots);
         tmp.clear();
         for (uint32_t j = 0; j < m; j++) tmp.push_back(win[(size_t)j * R + r]);
         std::sort(tmp.begin(), tmp.end());
@@ -724,7 +772,7 @@ int groot_hip_attempts_shape(groot_ctx *c, uint32_t *n_q, uint32_t *n_windows)
 int groot_hip_attempts_device(groot_ctx *c, void **d_counts, uint64_t *n_elems)
 {
     if (!c || !d_counts) return GROOT_E_INVALID;
-    *d_counts = c->attempts.p;
+    *d_counts = c->attempts_ptr;
     if (n_elems) *n_elems = (uint64_t)(c->max_q + 1) * c->n_windows;
     return GROOT_OK;
 }
@@ -736,7 +784,7 @@ int groot_hip_attempts_read(groot_ctx *c, uint32_t *out, uint64_t n_elems)
     if (n_elems < have) return fail(c, GROOT_E_NOSPACE, "need room for %llu counts", (unsigned long long)have);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (have) HIP_TRY(c, hipMemcpy(out, c->attempts.p, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (have) HIP_TRY(c, hipMemcpy(out, c->attempts_ptr, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GROOT_OK;
 }
 
@@ -744,8 +792,19 @@ int groot_hip_attempts_reset(groot_ctx *c)
 {
     if (!c) return GROOT_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->attempts.p, 0, (size_t)(c->max_q + 1) * c->n_windows * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->attempts_ptr, 0, (size_t)(c->max_q + 1) * c->n_windows * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_bind(groot_ctx *c, void *d_counts, uint64_t n_elems)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "a batch is in flight");
+    if (!d_counts) { c->attempts_ptr = c->attempts.p; return GROOT_OK; }
+    const uint64_t need = (uint64_t)(c->max_q + 1) * c->n_windows;
+    if (n_elems < need) return fail(c, GROOT_E_NOSPACE, "bound buffer holds %llu counts, need %llu", (unsigned long long)n_elems, (unsigned long long)need);
+    c->attempts_ptr = (uint32_t *)d_counts;
     return GROOT_OK;
 }
 

@@ -4,7 +4,7 @@
 //                        containment lookup -> per-read seed slots.          thread per read
 //   align_kernel         K3: per read the graphMinion loop: IncrementSubPath call counts and the
 //                        hierarchical exact-match DFS alignment.               thread per read
-//   gather_trav_kernel   reorder traversal records into canonical (read, ord) order
+//   order_*_kernel       compact traversal records into canonical (read, ord) order (scan + scatter)
 //
 // Integer/byte work throughout: no MFMA.  The sketch is VALU bound (64-bit multiply-mix-min per
 // (k-mer, slot)); reads are staged through LDS with coalesced 16-byte loads; the index (graphs,
@@ -129,10 +129,12 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     for (int i = 0; i < S; i++) m[i] = ~0ULL;
     const uint64_t M = (uint64_t)k * GROOT_MULTI_SEED;
     const uint32_t nk = len - k + 1;
+    unsigned high = 0;                       // any byte > 'T': RevComplement would panic (seqio.go:126)
     auto sketch = [&](const unsigned char *rd) {
         uint64_t fh = 0, rh = 0;
         for (uint32_t j = 0; j < k; j++) {   // ntf64 / ntr64 of the first k-mer in one pass
             const unsigned b = rd[j];
+            high |= b > 'T';
             fh = rol1(fh) ^ tabF[b];
             rh ^= rol64(tabC[b & 7], j);
         }
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
             }
             if (++j == nk) break;
             const unsigned prev = rd[j - 1], end = rd[j + k - 1];
+            high |= end > 'T';
             fh = rol1(fh) ^ tabFout[prev] ^ tabF[end];
             rh = ror1(rh) ^ tabCout[prev & 7] ^ tabCin[end & 7];
         }
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
             }
         }
     }
-    a.seed_count[r] = n_hits;
+    a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
     if (n_hits) {
         atomicAdd(&a.ctr->seeds, (unsigned long long)n_hits);
         atomicMax(&a.ctr->max_seeds, n_hits);
@@ -254,231 +257,459 @@ __device__ __forceinline__ unsigned comp_base(unsigned b)
     }
 }
 
-struct ReadRef {
-    const uint8_t *p;   // forward read
-    uint32_t len;       // full length
-    uint32_t rc;        // orientation
-    uint32_t clip_lo;   // bases hard-clipped at the start of the oriented read
-    uint32_t eff;       // effective length being aligned
-    __device__ __forceinline__ unsigned at(uint32_t d) const
-    {
-        const uint32_t i = d + clip_lo;
-        return rc ? comp_base(p[len - 1 - i]) : p[i];
-    }
-};
+// ---- 8 bases at a time (SWAR on the ASCII bytes; little endian: byte 0 = first base) ----
+constexpr uint64_t kLo7 = 0x7F7F7F7F7F7F7F7FULL, kHi1 = 0x8080808080808080ULL, kOnes = 0x0101010101010101ULL;
 
-struct EmitCtx {
-    uint32_t local_read, read_id, graph, flags;
-    uint32_t ord;              // per-read running traversal counter
-    unsigned long long alns;   // per-thread popcount sum
-};
-
-// performAlignment (alignment.go:162-193): every traversal from (node0, off0) spelling the read
-// (dfsRecursive, :196-254), kept with the path set present in all of its nodes (processTraversal,
-// :263-317).  Iterative DFS in OutEdges order; only pending alternatives are stacked; branches whose
-// path set is already empty are cut (they can only yield traversals without ids).
-template <int PW>
-__device__ uint32_t perform_alignment(const AlignArgs &a, const uint32_t stack_tid, const ReadRef &rd, const uint32_t node0,
-                                      const uint32_t off0, EmitCtx &ec)
+__device__ __forceinline__ uint64_t ld8(const uint8_t *p)
 {
-    const DeviceIndex &ix = a.ix;
-    uint32_t emitted = 0, sp = 0;
-    uint32_t cur = node0, off = off0, dist = 0;
-    uint64_t mask[PW];
-#pragma unroll
-    for (int w = 0; w < PW; w++) mask[w] = ~0ULL;
-    {
-        const uint32_t nlen = ix.node_seq_off[node0 + 1] - ix.node_seq_off[node0];
-        if (off0 >= nlen) return 0;                                   // alignment.go:199-201
-    }
-    for (;;) {
-        const uint32_t s0 = ix.node_seq_off[cur], s1 = ix.node_seq_off[cur + 1];
-        const uint32_t avail = s1 - s0 - off;
-        const uint32_t take = min(avail, rd.eff - dist);
-        bool ok = true;
-        const uint8_t *gb = ix.bases + s0 + off;
-        for (uint32_t i = 0; i < take; i++) {
-            const unsigned g = gb[i];
-            if (g != 'N' && g != rd.at(dist + i)) { ok = false; break; }   // :212-222
-        }
-        if (ok) {
-            dist += take;
-            bool any = false;
-#pragma unroll
-            for (int w = 0; w < PW; w++) {
-                mask[w] &= ix.node_mask[(size_t)cur * PW + w];
-                any |= mask[w] != 0;
-            }
-            const uint32_t e0 = ix.node_edge_off[cur], e1 = ix.node_edge_off[cur + 1];
-            if (dist == rd.eff || e0 == e1) {                         // :229-236 report the traversal
-                if (any) {
-                    const uint32_t slot = atomicAdd(&a.ctr->n_trav, 1u);
-                    if (slot < a.trav_cap) {
-                        groot_trav t;
-                        t.read_id = ec.read_id; t.graph_id = ec.graph; t.node = node0; t.offset = off0;
-                        t.ord = (uint16_t)ec.ord;
-                        t.flags = (uint8_t)(ec.flags | (emitted == 0 ? GROOT_TRAV_FIRST : 0));
-                        t.reserved = 0;
-                        a.trav[slot] = t;
-#pragma unroll
-                        for (int w = 0; w < PW; w++) a.trav_mask[(size_t)slot * PW + w] = mask[w];
-                        a.trav_key[slot] = ((uint64_t)ec.local_read << 16) | (ec.ord & 0xFFFFu);
-                    } else {
-                        atomicOr(&a.ctr->flags, kFlagTravOverflow);
-                    }
-                    if (ec.ord >= 0xFFFFu) atomicOr(&a.ctr->flags, kFlagOrdOverflow);
-                    ec.ord++;
-#pragma unroll
-                    for (int w = 0; w < PW; w++) ec.alns += __popcll(mask[w]);
-                    emitted++;
-                }
-            } else if (any) {
-                if (e1 - e0 > 1) {                                    // alternatives e0+1.. stay pending
-                    const size_t si = (size_t)sp * a.n_threads + stack_tid;
-                    a.stk_hdr[si] = (uint64_t)cur | (1ULL << 32) | ((uint64_t)dist << 48);
-#pragma unroll
-                    for (int w = 0; w < PW; w++) a.stk_mask[si * PW + w] = mask[w];
-                    sp++;
-                }
-                cur = ix.edges[e0];
-                off = 0;
-                continue;
-            }
-        }
-        if (sp == 0) break;                                           // backtrack to the newest pending edge
-        const size_t si = (size_t)(sp - 1) * a.n_threads + stack_tid;
-        const uint64_t hdr = a.stk_hdr[si];
-        const uint32_t pn = (uint32_t)hdr, next = (uint32_t)(hdr >> 32) & 0xFFFFu;
-        dist = (uint32_t)(hdr >> 48);
-#pragma unroll
-        for (int w = 0; w < PW; w++) mask[w] = a.stk_mask[si * PW + w];
-        const uint32_t e0 = ix.node_edge_off[pn], deg = ix.node_edge_off[pn + 1] - e0;
-        cur = ix.edges[e0 + next];
-        off = 0;
-        if (next + 1 == deg) sp--;
-        else a.stk_hdr[si] = (uint64_t)pn | ((uint64_t)(next + 1) << 32) | ((uint64_t)dist << 48);
-    }
-    return emitted;
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);   // unaligned 8-byte global load
+    return v;
+}
+// bit 7 of byte i set iff byte i of x is non-zero
+__device__ __forceinline__ uint64_t nonzero_bytes(uint64_t x) { return (((x & kLo7) + kLo7) | x) & kHi1; }
+// bit 7 of byte i set iff graph base i differs from read base i and is not the 'N' wildcard (alignment.go:212-222)
+__device__ __forceinline__ uint64_t mismatch8(uint64_t g, uint64_t r)
+{
+    return nonzero_bytes(g ^ r) & nonzero_bytes(g ^ (kOnes * 'N'));
+}
+// reverse-complement 8 read bytes: v holds read bytes [e-7, e]; result byte 0 = comp(read[e]).
+// A<->T differ by 0x15, C<->G by 0x04, and bit 1 of the ASCII code tells the two pairs apart.  Bytes
+// other than ACGT map to bytes other than ACGT, i.e. they never equal a graph base -- the same outcome as
+// complementBases' 0 (and 'N' only ever meets the graph's wildcard).
+__device__ __forceinline__ uint64_t revcomp8(uint64_t v)
+{
+    const uint64_t r = __builtin_bswap64(v);
+    const uint64_t cg = (r >> 1) & kOnes;
+    return r ^ ((cg * 0x04) | ((cg ^ kOnes) * 0x15));
 }
 
-// AlignRead (alignment.go:13-159) for one orientation of the read against one seed window
-template <int PW>
-__device__ uint32_t align_read(const AlignArgs &a, const uint32_t stack_tid, const uint8_t *p, const uint32_t len,
-                               const uint32_t rc, const uint32_t w, EmitCtx &ec)
+// 8 oriented read bases starting at logical index d of the view (rc, clip_lo); bytes past the view's
+// end are don't-care (callers mask them).  Never reads before p: the batch buffer may start there.
+__device__ __forceinline__ uint64_t read_chunk(const uint8_t *p, uint32_t len, uint32_t rc, uint32_t clip_lo, uint32_t d)
 {
-    const DeviceIndex &ix = a.ix;
-    const uint32_t seed = ix.win_node[w], off0 = ix.win_offset[w];
-    const uint32_t seed_len = ix.node_seq_off[seed + 1] - ix.node_seq_off[seed];
-    ReadRef rd{p, len, rc, 0, len};
-    const uint32_t base_flags = rc ? GROOT_TRAV_RC : 0;
-    ec.flags = base_flags;
-    // 1. seed offset shuffling (:34-45): offsets past the node end fail immediately
-    {
-        const uint64_t last = (uint64_t)off0 + ix.win_merge_span[w] + ix.w;
-        for (uint32_t off = off0; off <= last && off < seed_len; off++) {
-            const uint32_t n = perform_alignment<PW>(a, stack_tid, rd, seed, off, ec);
-            if (n) return n;
-        }
-    }
-    // 2. seed node shuffling (:47-70): ContainedNodes ascending SegmentID, offsets 0..10
-    for (uint32_t c = ix.win_cn_off[w]; c < ix.win_cn_off[w + 1]; c++) {
-        const uint32_t node = ix.cn_node[c];
-        const uint32_t nlen = ix.node_seq_off[node + 1] - ix.node_seq_off[node];
-        for (uint32_t off = 0; off <= 10 && off < nlen; off++) {
-            const uint32_t n = perform_alignment<PW>(a, stack_tid, rd, node, off, ec);
-            if (n) return n;
-        }
-    }
-    // 3. hard clip the first base (:72-85)
-    rd.clip_lo = 1; rd.eff = len - 1;
-    ec.flags = base_flags | GROOT_TRAV_START_CLIP;
-    {
-        const uint32_t n = perform_alignment<PW>(a, stack_tid, rd, seed, off0, ec);
-        if (n) return n;
-    }
-    // 4. hard clip the last base (:87-103)
-    rd.clip_lo = 0;
-    ec.flags = base_flags | GROOT_TRAV_END_CLIP;
-    return perform_alignment<PW>(a, stack_tid, rd, seed, off0, ec);
+    const uint32_t i = d + clip_lo;
+    if (!rc) return ld8(p + i);
+    const int e = (int)len - 1 - (int)i;                 // oriented base 0 = comp(read[e])
+    const uint64_t v = e >= 7 ? ld8(p + (e - 7)) : (e >= 0 ? ld8(p) << (8 * (7 - e)) : 0);
+    return revcomp8(v);
 }
+
+// first m (<= 8) bases equal under the 'N' wildcard rule?
+__device__ __forceinline__ bool prefix_ok(uint64_t g8, uint64_t r8, uint32_t m)
+{
+    const uint64_t mm = mismatch8(g8, r8);
+    return m >= 8 ? mm == 0 : (mm & ((1ULL << (8 * m)) - 1)) == 0;
+}
+
+// bytes [j, j+8) of the 16-byte little-endian window (lo, hi)
+__device__ __forceinline__ uint64_t window8(uint64_t lo, uint64_t hi, uint32_t j)
+{
+    const uint32_t sh = 8 * j;
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+// sum v over the workgroup; result valid in thread 0
+__device__ __forceinline__ unsigned long long block_sum(unsigned long long v, unsigned long long *lds4)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const unsigned wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// K3 as a per-lane state machine with wave-coherent phase scheduling.
+//   graphMinion loop (graphminion.go:46-102) -> AlignRead hierarchy (alignment.go:13-159)
+//   -> performAlignment / dfsRecursive / processTraversal (alignment.go:162-317)
+// Each lane is in one of three phases and advances by ONE step when its phase is executed:
+//   FETCH  take the next read (grid stride) / pick the read's next seed window, count IncrementSubPath
+//   SCAN   test up to 12 candidate start offsets of one node against the read prefix (SWAR, 4-base
+//          filter then exact 8-base check of the lowest survivor); walks the hierarchy levels 1..4
+//   DFS    match up to 16 bases of one graph node, choose the next neighbour, emit / backtrack
+// Per iteration the wave executes only the phase holding the most lanes (ballot + popcount in SALU), so
+// lanes in different reads / levels / depths never serialise each other's loops and every executed
+// instruction runs at the best available lane fill; a lane that finishes a read fetches the next one.
+enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_DONE };
+
+// 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
+__device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
+{
+    return ~(nonzero_bytes(x ^ (kOnes * c)) & nonzero_bytes(x ^ (kOnes * 'N'))) & kHi1;
+}
+// 0x80 in the low n bytes (n may exceed 8 or be <= 0)
+__device__ __forceinline__ uint64_t low_bytes(int n) { return n <= 0 ? 0 : (n >= 8 ? kHi1 : (kHi1 >> (8 * (8 - n)))); }
+
+// a NodeRec held in registers as dwords (16-byte loads; every access below uses a constant index)
+template <int PW> struct RecRegs {
+    static constexpr int NQ = (int)(sizeof(NodeRec<PW>) / 16);
+    uint32_t d[NQ * 4];
+    __device__ __forceinline__ void load(const NodeRec<PW> *rp)
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(rp);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const uint4 v = q[i];
+            d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+        }
+    }
+    __device__ __forceinline__ uint32_t seq_off() const { return d[0]; }
+    __device__ __forceinline__ uint32_t seq_len() const { return d[1]; }
+    __device__ __forceinline__ uint32_t deg() const { return d[2]; }
+    __device__ __forceinline__ unsigned child_first(int e) const { return (d[3] >> (8 * e)) & 0xFFu; }
+    __device__ __forceinline__ uint64_t first8() const { return (uint64_t)d[4] | ((uint64_t)d[5] << 32); }
+    __device__ __forceinline__ uint32_t edge(int e) const { return d[6 + e]; }
+    __device__ __forceinline__ uint64_t mask(int i) const { return (uint64_t)d[10 + 2 * i] | ((uint64_t)d[11 + 2 * i] << 32); }
+};
 
 template <int PW>
 __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 {
+    using Rec = NodeRec<PW>;
+    __shared__ unsigned long long red[4];
     const DeviceIndex &ix = a.ix;
+    const Rec *recs = reinterpret_cast<const Rec *>(a.node_rec);
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     // the seed stage ran out of per-read slots: the host grows them and re-runs the whole batch
     if (a.ctr->flags & kFlagSeedOverflow) return;
-    unsigned long long alns = 0;
-    for (uint32_t r = gtid; r < a.n_reads; r += a.n_threads) {
-        uint32_t cnt = a.seed_count[r];
-        if (cnt == 0) continue;
-        if (cnt > a.seed_slots) cnt = a.seed_slots;       // overflow already flagged; batch is re-run
-        const uint64_t o0 = a.seq_off[r];
-        const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
-        const uint8_t *p = a.seq + o0;
-        const uint32_t q = len - ix.k + 1;                // graphminion.go:60 kmerCount
-        EmitCtx ec{r, a.first_read_id + r, 0, 0, 0, 0};
-        uint32_t n_graphs = 0;
-        int high_byte = -1;                               // lazily: does RevComplement panic on this read?
-        // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
-        long long last = -1;
-        uint32_t done_graph = kEmpty;                     // graph whose minion already found an alignment
-        uint32_t cur_graph = kEmpty;
-        bool group_rc_called = false;
-        for (uint32_t it = 0; it < cnt; it++) {
-            uint32_t w = kEmpty;
+    unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
+#ifdef GROOT_WORK_COUNTERS
+    unsigned long long dbg[4] = {0, 0, 0, 0};
+#define GROOT_COUNT(i) (dbg[i]++)
+#else
+#define GROOT_COUNT(i) ((void)0)
+#endif
+
+    uint32_t phase = PH_FETCH;
+    uint32_t r = gtid - a.n_threads;                       // first fetch adds the stride
+    // ---- read ----
+    bool have_read = false;
+    const uint8_t *p = nullptr;
+    uint32_t len = 0, cnt = 0, q = 0, n_graphs = 0, ord = 0, read_id = 0;
+    uint32_t high_byte = 0;                                // RevComplement would panic on this read
+    long long last = -1;                                   // last seed window handled (ascending window id order)
+    uint32_t done_graph = kEmpty, cur_graph = kEmpty;
+    bool group_rc_called = false;
+    // ---- seed / hierarchy ----
+    uint32_t w = 0, g = 0, seed = 0, seed_s0 = 0, seed_len = 0, off0 = 0, l1_hi = 0, cn_cur = 0, cn_end = 0;
+    uint32_t rc = 0, level = 1;
+    uint32_t sc_node = 0, sc_s0 = 0, sc_len = 0, sc_pos = 0, sc_end = 0;   // range being scanned
+    uint32_t clip_lo = 0, eff = 0, tflags = 0;
+    uint64_t pre8 = 0;
+    // ---- DFS ----
+    uint32_t node0 = 0, noff0 = 0, cur = 0, coff = 0, dist = 0, sp = 0, emitted = 0;
+    uint64_t cur8 = 0;                                     // oriented read bases [dist, dist+8)
+    uint64_t mask[PW];
+#pragma unroll
+    for (int i = 0; i < PW; i++) mask[i] = 0;
+
+    auto set_view = [&](uint32_t clip_lo_, uint32_t eff_, uint32_t clip_flag) {
+        clip_lo = clip_lo_; eff = eff_;
+        tflags = (rc ? GROOT_TRAV_RC : 0u) | clip_flag;
+        pre8 = read_chunk(p, len, rc, clip_lo, 0);
+    };
+    auto scan_range = [&](uint32_t node, uint32_t s0, uint32_t nlen, uint32_t from, uint32_t to) {
+        sc_node = node; sc_s0 = s0; sc_len = nlen; sc_pos = from; sc_end = to;
+    };
+    auto begin_orientation = [&](uint32_t t) {             // 1. seed offset shuffling (alignment.go:34-45)
+        rc = t; level = 1;
+        set_view(0, len, 0);
+        scan_range(seed, seed_s0, seed_len, off0, l1_hi);
+        phase = PH_SCAN;
+    };
+    // the current scan range is used up: move through the hierarchy until a non-empty range or the end
+    auto next_range = [&]() {
+        for (;;) {
+            if (level == 1) { level = 2; cn_cur = ix.win_cn_off[w]; }
+            else if (level == 2) cn_cur++;
+            else if (level == 3) {
+                level = 4;                                  // 4. hard clip the last base (:87-103)
+                set_view(0, len - 1, GROOT_TRAV_END_CLIP);
+                scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
+                return;
+            } else {
+                // AlignRead found nothing in this orientation: graphminion.go:94 RevComplement
+                if (!group_rc_called) {                     // first RevComplement of this minion's copy of the read
+                    group_rc_called = true;
+                    if (high_byte) panics++;                 // seqio.go:126 index out of range
+                }
+                if (rc == 0) begin_orientation(1);
+                else phase = PH_FETCH;                       // both orientations failed: next mapping
+                return;
+            }
+            if (level == 2) {                               // 2. seed node shuffling (:47-70): offsets 0..10
+                if (cn_cur < cn_end) {
+                    const uint32_t node = ix.cn_node[cn_cur];
+                    const uint32_t nlen = recs[node].seq_len;
+                    scan_range(node, recs[node].seq_off, nlen, 0, min(nlen, 11u));
+                    return;
+                }
+                level = 3;                                  // 3. hard clip the first base (:72-85)
+                if (off0 >= seed_len) { level = 4; continue; }   // :199-201 holds for levels 3 and 4 alike
+                set_view(1, len - 1, GROOT_TRAV_START_CLIP);
+                scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
+                return;
+            }
+        }
+    };
+
+    for (;;) {
+        // ---- pick the fullest phase (wave-uniform) ----
+        const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
+        if (!(bf | bs | bd)) break;
+        const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
+        const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
+        if (phase != run) continue;
+
+        if (run == PH_FETCH) {
+            if (!have_read) {
+                r += a.n_threads;
+                if (r >= a.n_reads) { phase = PH_DONE; continue; }
+                const uint32_t sc = a.seed_count[r];
+                cnt = min(sc & 0x7FFFFFFFu, a.seed_slots);   // overflow already flagged; batch is re-run
+                if (cnt == 0) { a.trav_cnt[r] = 0; continue; }
+                high_byte = sc >> 31;
+                const uint64_t o0 = a.seq_off[r];
+                len = (uint32_t)(a.seq_off[r + 1] - o0);
+                p = a.seq + o0;
+                q = len - ix.k + 1;                           // graphminion.go:60 kmerCount
+                read_id = a.first_read_id + r;
+                n_graphs = 0; ord = 0; last = -1;
+                done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
+                have_read = true;
+            }
+            // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
+            uint32_t nw = kEmpty;
             for (uint32_t j = 0; j < cnt; j++) {
                 const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
-                if ((long long)cand > last && cand < w) w = cand;
+                if ((long long)cand > last && cand < nw) nw = cand;
             }
-            if (w == kEmpty) break;                       // duplicates cannot occur; defensive
-            last = w;
-            const uint32_t g = ix.win_graph[w];
+            if (nw == kEmpty) {                               // every seed of the read handled
+                a.trav_cnt[r] = ord;
+                mapped++;                                     // boss.go:195-200
+                if (n_graphs > 1) multimapped++;
+                have_read = false;
+                continue;
+            }
+            w = nw; last = nw;
+            g = ix.win_graph[w];
             if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
-            if (g == done_graph) continue;                // graphminion.go:96-98 break after first alignment
+            if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
             if (a.update_weights) atomicAdd(&a.attempts[(size_t)q * ix.n_windows + w], 1u);   // :67 IncrementSubPath
-            if (a.no_align) continue;                     // :70-72
-            ec.graph = g;
-            bool found = false;
-            for (uint32_t t = 0; t < 2; t++) {            // :76-95 forward, then reverse complement
-                if (align_read<PW>(a, threadIdx.x + blockIdx.x * kBlock, p, len, t, w, ec)) { found = true; break; }
-                if (!group_rc_called) {                   // first RevComplement of this minion's copy of the read
-                    group_rc_called = true;
-                    if (high_byte < 0) {
-                        high_byte = 0;
-                        for (uint32_t i = 0; i < len; i++) high_byte |= p[i] > 'T';
+            if (a.no_align) continue;                         // :70-72
+            seed = ix.win_node[w]; off0 = ix.win_offset[w];
+            seed_s0 = recs[seed].seq_off; seed_len = recs[seed].seq_len;
+            const uint64_t lastoff = (uint64_t)off0 + ix.win_merge_span[w] + ix.w;   // alignment.go:36
+            l1_hi = (uint32_t)min((uint64_t)seed_len, lastoff + 1);   // offsets past the node end fail at once (:199-201)
+            cn_end = ix.win_cn_off[w + 1];
+            begin_orientation(0);
+        } else if (run == PH_SCAN) {
+            GROOT_COUNT(0);
+            if (sc_pos >= sc_end) { next_range(); continue; }
+            // up to 12 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
+            const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
+            const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
+            const uint32_t npos = min(12u, sc_end - sc_pos);
+            const int room = (int)(sc_len - sc_pos);          // bases from sc_pos to the node end
+            uint64_t c_lo = low_bytes((int)npos), c_hi = low_bytes((int)npos - 8);
+            const uint32_t kf = min(4u, eff);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((uint32_t)b >= kf) break;
+                const unsigned rb = (unsigned)(pre8 >> (8 * b)) & 0xFF;
+                // positions whose base b lies inside the node must match it; past the node end the DFS decides
+                const uint64_t need_lo = low_bytes(room - b), need_hi = low_bytes(room - b - 8);
+                c_lo &= match_or_n(window8(w0, w1, b), rb) | ~need_lo;
+                c_hi &= match_or_n(window8(w1, w2, b), rb) | ~need_hi;
+            }
+            uint32_t j = 12;
+            if (c_lo) j = (uint32_t)__builtin_ctzll(c_lo) >> 3;
+            else if (c_hi) j = 8 + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
+            if (j >= npos) { sc_pos += npos; continue; }
+            // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
+            const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
+            const uint32_t off = sc_pos + j;
+            sc_pos = off + 1;
+            if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) continue;
+            node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
+            cur8 = pre8;
+#pragma unroll
+            for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
+            phase = PH_DFS;
+            GROOT_COUNT(1);
+        } else {
+            // ---- DFS: match up to 16 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
+            GROOT_COUNT(2);
+            RecRegs<PW> rec;
+            rec.load(recs + cur);
+            const uint32_t take = min(rec.seq_len() - coff, eff - dist);
+            const uint32_t nb = min(take, 16u);
+            bool ok = true;
+            if (nb) {
+                const uint8_t *gb = ix.bases + rec.seq_off() + coff;
+                const uint64_t ga = coff == 0 ? rec.first8() : ld8(gb);
+                ok = prefix_ok(ga, cur8, min(nb, 8u));
+                if (ok && nb > 8) ok = prefix_ok(ld8(gb + 8), read_chunk(p, len, rc, clip_lo, dist + 8), nb - 8);
+            }
+            bool backtrack = !ok;
+            if (ok) {
+                dist += nb; coff += nb;
+                cur8 = read_chunk(p, len, rc, clip_lo, dist);
+                if (nb == take) {                              // node consumed (or read finished)
+                    bool any = false;
+#pragma unroll
+                    for (int i = 0; i < PW; i++) { mask[i] &= rec.mask(i); any |= mask[i] != 0; }
+                    const uint32_t rdeg = rec.deg();
+                    if (dist == eff || rdeg == 0) {             // :229-236 report the traversal
+                        if (any) {
+                            groot_trav t;
+                            t.read_id = read_id; t.graph_id = g; t.node = node0; t.offset = noff0;
+                            t.ord = (uint16_t)ord;
+                            t.flags = (uint8_t)(tflags | (emitted == 0 ? GROOT_TRAV_FIRST : 0));
+                            t.reserved = 0;
+                            if (ord == 0) {                    // the common case: no allocation at all
+                                a.trav_first[r] = t;
+#pragma unroll
+                                for (int i = 0; i < PW; i++) a.mask_first[(size_t)r * PW + i] = mask[i];
+                            } else {
+                                const uint32_t shard = blockIdx.x & (kOvfShards - 1);
+                                const uint32_t slot = atomicAdd(&a.ovf_cnt[shard], 1u);
+                                if (slot < a.ovf_cap) {
+                                    const size_t o = (size_t)shard * a.ovf_cap + slot;
+                                    a.ovf_trav[o] = t;
+#pragma unroll
+                                    for (int i = 0; i < PW; i++) a.ovf_mask[o * PW + i] = mask[i];
+                                } else atomicOr(&a.ctr->flags, kFlagOvfOverflow);
+                            }
+                            if (ord >= 0xFFFFu) atomicOr(&a.ctr->flags, kFlagOrdOverflow);
+                            ord++;
+#pragma unroll
+                            for (int i = 0; i < PW; i++) alns += __popcll(mask[i]);
+                            emitted++;
+                        }
+                        backtrack = true;
+                    } else if (!any) backtrack = true;         // no path left: descendants cannot yield ids
+                    else {
+                        // :242-252 neighbours in OutEdges order; a neighbour whose first base cannot match the
+                        // next read base dies in its first comparison, so it is skipped without being visited
+                        const unsigned nextb = (unsigned)cur8 & 0xFF;
+                        uint32_t first = kEmpty, more = kEmpty;
+                        if (rdeg <= 4) {
+#pragma unroll
+                            for (int e = 3; e >= 0; e--) {
+                                const unsigned cf1 = rec.child_first(e);
+                                if ((uint32_t)e < rdeg && (cf1 == 'N' || cf1 == nextb)) { more = first; first = e; }
+                            }
+                        } else { first = 0; more = 1; }
+                        if (first == kEmpty) backtrack = true;
+                        else {
+                            if (more != kEmpty) {              // further candidates stay pending
+                                const size_t si = (size_t)sp * a.n_threads + gtid;
+                                a.stk_hdr[si] = (uint64_t)cur | ((uint64_t)more << 32) | ((uint64_t)dist << 48);
+#pragma unroll
+                                for (int i = 0; i < PW; i++) a.stk_mask[si * PW + i] = mask[i];
+                                sp++;
+                                GROOT_COUNT(3);
+                            }
+                            if (rdeg <= 4) {                   // select, not index: keeps the record in registers
+                                cur = rec.edge(0);
+                                if (first == 1) cur = rec.edge(1);
+                                if (first == 2) cur = rec.edge(2);
+                                if (first == 3) cur = rec.edge(3);
+                            } else cur = ix.edges[rec.edge(0) + first];
+                            coff = 0;
+                        }
                     }
-                    if (high_byte && a.update_weights) atomicAdd(&a.ctr->revcomp_panics, 1ULL);
                 }
             }
-            if (found) done_graph = g;
+            if (backtrack) {
+                if (sp == 0) {                                 // performAlignment is over
+                    if (emitted) { done_graph = g; phase = PH_FETCH; }   // alignment found for (read, graph)
+                    else phase = PH_SCAN;
+                } else {                                       // resume at the newest pending neighbour
+                    const size_t si = (size_t)(sp - 1) * a.n_threads + gtid;
+                    const uint64_t hdr = a.stk_hdr[si];
+                    const uint32_t pn = (uint32_t)hdr, e = (uint32_t)(hdr >> 32) & 0xFFFFu;
+                    dist = (uint32_t)(hdr >> 48);
+#pragma unroll
+                    for (int i = 0; i < PW; i++) mask[i] = a.stk_mask[si * PW + i];
+                    cur8 = read_chunk(p, len, rc, clip_lo, dist);
+                    const Rec &pr = recs[pn];
+                    const uint32_t deg = pr.deg;
+                    uint32_t more = kEmpty;
+                    if (deg <= 4) {
+                        const unsigned nextb = (unsigned)cur8 & 0xFF;
+                        for (uint32_t e2 = e + 1; e2 < deg; e2++) {
+                            const unsigned cf1 = pr.child_first[e2];
+                            if (cf1 == 'N' || cf1 == nextb) { more = e2; break; }
+                        }
+                        cur = pr.edges[e];
+                    } else {
+                        if (e + 1 < deg) more = e + 1;
+                        cur = ix.edges[pr.edges[0] + e];
+                    }
+                    coff = 0;
+                    if (more == kEmpty) sp--;
+                    else a.stk_hdr[si] = (uint64_t)pn | ((uint64_t)more << 32) | ((uint64_t)dist << 48);
+                }
+            }
         }
-        if (a.update_weights) {
-            atomicAdd(&a.ctr->mapped, 1ULL);                              // boss.go:195-200
-            if (n_graphs > 1) atomicAdd(&a.ctr->multimapped, 1ULL);
-        }
-        alns += ec.alns;
     }
-    if (alns) atomicAdd(&a.ctr->alignments, alns);
+
+#ifdef GROOT_WORK_COUNTERS
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long v = block_sum(dbg[i], red);
+        if (threadIdx.x == 0 && v) atomicAdd(&a.ctr->dbg[i], v);
+    }
+#endif
+    alns = block_sum(alns, red);
+    mapped = block_sum(mapped, red);
+    multimapped = block_sum(multimapped, red);
+    panics = block_sum(panics, red);
+    if (threadIdx.x == 0) {
+        if (alns) atomicAdd(&a.ctr->alignments, alns);
+        if (a.update_weights) {
+            if (mapped) atomicAdd(&a.ctr->mapped, mapped);
+            if (multimapped) atomicAdd(&a.ctr->multimapped, multimapped);
+            if (panics) atomicAdd(&a.ctr->revcomp_panics, panics);
+        }
+    }
 }
 
-// canonical order: perm[i] = index of the i-th record after sorting keys
-__global__ __launch_bounds__(kBlock) void gather_trav_kernel(const groot_trav *in, const uint64_t *mask_in, const uint32_t *perm,
-                                                           groot_trav *out, uint64_t *mask_out, uint32_t n, uint32_t pw_in,
-                                                           uint32_t pw_out)
+// ---- ordering: (read, ord) order without a sort -------------------------------------------------
+// off = exclusive scan of trav_cnt (rocprim); record (r, ord) lands at off[r] + ord.
+__global__ void order_total_kernel(const uint32_t *off, const uint32_t *cnt, uint32_t n, DeviceCounters *ctr)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = perm[i];
-    out[i] = in[s];
-    for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = mask_in[(size_t)s * pw_in + w];
+    if (n) ctr->n_trav = off[n - 1] + cnt[n - 1];
 }
 
-__global__ __launch_bounds__(kBlock) void iota_kernel(uint32_t *p, uint32_t n)
+__global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *first, const uint64_t *mask_first, const uint32_t *off,
+                                                           const uint32_t *cnt, uint32_t n, groot_trav *out, uint64_t *mask_out,
+                                                           uint32_t cap, uint32_t pw_in, uint32_t pw_out, DeviceCounters *ctr)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) p[i] = i;
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n || cnt[r] == 0) return;
+    const uint32_t i = off[r];
+    if (i >= cap) { atomicOr(&ctr->flags, kFlagTravOverflow); return; }
+    out[i] = first[r];
+    for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = mask_first[(size_t)r * pw_in + w];
+}
+
+__global__ __launch_bounds__(kBlock) void order_ovf_kernel(const groot_trav *ovf, const uint64_t *ovf_mask, const uint32_t *ovf_cnt,
+                                                         uint32_t ovf_cap, const uint32_t *off, uint32_t first_read_id, groot_trav *out,
+                                                         uint64_t *mask_out, uint32_t cap, uint32_t pw_in, uint32_t pw_out,
+                                                         DeviceCounters *ctr)
+{
+    const uint32_t shard = blockIdx.y;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= min(ovf_cnt[shard], ovf_cap)) return;
+    const size_t o = (size_t)shard * ovf_cap + slot;
+    const groot_trav t = ovf[o];
+    const uint32_t i = off[t.read_id - first_read_id] + t.ord;
+    if (i >= cap) { atomicOr(&ctr->flags, kFlagTravOverflow); return; }
+    out[i] = t;
+    for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = ovf_mask[o * pw_in + w];
 }
 
 // sketch-only entry (groot_hip_sketch): reuse K1 with an index that has no windows

@@ -178,6 +178,9 @@ class Aligner:
         self._check(lib().groot_hip_attempts_read(self._h, _ffi.as_ptr(out, C.c_uint32), C.c_uint64(out.size)))
         return out
 
+    def attempts_bind(self, d_ptr, n_elems):
+        self._check(lib().groot_hip_attempts_bind(self._h, C.c_void_p(d_ptr), C.c_uint64(n_elems)))
+
     def attempts_reset(self):
         self._check(lib().groot_hip_attempts_reset(self._h))
 

@@ -86,8 +86,9 @@ int groot_hip_set_profiling(groot_ctx *ctx, int enable);
  * seq_off[i]..seq_off[i+1] = read i (n_reads+1 entries).  Copies H2D and launches; asynchronous. */
 int groot_hip_submit(groot_ctx *ctx, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n_reads,
                      uint32_t first_read_id);
-/* Same, inputs already resident in HBM.  d_seq must be 16-byte aligned and readable up to the next
- * multiple of 16 past the last base; max_len = longest read of the batch (0 = params.max_read_len). */
+/* Same, inputs already resident in HBM.  d_seq must be 16-byte aligned and readable for 16 bytes past
+ * the last base (the kernels load 16-byte / 8-byte words); max_len = longest read of the batch
+ * (0 = params.max_read_len). */
 int groot_hip_submit_device(groot_ctx *ctx, const void *d_seq, const void *d_seq_off, uint32_t n_reads,
                             uint32_t first_read_id, uint32_t max_len);
 /* Blocks until the submitted batch is finished; counts are for that batch. */
@@ -108,6 +109,9 @@ int groot_hip_attempts_shape(groot_ctx *ctx, uint32_t *n_q, uint32_t *n_windows)
 int groot_hip_attempts_device(groot_ctx *ctx, void **d_counts_u32, uint64_t *n_elems);
 int groot_hip_attempts_read(groot_ctx *ctx, uint32_t *out, uint64_t n_elems);
 int groot_hip_attempts_reset(groot_ctx *ctx);
+/* Accumulate into a caller-owned device buffer of n_q*n_windows uint32 (e.g. a torch tensor that is
+ * all-reduced over RCCL afterwards) instead of the ctx's own; NULL = back to the ctx's buffer. */
+int groot_hip_attempts_bind(groot_ctx *ctx, void *d_counts_u32, uint64_t n_elems);
 
 /* Fine-grained mirror of Sequence.RunMinHash(k, s, false, nil) (seqio.go:40-68) for a batch of
  * sequences in host memory: out[i*s .. (i+1)*s) = KHF sketch of sequence i. */
