@@ -55,6 +55,9 @@ struct DeviceIndex {
     const uint8_t *bases;
     const uint32_t *win_graph, *win_node, *win_offset, *win_merge_span, *win_cn_off, *cn_node;
     const uint64_t *win_sketch;     // [n_windows*s]
+    // per window: which 5-base read prefixes (2 bits per base, A=0 C=1 T=2 G=3) can be spelled from any
+    // level-1 / level-2 start position of AlignRead (alignment.go:34-70); 1024 bits = 32 words per window
+    const uint32_t *win_kmer5;
     // lookup structures
     const ExactEntry *exact;        // open addressing, exact_mask+1 slots
     uint32_t exact_mask;

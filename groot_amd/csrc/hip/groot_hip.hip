@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -49,7 +50,7 @@ struct groot_ctx {
     groot_stage_ms ms{};
 
     // index in HBM
-    DevBuf<uint32_t> edges, win_graph, win_node, win_offset, win_merge_span, win_cn_off, cn_node,
+    DevBuf<uint32_t> win_kmer5, edges, win_graph, win_node, win_offset, win_merge_span, win_cn_off, cn_node,
         band_keys, band_ids;
     DevBuf<uint8_t> bases, q_k, q_l;
     DevBuf<uint16_t> q_min_eq;
@@ -175,6 +176,56 @@ uint32_t round_pw(uint32_t pw)
         if (pw <= c) return c;
     return 0;
 }
+
+// Per window: every 5-base prefix a read must start with for AlignRead's level 1 (seed node, offsets
+// OffSet..OffSet+MergeSpan+WindowSize inside the node, alignment.go:34-45) or level 2 (ContainedNodes,
+// offsets 0..10, :47-70) to have any chance: the spellings of 5 bases from each such start position,
+// following every OutEdge at node ends ('N' spells anything; a sink before 5 bases accepts anything, as
+// dfsRecursive reports a traversal that runs off the graph, :229).  Sound: never clears a spellable prefix.
+struct Kmer5Builder {
+    const groot_index_view *v;
+    uint32_t *bits;   // 32 words of the current window
+    void set_all(int code, int have)   // every completion of the `have` bases already in code
+    {
+        const int free_bits = 2 * (5 - have);
+        for (int x = 0; x < (1 << free_bits); x++) {
+            const int c = code | (x << (2 * have));
+            bits[c >> 5] |= 1u << (c & 31);
+        }
+    }
+    void walk(uint32_t node, uint32_t off, int code, int have)
+    {
+        const uint32_t s0 = v->node_seq_off[node], len = v->node_seq_off[node + 1] - s0;
+        while (off < len && have < 5) {
+            const uint8_t b = v->bases[s0 + off];
+            if (b == 'N') {
+                for (int c = 0; c < 4; c++) walk_from(node, off + 1, code | (c << (2 * have)), have + 1);
+                return;
+            }
+            code |= (int)((b >> 1) & 3) << (2 * have);
+            have++; off++;
+        }
+        if (have == 5) { bits[code >> 5] |= 1u << (code & 31); return; }
+        const uint32_t e0 = v->node_edge_off[node], e1 = v->node_edge_off[node + 1];
+        if (e0 == e1) { set_all(code, have); return; }
+        for (uint32_t e = e0; e < e1; e++) walk(v->edges[e], 0, code, have);
+    }
+    void walk_from(uint32_t node, uint32_t off, int code, int have) { walk(node, off, code, have); }
+    void window(uint32_t w, uint32_t *out)
+    {
+        bits = out;
+        const uint32_t seed = v->win_node[w], off0 = v->win_offset[w];
+        const uint32_t seed_len = v->node_seq_off[seed + 1] - v->node_seq_off[seed];
+        const uint64_t last = (uint64_t)off0 + v->win_merge_span[w] + v->window_size;
+        const uint32_t hi = (uint32_t)std::min<uint64_t>(seed_len, last + 1);
+        for (uint32_t o = off0; o < hi; o++) walk(seed, o, 0, 0);
+        for (uint32_t c = v->win_cn_off[w]; c < v->win_cn_off[w + 1]; c++) {
+            const uint32_t n = v->cn_node[c];
+            const uint32_t nlen = v->node_seq_off[n + 1] - v->node_seq_off[n];
+            for (uint32_t o = 0; o < std::min(nlen, 11u); o++) walk(n, o, 0, 0);
+        }
+    }
+};
 
 template <int PW> void build_node_records(const groot_index_view *v, std::vector<unsigned char> &out)
 {
@@ -445,6 +496,18 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         else build_node_records<11>(v, recs);
         HIP_TRY(c, upload(c->node_rec, recs.data(), recs.size()));
     }
+    {
+        std::vector<uint32_t> k5((size_t)v->n_windows * 32, 0);
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                Kmer5Builder b{v, nullptr};
+                for (uint32_t w = t; w < v->n_windows; w += nt) b.window(w, k5.data() + (size_t)w * 32);
+            });
+        for (auto &x : th) x.join();
+        HIP_TRY(c, upload(c->win_kmer5, k5.data(), k5.size()));
+    }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
     HIP_TRY(c, upload(c->win_node, v->win_node, v->n_windows));
     HIP_TRY(c, upload(c->win_offset, v->win_offset, v->n_windows));
@@ -508,7 +571,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     x.k = v->kmer_size; x.s = s; x.w = v->window_size; x.num_window_kmers = v->num_window_kmers;
     x.n_windows = n; x.n_nodes = v->n_nodes; x.pw = c->pw;
     x.edges = c->edges.p; x.bases = c->bases.p;
-    x.win_graph = c->win_graph.p; x.win_node = c->win_node.p; x.win_offset = c->win_offset.p;
+    x.win_kmer5 = c->win_kmer5.p; x.win_graph = c->win_graph.p; x.win_node = c->win_node.p; x.win_offset = c->win_offset.p;
     x.win_merge_span = c->win_merge_span.p; x.win_cn_off = c->win_cn_off.p; x.cn_node = c->cn_node.p;
     x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
@@ -681,7 +744,7 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
     }
     c->n_trav = c->hctr.n_trav;
 #ifdef GROOT_WORK_COUNTERS
-    fprintf(stderr, "[groot work] prefix_checks=%llu dfs_calls=%llu dfs_nodes=%llu pushes=%llu\n", c->hctr.dbg[0], c->hctr.dbg[1],
+    fprintf(stderr, "[groot work] lane_steps fetch=%llu scan=%llu dfs=%llu dfs_calls=%llu\n", c->hctr.dbg[0], c->hctr.dbg[1],
             c->hctr.dbg[2], c->hctr.dbg[3]);
 #endif
     if (c->profiling) {

@@ -333,6 +333,19 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
 // instruction runs at the best available lane fill; a lane that finishes a read fetches the next one.
 enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_DONE };
 
+// 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 10-bit code of the first 5 bases of r8,
+// or -1 if one of them is not ACGT (such a base can still meet the graph's 'N' wildcard)
+__host__ __device__ __forceinline__ int kmer5_code(uint64_t r8)
+{
+    int code = 0;
+    for (int i = 0; i < 5; i++) {
+        const unsigned b = (unsigned)(r8 >> (8 * i)) & 0xFF;
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return -1;
+        code |= (int)((b >> 1) & 3) << (2 * i);
+    }
+    return code;
+}
+
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
 __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
 {
@@ -417,6 +430,14 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
         set_view(0, len, 0);
         scan_range(seed, seed_s0, seed_len, off0, l1_hi);
         phase = PH_SCAN;
+        // can any level-1/2 start position spell the first 5 bases of this orientation?  If not, both
+        // levels are known to fail: leave an empty level-2 range so the next step moves on to level 3.
+        if (eff >= 5) {
+            const int code = kmer5_code(pre8);
+            if (code >= 0 && !((ix.win_kmer5[(size_t)w * 32 + (code >> 5)] >> (code & 31)) & 1u)) {
+                level = 2; cn_cur = cn_end; sc_pos = sc_end = 0;
+            }
+        }
     };
     // the current scan range is used up: move through the hierarchy until a non-empty range or the end
     auto next_range = [&]() {
@@ -455,11 +476,15 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
     };
 
     for (;;) {
-        // ---- pick the fullest phase (wave-uniform) ----
+        // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
         if (!(bf | bs | bd)) break;
         const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
+#ifdef GROOT_WORK_COUNTERS
+        if (phase == run) dbg[run == PH_FETCH ? 0 : (run == PH_SCAN ? 1 : 2)]++;   // lane steps per phase
+        if (phase == run && run == PH_DFS && dist == 0) dbg[3]++;                  // performAlignment calls
+#endif
         if (phase != run) continue;
 
         if (run == PH_FETCH) {
@@ -505,8 +530,7 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
             cn_end = ix.win_cn_off[w + 1];
             begin_orientation(0);
         } else if (run == PH_SCAN) {
-            GROOT_COUNT(0);
-            if (sc_pos >= sc_end) { next_range(); continue; }
+            if (sc_pos >= sc_end) { next_range(); continue; }   // only after a DFS that used the range's last offset
             // up to 12 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
             const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
             const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
@@ -526,31 +550,37 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
             uint32_t j = 12;
             if (c_lo) j = (uint32_t)__builtin_ctzll(c_lo) >> 3;
             else if (c_hi) j = 8 + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
-            if (j >= npos) { sc_pos += npos; continue; }
+            if (j >= npos) {
+                sc_pos += npos;
+                if (sc_pos >= sc_end) next_range();           // set up the next range now: no empty step
+                continue;
+            }
             // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
             const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
             const uint32_t off = sc_pos + j;
             sc_pos = off + 1;
-            if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) continue;
+            if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
+                if (sc_pos >= sc_end) next_range();
+                continue;
+            }
             node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
             cur8 = pre8;
 #pragma unroll
             for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
             phase = PH_DFS;
-            GROOT_COUNT(1);
         } else {
             // ---- DFS: match up to 16 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
-            GROOT_COUNT(2);
             RecRegs<PW> rec;
             rec.load(recs + cur);
             const uint32_t take = min(rec.seq_len() - coff, eff - dist);
-            const uint32_t nb = min(take, 16u);
+            const uint32_t nb = min(take, 32u);
             bool ok = true;
             if (nb) {
                 const uint8_t *gb = ix.bases + rec.seq_off() + coff;
                 const uint64_t ga = coff == 0 ? rec.first8() : ld8(gb);
                 ok = prefix_ok(ga, cur8, min(nb, 8u));
-                if (ok && nb > 8) ok = prefix_ok(ld8(gb + 8), read_chunk(p, len, rc, clip_lo, dist + 8), nb - 8);
+                for (uint32_t i = 8; ok && i < nb; i += 8)
+                    ok = prefix_ok(ld8(gb + i), read_chunk(p, len, rc, clip_lo, dist + i), nb - i);
             }
             bool backtrack = !ok;
             if (ok) {
@@ -610,7 +640,6 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 #pragma unroll
                                 for (int i = 0; i < PW; i++) a.stk_mask[si * PW + i] = mask[i];
                                 sp++;
-                                GROOT_COUNT(3);
                             }
                             if (rdeg <= 4) {                   // select, not index: keeps the record in registers
                                 cur = rec.edge(0);
