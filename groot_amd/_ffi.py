@@ -15,7 +15,7 @@ u8p, u32p, u64p, f64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint6
 
 
 class IndexView(C.Structure):
-    """groot_index_view (include/groot_index.h); oracle_index has the same layout."""
+    """groot_index_view (include/groot_index.h)"""
 
     _scalars32 = ["kmer_size", "sketch_size", "window_size", "num_part", "max_k", "num_window_kmers", "path_words",
                   "reserved0", "n_graphs", "n_nodes", "n_edges", "n_paths", "n_windows", "reserved1"]

@@ -127,3 +127,105 @@ def window_sketch(seq, k, s):
 def msa_files(msa_dir):
     """cluster*.msa in filepath.Glob (lexical) order: cmd/index.go:143"""
     return sorted(glob.glob(os.path.join(msa_dir, "cluster*.msa")))
+
+
+# ---- FASTQ in / BAM + GFA out (host side of `groot align`) ------------------------------------------
+class AlnRecord(C.Structure):
+    """groot_aln_record"""
+    _fields_ = [("name", C.c_char_p), ("name_len", C.c_uint32), ("seq", C.POINTER(C.c_uint8)), ("qual", C.POINTER(C.c_uint8)),
+                ("seq_len", C.c_uint32), ("ref_id", C.c_uint32), ("pos", C.c_uint32), ("start_clip", C.c_uint8),
+                ("end_clip", C.c_uint8), ("reverse", C.c_uint8), ("secondary", C.c_uint8)]
+
+
+class FastqReader:
+    """DataStreamer + FastqHandler (src/pipeline/sketch.go:41-77,175-238): batches of reads from FASTQ files"""
+
+    def __init__(self, files):
+        self._h = C.c_void_p()
+        arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+        _check(lib().groot_fastq_open(arr, C.c_uint32(len(files)), C.byref(self._h)))
+
+    def batches(self, max_reads=1 << 16, max_bases=1 << 24, max_name_bytes=1 << 23):
+        L = lib()
+        L.groot_fastq_next_batch.restype = C.c_int64
+        seq = np.empty(max_bases, dtype=np.uint8)
+        qual = np.empty(max_bases, dtype=np.uint8)
+        names = np.empty(max_name_bytes, dtype=np.uint8)
+        soff = np.empty(max_reads + 1, dtype=np.uint64)
+        noff = np.empty(max_reads + 1, dtype=np.uint64)
+        while True:
+            n = L.groot_fastq_next_batch(self._h, C.c_uint32(max_reads), _ffi.as_ptr(seq, C.c_uint8), _ffi.as_ptr(qual, C.c_uint8),
+                                         _ffi.as_ptr(soff, C.c_uint64), C.c_uint64(max_bases), names.ctypes.data_as(C.c_char_p),
+                                         _ffi.as_ptr(noff, C.c_uint64), C.c_uint64(max_name_bytes))
+            _check(int(n))
+            if n == 0:
+                return
+            nb, nn = int(soff[n]), int(noff[n])
+            yield {"n": int(n), "seq": seq[:nb].copy(), "qual": qual[:nb].copy(), "seq_off": soff[: n + 1].copy(),
+                   "names": names[:nn].copy(), "name_off": noff[: n + 1].copy()}
+
+    def close(self):
+        if self._h:
+            lib().groot_fastq_close(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class BamWriter:
+    """setupBAM + the record collector of theBoss (src/pipeline/boss.go:45-105,225-240)"""
+
+    def __init__(self, path, index, date=None):
+        self._h = C.c_void_p()
+        self.index = index
+        _check(lib().groot_bam_open(path.encode() if path else None, C.byref(index.view), date.encode() if date else None,
+                                    C.byref(self._h)))
+
+    def write(self, alns, batch, first_read_id=0):
+        """alns: expanded records (ALN_DTYPE) of reads held in `batch` (a FastqReader batch dict).
+        Seq/Qual of a reverse-complemented read are the reverse complement / reverse (seqio.go:120-133);
+        a start-clipped record still carries read.Seq[0:seqLen] (alignment.go:120)."""
+        comp = np.zeros(256, dtype=np.uint8)
+        for a, b in zip(b"ACGTN", b"TGCAN"):
+            comp[a] = b
+        recs = (AlnRecord * len(alns))()
+        keep = []
+        for i, a in enumerate(alns):
+            r = int(a["read_id"]) - first_read_id
+            s0, s1 = int(batch["seq_off"][r]), int(batch["seq_off"][r + 1])
+            n0, n1 = int(batch["name_off"][r]), int(batch["name_off"][r + 1])
+            seq, qual = batch["seq"][s0:s1], batch["qual"][s0:s1]
+            if a["rc"]:
+                seq, qual = comp[seq][::-1], qual[::-1]
+            seq_len = (s1 - s0) - int(a["start_clip"]) - int(a["end_clip"])
+            seq = np.ascontiguousarray(seq[:seq_len])
+            qual = np.ascontiguousarray(qual[:seq_len])
+            name = bytes(batch["names"][n0:n1])
+            keep.append((seq, qual, name))
+            recs[i] = AlnRecord(name, len(name), _ffi.as_ptr(seq, C.c_uint8), _ffi.as_ptr(qual, C.c_uint8), seq_len, int(a["ref_id"]),
+                                int(a["pos"]), int(a["start_clip"]), int(a["end_clip"]), int(a["rc"]), int(a["secondary"]))
+        _check(lib().groot_bam_write(self._h, recs, C.c_uint64(len(alns))))
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            _check(lib().groot_bam_close(h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                self.close()
+            except Exception:
+                pass
+
+
+def save_gfa(index, graph, kmer_freq, path_kept, node_removed, total_kmers, file_name, timestamp=None):
+    """GrootGraph.SaveGraphAsGFA (src/graph/graphio.go:19-112); returns True if a file was written"""
+    kf = np.ascontiguousarray(kmer_freq, dtype=np.float64)
+    pk = np.ascontiguousarray(path_kept, dtype=np.uint8)
+    nr = np.ascontiguousarray(node_removed, dtype=np.uint8)
+    written = C.c_int(0)
+    _check(lib().groot_host_save_gfa(C.byref(index.view), C.c_uint32(graph), _ffi.as_ptr(kf, C.c_double), _ffi.as_ptr(pk, C.c_uint8),
+                                     _ffi.as_ptr(nr, C.c_uint8), C.c_uint64(total_kmers), timestamp.encode() if timestamp else None,
+                                     file_name.encode(), C.byref(written)))
+    return bool(written.value)

@@ -554,6 +554,24 @@ static uint32_t align_read(oracle_run *r, uint32_t read_id, const uint8_t *read,
     return n;
 }
 
+uint32_t oracle_align_read(const oracle_index *idx, const uint8_t *read, uint32_t len, int rc, uint32_t window,
+                           oracle_aln *out, uint32_t cap)
+{
+    oracle_run *r = calloc(1, sizeof *r);
+    r->idx = idx;
+    vec_init(&r->seeds, sizeof(oracle_seed));
+    vec_init(&r->alns, sizeof(oracle_aln));
+    vec_init(&r->sketches, sizeof(uint64_t));
+    vec_init(&r->trav_nodes, sizeof(uint32_t));
+    vec_init(&r->trav_off, sizeof(uint32_t));
+    uint32_t n = align_read(r, 0, read, (int)len, rc, window);
+    for (uint32_t i = 0; i < n && i < cap; i++) out[i] = ((oracle_aln *)r->alns.p)[i];
+    vec_free(&r->alns); vec_free(&r->trav_nodes); vec_free(&r->trav_off);
+    free(r->path_buf);
+    free(r);
+    return n;
+}
+
 /* graph.go:401-451 IncrementSubPath (ContainedNodes iterated in ascending SegmentID) */
 static void increment_sub_path(const oracle_index *ix, uint32_t w, double num_kmers, double *kf, uint64_t *kt)
 {

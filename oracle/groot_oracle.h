@@ -105,6 +105,11 @@ void   oracle_lshe_free(oracle_lshe *);
 uint32_t oracle_lshe_query(const oracle_lshe *, const uint64_t *sig, int query_size, double threshold,
                            uint32_t *out, uint32_t cap);
 
+/* ---- src/graph/alignment.go:13-159 AlignRead for one (already oriented) read against one seed window
+ * (the call alignment_test.go:70-94 makes).  Returns the number of records; at most cap are written. */
+uint32_t oracle_align_read(const oracle_index *idx, const uint8_t *read, uint32_t len, int rc, uint32_t window,
+                           oracle_aln *out, uint32_t cap);
+
 /* ---- whole path: boss.go:108-242 + graphminion.go:46-102 + alignment.go:13-317 ---- */
 oracle_run *oracle_run_new(const oracle_index *idx, double containment_threshold, int no_exact_align);
 void oracle_run_free(oracle_run *);

@@ -98,6 +98,17 @@ def containment(q, x, q_size, x_size):
     return lib().oracle_containment(_p(q, C.c_uint64), _p(x, C.c_uint64), len(q), q_size, x_size)
 
 
+def align_read(index, read, window, rc=False):
+    """AlignRead (alignment.go:13-159) of one oriented read against one seed window"""
+    b = np.frombuffer(bytes(read), dtype=np.uint8)
+    cap = 4096
+    out = np.zeros(cap, dtype=ALN_DTYPE)
+    n = lib().oracle_align_read(C.cast(C.byref(index.view), C.c_void_p), _p(b, C.c_uint8), C.c_uint32(len(b)),
+                                C.c_int(1 if rc else 0), C.c_uint32(window), out.ctypes.data_as(C.c_void_p), C.c_uint32(cap))
+    assert n <= cap
+    return out[:n].copy()
+
+
 class Lshe:
     def __init__(self, sketches, s, num_part, max_k, num_window_kmers):
         self.sk = np.ascontiguousarray(sketches, dtype=np.uint64).reshape(-1)

@@ -1,0 +1,113 @@
+"""Shared fixtures.  `-m "not gpu"` runs here on the CPU (oracle, host logic, ABI); `-m gpu` tests are
+the parity tests proper and call the HIP path through the C ABI."""
+import gzip
+import os
+import sys
+import tarfile
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+DATA = os.path.join(REPO, "tests", "golden", "data")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (HIP path through libgroot_hip.so)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def native_libs():
+    """host library + oracle are needed by every test; both build in seconds"""
+    import __graft_entry__ as g
+
+    g.build_host()
+    g.build_oracle()
+
+
+@pytest.fixture(scope="session")
+def hip_lib(native_libs):
+    import __graft_entry__ as g
+
+    return g.build_hip()
+
+
+def read_fastq(path):
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    return [(lines[i][1:], lines[i + 1], lines[i + 3]) for i in range(0, len(lines) - 3, 4)]
+
+
+@pytest.fixture(scope="session")
+def msa_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("argannot")
+    with tarfile.open(os.path.join(DATA, "arg-annot.90.tar.gz")) as tf:
+        members = [m for m in tf.getmembers() if os.path.basename(m.name).startswith("cluster") and m.name.endswith(".msa")]
+        tf.extractall(d, members=members)
+    return os.path.join(d, "arg-annot.90")
+
+
+@pytest.fixture(scope="session")
+def argannot_index(msa_dir):
+    """arg-annot.90 with the `groot index` defaults k=31 s=21 w=100 x=8 y=4 (cmd/index.go:45-49)"""
+    from groot_amd import host
+
+    cache = os.path.join(REPO, "build", "arg-annot.90.k31.s21.w100.gidx")
+    if os.path.exists(cache):
+        try:
+            return host.Index.load(cache)
+        except Exception:
+            pass
+    idx = host.Index.from_msa_dir(msa_dir)
+    try:
+        idx.save(cache)
+    except Exception:
+        pass
+    return idx
+
+
+@pytest.fixture(scope="session")
+def small_index(msa_dir):
+    """first 24 clusters (lexical order) of arg-annot.90"""
+    from groot_amd import host
+
+    return host.Index.from_msa_files(host.msa_files(msa_dir)[:24])
+
+
+@pytest.fixture(scope="session")
+def testgfa_index():
+    """the reference's src/graph/test.gfa (6 Bla-B alleles) windowed with small parameters"""
+    from groot_amd import host
+
+    return host.Index.from_gfa_files([os.path.join(DATA, "test.gfa")], host.index_params(k=7, s=10, w=30))
+
+
+@pytest.fixture(scope="session")
+def genes_index():
+    """src/pipeline/test-data/test-genes.msa with the parameters of 1_pipeline_test.go:32-40"""
+    from groot_amd import host
+
+    return host.Index.from_msa_files([os.path.join(DATA, "test-genes.msa")], host.index_params(k=51, s=30, w=100))
+
+
+@pytest.fixture(scope="session")
+def perfect_reads():
+    return read_fastq(os.path.join(DATA, "full-argannot-perfect-reads-small.fq.gz"))
+
+
+@pytest.fixture(scope="session")
+def variable_reads():
+    return read_fastq(os.path.join(DATA, "full-argannot-perfect-reads-small-variable-rl.fq.gz"))
+
+
+@pytest.fixture(scope="session")
+def oxa_reads():
+    return read_fastq(os.path.join(DATA, "test-reads-OXA90-OXA106-100bp-with-errors.fastq.gz"))
+
+
+def digest(arr):
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()

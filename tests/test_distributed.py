@@ -1,0 +1,90 @@
+"""N>1 path on CPU: world_size 2 over gloo.  Each rank handles its shard of the reads (here through
+the oracle, standing in for its GPU) and the call-count table + counters are all-reduced exactly as
+bench.py does over RCCL; the reduced result must equal the single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, msa_files, n_reads, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from groot_amd import host, multi, synth
+    from oracle import oracle_py as O
+
+    index = host.Index.from_msa_files(msa_files)          # replicated index
+    cat, off, lens = synth.reference_sequences(index)
+    lo, hi = multi.shard_range(n_reads, rank, world)
+    seq, so, _ = synth.reads_np(cat, off, lens, hi - lo, 100, first=lo)
+    run = O.Run(index)
+    run.batch(seq, so, first_read_id=lo)
+    att = run.attempts()
+    n_q = 256 - index.view.kmer_size + 2                  # table shape of a ctx opened with max_read_len=256
+    full = np.zeros((n_q, index.view.n_windows), dtype=np.int64)
+    full[: att.shape[0]] = att
+    t = torch.from_numpy(full)
+    multi.reduce_attempts(dist, t)
+    counts = multi.reduce_counts(dist, run.counts())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "att.npy"), t.numpy())
+        np.save(os.path.join(out_dir, "counts.npy"), np.array([counts[k] for k in multi.COUNT_KEYS]))
+    al = run.alns()
+    np.save(os.path.join(out_dir, f"alns{rank}.npy"), al)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from groot_amd import multi
+
+    for n, w in [(10, 3), (7, 8), (0, 2), (100, 4)]:
+        spans = [multi.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one(msa_dir, tmp_path):
+    from groot_amd import device, host, multi, synth
+    from oracle import oracle_py as O
+
+    files = host.msa_files(msa_dir)[:24]
+    n_reads = 3000
+    mp.spawn(_worker, args=(2, _free_port(), files, n_reads, str(tmp_path)), nprocs=2, join=True)
+    index = host.Index.from_msa_files(files)
+    cat, off, lens = synth.reference_sequences(index)
+    seq, so, _ = synth.reads_np(cat, off, lens, n_reads, 100)
+    run = O.Run(index)
+    run.batch(seq, so)
+    att = run.attempts()
+    got = np.load(os.path.join(tmp_path, "att.npy"))
+    assert np.array_equal(got[: att.shape[0]], att) and not got[att.shape[0]:].any()
+    counts = np.load(os.path.join(tmp_path, "counts.npy"))
+    c1 = run.counts()
+    assert counts.tolist() == [c1[k] for k in multi.COUNT_KEYS]
+    # weights from the reduced table = single-process canonical weights (independent of the GPU count)
+    kf, kt = device.weights(index, got.astype(np.uint32))
+    kf1, kt1 = run.weights(order=1)
+    assert np.array_equal(kf, kf1) and np.array_equal(kt, kt1)
+    # alignment records of the shards, concatenated in rank order, are the single-process records
+    al = np.concatenate([np.load(os.path.join(tmp_path, f"alns{r}.npy")) for r in range(2)])
+    assert np.array_equal(al, run.alns())

@@ -1,0 +1,298 @@
+"""Parity tests proper: the HIP path (through the C ABI of libgroot_hip.so) against the CPU oracle on
+the same inputs -- bit-exact sketches, seed sets, alignment records, IncrementSubPath call counts,
+counters, graph weights and pruning -- plus size-independent properties at BASELINE.json's full size."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, digest
+from groot_amd import device, host, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(hip_lib):
+    assert device.device_count() > 0, "no MI355X visible: the HIP path has no CPU fallback"
+
+
+def run_both(index, seq, off, threshold=0.99, no_align=False, first=0, **kw):
+    al = device.Aligner(index, threshold=threshold, no_align=no_align, keep_sketches=True,
+                        max_batch_reads=max(1024, len(off) - 1), **kw)
+    al.submit(seq, off, first_read_id=first)
+    counts = al.wait()
+    run = O.Run(index, threshold, no_align)
+    run.batch(seq, off, first_read_id=first)
+    return al, counts, run
+
+
+def assert_same(al, counts, run, index):
+    oc = run.counts()
+    for k in ("received", "mapped", "multimapped", "alignments", "seeds", "revcomp_panics"):
+        assert counts[k] == oc[k], (k, counts[k], oc[k])
+    assert np.array_equal(al.sketches(), run.sketches())
+    assert np.array_equal(al.seeds(), run.seeds().astype(device.SEED_DTYPE))
+    got, exp = al.alns(), run.alns()
+    assert len(got) == len(exp)
+    for f in exp.dtype.names:
+        assert np.array_equal(got[f], exp[f]), f
+    att, oatt = al.attempts(), run.attempts()
+    assert np.array_equal(att[: oatt.shape[0]], oatt) and not att[oatt.shape[0]:].any()
+    kf, kt = device.weights(index, att)
+    okf, okt = run.weights(order=1)
+    assert np.array_equal(kf, okf) and np.array_equal(kt, okt)
+    return got
+
+
+def pack(reads):
+    return O.pack_reads([r[1] for r in reads])
+
+
+def test_perfect_reads_fixture_and_golden(argannot_index, perfect_reads):
+    seq, off = pack(perfect_reads)
+    al, counts, run = run_both(argannot_index, seq, off)
+    assert_same(al, counts, run, argannot_index)
+    exp = json.load(open(GOLDEN))["perfect_reads_small@arg-annot.90(k31,s21,w100),t0.99"]
+    assert digest(al.sketches()) == exp["sketches"]
+    assert digest(al.seeds().astype(O.SEED_DTYPE)) == exp["seeds"]
+    assert digest(al.alns().astype(O.ALN_DTYPE)) == exp["alns"]
+    kf, kt = device.weights(argannot_index, al.attempts())
+    assert digest(kf) == exp["kmer_freq"] and digest(kt) == exp["kmer_total"]
+    assert {k: counts[k] for k in ("received", "mapped", "multimapped", "alignments", "seeds")} == \
+           {k: exp["counts"][k] for k in ("received", "mapped", "multimapped", "alignments", "seeds")}
+    al.close()
+
+
+@pytest.mark.parametrize("threshold", [0.99, 0.90])
+def test_variable_length_reads_general_lsh_path(argannot_index, variable_reads, threshold):
+    """50-100 bp reads: kmerCount < NumWindowKmers, so hits need fewer than all slots equal and the LSH
+    forest (K, L) prefix search is used instead of the exact-sketch table; seed lists overflow their slots"""
+    seq, off = pack(variable_reads)
+    al, counts, run = run_both(argannot_index, seq, off, threshold=threshold, max_seeds_per_read=2)
+    assert_same(al, counts, run, argannot_index)
+    key = f"perfect_reads_small_variable_rl@arg-annot.90,t{threshold:.2f}"
+    assert digest(al.alns().astype(O.ALN_DTYPE)) == json.load(open(GOLDEN))[key]["alns"]
+    al.close()
+
+
+def test_reads_with_errors_and_clipping(genes_index, oxa_reads):
+    """src/pipeline/3_sketch_test.go input (k=51, s=30): failing seeds, level-3/4 hard clips, pruning"""
+    seq, off = pack(oxa_reads)
+    al, counts, run = run_both(genes_index, seq, off)
+    got = assert_same(al, counts, run, genes_index)
+    assert got["start_clip"].any() and got["end_clip"].any()
+    kf, kt = device.weights(genes_index, al.attempts())
+    gk, pk, nr = device.prune(genes_index, kf, 10.0)
+    kept = [genes_index.path_name(i) for i in range(genes_index.view.n_paths) if pk[i]]
+    assert "argannot~~~(Bla)OXA-90~~~EU547443:1-825" in kept and gk.tolist() == [1]
+    al.close()
+
+
+def test_config0_synthetic_10k(argannot_index):
+    """BASELINE configs[0]: 10k synthetic 100 bp reads on arg-annot.90"""
+    cat, o, lens = synth.reference_sequences(argannot_index)
+    seq, off, truth = synth.reads_np(cat, o, lens, 10_000, 100)
+    al, counts, run = run_both(argannot_index, seq, off, first=777)
+    got = assert_same(al, counts, run, argannot_index)
+    have = set(zip(got["read_id"].tolist(), got["ref_id"].tolist(), got["pos"].tolist(), got["rc"].tolist()))
+    hits = sum((777 + i, int(truth["seq"][i]), int(truth["start"][i]), int(truth["strand"][i])) in have for i in range(10_000))
+    assert hits >= 9900
+    al.close()
+
+
+def test_small_graph_fixture_all_windows(testgfa_index):
+    """src/graph/test.gfa (k=7, s=10, w=30): every window of every path, both strands, plus shifted reads"""
+    idx = testgfa_index
+    reads = []
+    for p in range(6):
+        s = idx.path_sequence(0, p)
+        for i in range(0, len(s) - 30, 3):
+            r = s[i:i + 30]
+            reads.append(r)
+            reads.append(O.revcomp(r)[0])
+            reads.append(s[i:i + 25])      # shorter than the window
+    seq, off = O.pack_reads(reads)
+    for t in (0.99, 0.8):
+        al, counts, run = run_both(idx, seq, off, threshold=t, max_seeds_per_read=1)
+        assert_same(al, counts, run, idx)
+        assert counts["alignments"] > len(reads)
+        al.close()
+
+
+def test_edge_cases(small_index):
+    cat, o, lens = synth.reference_sequences(small_index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 64, 100)
+    base = [bytes(seq[int(off[i]):int(off[i + 1])]) for i in range(64)]
+    k = small_index.view.kmer_size
+    reads = list(base)
+    reads[3] = reads[3][:50] + b"N" + reads[3][51:]           # N in the read: matches only a graph N
+    reads[4] = b"N" * 100
+    reads[5] = reads[5][:k]                                    # exactly one k-mer
+    reads[6] = reads[6] + reads[7]                             # 200 bp: longer than the window
+    reads[8] = b"ACGT" * 25                                    # low complexity
+    reads[9] = reads[9][:99]                                   # ragged lengths
+    reads[10] = reads[10][:31] + b"R" + reads[10][32:]         # IUPAC code <= 'T': complement is 0
+    seq2, off2 = O.pack_reads(reads)
+    al, counts, run = run_both(small_index, seq2, off2)
+    assert_same(al, counts, run, small_index)
+    # empty batch
+    al.submit(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    c = al.wait()
+    assert c["received"] == 0 and len(al.seeds()) == 0 and len(al.travs()[0]) == 0
+    al.close()
+
+
+def test_error_behaviour_matches_reference_panics(small_index):
+    cat, o, lens = synth.reference_sequences(small_index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)
+    reads = [bytes(seq[int(off[i]):int(off[i + 1])]) for i in range(32)]
+    # a read shorter than k: NewHasher error -> panic (boss.go:164-166)
+    al = device.Aligner(small_index, max_batch_reads=1024)
+    s2, o2 = O.pack_reads(reads[:5] + [reads[5][:10]] + reads[6:])
+    al.submit(s2, o2)
+    with pytest.raises(host.GrootError) as e:
+        al.wait()
+    assert e.value.code == -7
+    with pytest.raises(ValueError):
+        run = O.Run(small_index)
+        run.batch(s2, o2)
+    # lower-case read: sketches like upper case (seedTab), fails forward alignment, RevComplement panics (seqio.go:126)
+    strand0 = [i for i in range(32) if True][0]
+    s3, o3 = O.pack_reads([reads[strand0].lower()] + reads[1:])
+    al.attempts_reset()
+    al.submit(s3, o3)
+    with pytest.raises(host.GrootError) as e:
+        al.wait()
+    assert e.value.code == -8
+    c = al.wait(check=False)
+    run = O.Run(small_index)
+    run.batch(s3, o3)
+    assert c["revcomp_panics"] == run.counts()["revcomp_panics"] >= 1
+    assert np.array_equal(al.seeds(), run.seeds().astype(device.SEED_DTYPE))
+    # a read longer than max_read_len is refused, not truncated
+    al2 = device.Aligner(small_index, max_batch_reads=1024, max_read_len=120)
+    s4, o4 = O.pack_reads(reads[:3] + [reads[3] + reads[4]])
+    al2.submit(s4, o4)
+    with pytest.raises(host.GrootError) as e:
+        al2.wait()
+    assert e.value.code == -6
+    # too many reads for the ctx
+    with pytest.raises(host.GrootError):
+        al2.submit(*O.pack_reads(reads * 40))
+    al.close(); al2.close()
+
+
+def test_no_align_mode_and_batch_accumulation(small_index):
+    """--noAlign: every seed is weighted, nothing is aligned (graphminion.go:70-72); weights add up over batches"""
+    cat, o, lens = synth.reference_sequences(small_index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 3000, 100)
+    al, counts, run = run_both(small_index, seq, off, no_align=True)
+    assert_same(al, counts, run, small_index)
+    assert counts["alignments"] == 0 and counts["travs"] == 0
+    al.close()
+    al = device.Aligner(small_index, max_batch_reads=1024)
+    run = O.Run(small_index)
+    for b in range(3):
+        lo, hi = b * 1000, (b + 1) * 1000
+        s = seq[int(off[lo]):int(off[hi])]
+        o2 = off[lo:hi + 1] - off[lo]
+        al.submit(s, o2, first_read_id=lo)
+        al.wait()
+        run.batch(s, o2, first_read_id=lo)
+    att, oatt = al.attempts(), run.attempts()
+    assert np.array_equal(att[: oatt.shape[0]], oatt)
+    al.close()
+
+
+def test_sketch_mirror_of_run_minhash(small_index, genes_index, testgfa_index):
+    """groot_hip_sketch = Sequence.RunMinHash(k, s, false, nil) for several (k, s)"""
+    rng = np.random.default_rng(7)
+    for idx in (small_index, genes_index, testgfa_index):
+        k, s = idx.view.kmer_size, idx.view.sketch_size
+        seqs = [bytes(rng.choice(list(b"ACGT"), size=int(n)).astype(np.uint8)) for n in rng.integers(k, 250, size=300)]
+        seqs += [b"ACGTN" * 20, b"acgtacgtnn" * 10, bytes(range(48, 48 + 80))]
+        seqs = [x for x in seqs if len(x) >= k]
+        cat, off = O.pack_reads(seqs)
+        al = device.Aligner(idx, max_batch_reads=1024)
+        got = al.sketch(cat, off)
+        for i, x in enumerate(seqs):
+            assert np.array_equal(got[i], O.khf_sketch(x, k, s)), (k, s, i)
+        al.close()
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_properties(argannot_index):
+    """BASELINE configs[2] size (10M x 100 bp) through size-independent properties: determinism, batch-split
+    invariance (checksum of checksums), truth containment, and an oracle comparison on a random sample"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    cat, o, lens = synth.reference_sequences(argannot_index)
+    cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, o, lens))
+    R, L = 10_000_000, 100
+    parts = []
+    for c0 in range(0, R, 1_000_000):
+        p, _, _ = synth.reads_torch(cat_t, off_t, lens_t, 1_000_000, L, first=c0)
+        parts.append(p[: 1_000_000 * L])
+    d_seq = torch.zeros(R * L + 64, dtype=torch.uint8, device=dev)
+    d_seq[: R * L] = torch.cat(parts)
+    del parts
+    d_off = torch.arange(0, R + 1, dtype=torch.int64, device=dev) * L
+    torch.cuda.synchronize()
+    al = device.Aligner(argannot_index, max_batch_reads=R, max_batch_bases=R * L + 64)
+
+    def run(lo, hi):
+        # offsets are absolute into d_seq, so a sub-batch is just a window of the offset array
+        al.submit_device(d_seq.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, first_read_id=lo, max_len=L)
+        c = al.wait()
+        t, m = al.travs()
+        return c, t, m
+
+    c1, t1, m1 = run(0, R)
+    att1 = al.attempts()
+    al.attempts_reset()
+    c2, t2, m2 = run(0, R)
+    assert c1 == c2 and np.array_equal(t1, t2) and np.array_equal(m1, m2)          # deterministic
+    assert np.array_equal(att1, al.attempts())
+    assert c1["received"] == R and c1["mapped"] > 0.99 * R and c1["travs"] == len(t1)
+    assert np.all(np.diff(t1["read_id"].astype(np.int64)) >= 0)                    # canonical read order
+    # batch-split invariance: 4 unequal batches give the same records and the same call counts
+    al.attempts_reset()
+    cuts = [0, 1_000_000, 3_500_000, 3_500_001, R]
+    ts, ms, tot = [], [], {k: 0 for k in c1}
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        c, t, m = run(lo, hi)
+        ts.append(t); ms.append(m)
+        for k in tot:
+            tot[k] += c[k]
+    assert tot == c1
+    assert digest(np.concatenate(ts)) == digest(t1) and digest(np.concatenate(ms)) == digest(m1)
+    assert np.array_equal(att1, al.attempts())
+    # truth containment on the expanded records of a slice
+    sl = slice(0, int(np.searchsorted(t1["read_id"], 200_000)))
+    recs = device.expand_alns(argannot_index, t1[sl], m1[sl])
+    truth = synth.plan_np(lens, 200_000, L)
+    have = set(zip(recs["read_id"].tolist(), recs["ref_id"].tolist(), recs["pos"].tolist(), recs["rc"].tolist()))
+    hits = sum((i, int(truth[0][i]), int(truth[1][i]), int(truth[2][i])) in have for i in range(200_000))
+    assert hits >= 0.995 * 200_000
+    # oracle on a random sample of reads
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(R, 20_000, replace=False))
+    host_seq = d_seq[: R * L].view(R, L)[torch.from_numpy(pick).to(dev)].cpu().numpy().reshape(-1)
+    orun = O.Run(argannot_index)
+    orun.batch(host_seq, np.arange(0, 20_001, dtype=np.uint64) * L)
+    oal = orun.alns()
+    full = device.expand_alns(argannot_index, t1, m1) if len(t1) < 20_000_000 else None
+    sel = np.isin(full["read_id"], pick)
+    got = full[sel]
+    remap = np.searchsorted(pick, got["read_id"])
+    assert len(got) == len(oal)
+    assert np.array_equal(remap, oal["read_id"])
+    for f in ("graph_id", "path_id", "ref_id", "pos", "start_clip", "end_clip", "rc", "secondary"):
+        assert np.array_equal(got[f], oal[f]), f
+    al.close()
