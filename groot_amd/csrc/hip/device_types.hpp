@@ -80,6 +80,7 @@ struct SeedArgs {
     uint32_t *seed_count;        // [n_reads]
     uint32_t *seed_win;          // [H][n_reads] slot-major
     uint64_t *sketch_out;        // [n_reads*s] or null
+    uint32_t *sort_key;          // [n_reads] (first seed window << 1 | likely reverse), kEmpty without seeds; or null
     DeviceCounters *ctr;
 };
 
@@ -91,6 +92,7 @@ struct AlignArgs {
     uint32_t seed_slots;
     const uint32_t *seed_count;
     const uint32_t *seed_win;
+    const uint32_t *perm;        // [n_reads] processing order (reads sorted by sort_key) or null
     uint32_t no_align, update_weights;
     const void *node_rec;        // NodeRec<pw>[n_nodes]
     uint32_t *attempts;          // [(max_q+1)*n_windows]
@@ -107,6 +109,7 @@ struct AlignArgs {
     uint64_t *stk_hdr;
     uint64_t *stk_mask;          // [(d*n_threads + t)*pw + word]
     uint32_t n_threads, stk_depth;
+    uint32_t lds_stride_dw;      // dwords of LDS per lane for the staged read (odd), 0 = reads stay in global memory
     DeviceCounters *ctr;
 };
 

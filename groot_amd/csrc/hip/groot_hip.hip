@@ -67,7 +67,8 @@ struct groot_ctx {
     uint32_t n_reads = 0, first_read_id = 0, batch_max_len = 0;
     bool submitted = false, finished = false;
     uint32_t seed_slots = 0;
-    DevBuf<uint32_t> seed_count, seed_win;
+    DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm;
+    DevBuf<char> sort_tmp;
     DevBuf<uint64_t> sketches;
     DevBuf<DeviceCounters> ctr;
     DeviceCounters hctr{};
@@ -292,10 +293,13 @@ static void launch_seed(uint32_t s, const SeedArgs &a, bool dump, dim3 grid, siz
 
 static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
 {
-    switch (pw) {
-    case 3: hipLaunchKernelGGL((align_kernel<3>), grid, dim3(kBlock), 0, st, a); break;
-    case 11: hipLaunchKernelGGL((align_kernel<11>), grid, dim3(kBlock), 0, st, a); break;
-    default: break;
+    const size_t lds = a.lds_stride_dw ? (size_t)kBlock * a.lds_stride_dw * 4 + 16 : 0;
+    if (pw == 3) {
+        if (lds) hipLaunchKernelGGL((align_kernel<3, true>), grid, dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((align_kernel<3, false>), grid, dim3(kBlock), 0, st, a);
+    } else if (pw == 11) {
+        if (lds) hipLaunchKernelGGL((align_kernel<11, true>), grid, dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((align_kernel<11, false>), grid, dim3(kBlock), 0, st, a);
     }
 }
 
@@ -341,11 +345,23 @@ static int launch_seed_stage(groot_ctx *c)
     a.seed_count = c->seed_count.p;
     a.seed_win = c->seed_win.p;
     a.sketch_out = c->prm.keep_sketches ? c->sketches.p : nullptr;
+    a.sort_key = c->sort_key.p;
     a.ctr = c->ctr.p;
     const dim3 grid((c->n_reads + kBlock - 1) / kBlock);
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
     launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
+    // processing order of the align stage: reads sorted by (first seed window, likely orientation)
+    unsigned end_bit = 2;
+    for (uint32_t v = c->n_windows; v; v >>= 1) end_bit++;
+    end_bit = std::min(32u, end_bit);
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p, c->n_reads, 0,
+                                         32, c->stream));
+    if (tmp_bytes > c->sort_tmp.n) HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes));
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p,
+                                         c->n_reads, 0, 32, c->stream));
+    (void)end_bit;
     return GROOT_OK;
 }
 
@@ -360,6 +376,7 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     a.seed_slots = c->seed_slots;
     a.seed_count = c->seed_count.p;
     a.seed_win = c->seed_win.p;
+    a.perm = c->perm.p;
     a.no_align = c->prm.no_exact_align;
     a.update_weights = update_weights ? 1 : 0;
     a.attempts = c->attempts_ptr;
@@ -376,6 +393,11 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     const uint32_t blocks = std::min<uint32_t>((c->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
+    // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB (<= 2 workgroups... per CU budget)
+    {
+        const uint32_t stride = ((c->batch_max_len + 16) / 4) | 1u;
+        a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
+    }
     a.ctr = c->ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, kOvfShards * sizeof(uint32_t), c->stream));
     launch_align(c->pw, a, dim3(blocks), c->stream);
@@ -581,6 +603,14 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->seq.alloc(c->prm.max_batch_bases + 64));
     HIP_TRY(c, c->seq_off.alloc((size_t)R + 1));
     HIP_TRY(c, c->seed_count.alloc(R));
+    HIP_TRY(c, c->sort_key.alloc(R));
+    HIP_TRY(c, c->sort_key_out.alloc(R));
+    HIP_TRY(c, c->perm.alloc(R));
+    {
+        std::vector<uint32_t> iota(R);
+        std::iota(iota.begin(), iota.end(), 0u);
+        HIP_TRY(c, upload(c->perm_in, iota.data(), iota.size()));
+    }
     if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
     if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
     HIP_TRY(c, c->ctr.alloc(1));
@@ -744,7 +774,7 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
     }
     c->n_trav = c->hctr.n_trav;
 #ifdef GROOT_WORK_COUNTERS
-    fprintf(stderr, "[groot work] lane_steps fetch=%llu scan=%llu dfs=%llu dfs_calls=%llu\n", c->hctr.dbg[0], c->hctr.dbg[1],
+    fprintf(stderr, "[groot work] wave_iters fetch=%llu scan=%llu dfs=%llu lane_steps=%llu\n", c->hctr.dbg[0], c->hctr.dbg[1],
             c->hctr.dbg[2], c->hctr.dbg[3]);
 #endif
     if (c->profiling) {
@@ -893,7 +923,7 @@ int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     a.seq = c->seq.p; a.seq_off = c->seq_off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
-    a.sketch_out = sk.p; a.ctr = c->ctr.p;
+    a.sketch_out = sk.p; a.sort_key = nullptr; a.ctr = c->ctr.p;
     launch_seed(c->s, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
     HIP_TRY(c, hipGetLastError());
     DeviceCounters h{};

@@ -57,6 +57,19 @@ __host__ __device__ __forceinline__ uint64_t sketch_hash_step(uint64_t h, uint64
 }
 #define GROOT_SKETCH_HASH_INIT 0x9E3779B97F4A7C15ULL
 
+// 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 10-bit code of the first 5 bases of r8,
+// or -1 if one of them is not ACGT (such a base can still meet the graph's 'N' wildcard)
+__host__ __device__ __forceinline__ int kmer5_code(uint64_t r8)
+{
+    int code = 0;
+    for (int i = 0; i < 5; i++) {
+        const unsigned b = (unsigned)(r8 >> (8 * i)) & 0xFF;
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return -1;
+        code |= (int)((b >> 1) & 3) << (2 * i);
+    }
+    return code;
+}
+
 // LDS layout of sketch_seed_kernel (bytes)
 constexpr uint32_t kLdsTabF = 0;                 // u64[256] seedTab[b]
 constexpr uint32_t kLdsTabFout = 2048;           // u64[256] rol(seedTab[b], k)
@@ -130,10 +143,12 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     const uint64_t M = (uint64_t)k * GROOT_MULTI_SEED;
     const uint32_t nk = len - k + 1;
     unsigned high = 0;                       // any byte > 'T': RevComplement would panic (seqio.go:126)
+    uint64_t first5 = 0;                     // first 5 bases of the read (for the scheduling key below)
     auto sketch = [&](const unsigned char *rd) {
         uint64_t fh = 0, rh = 0;
         for (uint32_t j = 0; j < k; j++) {   // ntf64 / ntr64 of the first k-mer in one pass
             const unsigned b = rd[j];
+            if (j < 5) first5 |= (uint64_t)b << (8 * j);
             high |= b > 'T';
             fh = rol1(fh) ^ tabF[b];
             rh ^= rol64(tabC[b & 7], j);
@@ -164,9 +179,11 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     // ---- ContainmentIndex.Query (lshe.go:153-175) ----
     const uint32_t q = nk;                                 // kmerCount, boss.go:169
     const uint32_t min_eq = q <= ix.max_q ? ix.q_min_eq[q] : (uint32_t)S + 1;
+    uint32_t min_win = kEmpty;
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
         n_hits++;
+        min_win = min(min_win, id);
     };
     if (min_eq == (uint32_t)S) {
         // Containment > t needs every slot equal: windows with an identical sketch.  One probe
@@ -234,6 +251,21 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
         }
     }
     a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
+    // scheduling key for the align stage: reads are processed in (first seed window, likely orientation) order so
+    // that neighbouring lanes walk the same graph nodes in step; reads without seeds sort to the end.  Processing
+    // order only -- every output is addressed by read.
+    if (a.sort_key) {
+        uint32_t key = kEmpty;
+        if (n_hits) {
+            uint32_t likely_rc = 0;
+            if (len >= 5 && k <= len) {
+                const int code = kmer5_code(first5);
+                if (code >= 0) likely_rc = !((ix.win_kmer5[(size_t)min_win * 32 + (code >> 5)] >> (code & 31)) & 1u);
+            }
+            key = (min_win << 1) | likely_rc;
+        }
+        a.sort_key[r] = key;
+    }
     if (n_hits) {
         atomicAdd(&a.ctr->seeds, (unsigned long long)n_hits);
         atomicMax(&a.ctr->max_seeds, n_hits);
@@ -331,20 +363,7 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
 // Per iteration the wave executes only the phase holding the most lanes (ballot + popcount in SALU), so
 // lanes in different reads / levels / depths never serialise each other's loops and every executed
 // instruction runs at the best available lane fill; a lane that finishes a read fetches the next one.
-enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_DONE };
-
-// 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 10-bit code of the first 5 bases of r8,
-// or -1 if one of them is not ACGT (such a base can still meet the graph's 'N' wildcard)
-__host__ __device__ __forceinline__ int kmer5_code(uint64_t r8)
-{
-    int code = 0;
-    for (int i = 0; i < 5; i++) {
-        const unsigned b = (unsigned)(r8 >> (8 * i)) & 0xFF;
-        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return -1;
-        code |= (int)((b >> 1) & 3) << (2 * i);
-    }
-    return code;
-}
+enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
 
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
 __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
@@ -376,11 +395,18 @@ template <int PW> struct RecRegs {
     __device__ __forceinline__ uint64_t mask(int i) const { return (uint64_t)d[10 + 2 * i] | ((uint64_t)d[11 + 2 * i] << 32); }
 };
 
-template <int PW>
+// LDSR: the oriented read of every lane is staged in LDS when its first DFS of that orientation starts
+// (lane-private slice of lds_stride_dw dwords, odd stride = conflict-free across lanes); DFS steps then read
+// their 8-base chunks with three ds_read_b32 + two alignbit instead of going back to the Infinity Cache /
+// HBM for the read's line and re-doing the reverse complement at every step.
+template <int PW, bool LDSR>
 __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 {
     using Rec = NodeRec<PW>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_reads[];
     __shared__ unsigned long long red[4];
+    uint32_t *my_lds = lds_reads + (size_t)threadIdx.x * a.lds_stride_dw;
+    uint32_t lds_rc = 2;                                   // orientation currently staged (2 = none)
     const DeviceIndex &ix = a.ix;
     const Rec *recs = reinterpret_cast<const Rec *>(a.node_rec);
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
@@ -395,7 +421,8 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 #endif
 
     uint32_t phase = PH_FETCH;
-    uint32_t r = gtid - a.n_threads;                       // first fetch adds the stride
+    uint32_t slot = gtid - a.n_threads;                    // first fetch adds the stride
+    uint32_t r = 0;
     // ---- read ----
     bool have_read = false;
     const uint8_t *p = nullptr;
@@ -417,6 +444,15 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 #pragma unroll
     for (int i = 0; i < PW; i++) mask[i] = 0;
 
+    // oriented bases [d, d+8) of the current view during DFS
+    auto dfs_chunk = [&](uint32_t d) -> uint64_t {
+        if (!LDSR) return read_chunk(p, len, rc, clip_lo, d);
+        const uint32_t i = d + clip_lo;
+        const uint32_t *wp = my_lds + (i >> 2);
+        const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2];
+        const uint32_t sh = (i & 3u) * 8u;
+        return (uint64_t)__funnelshift_r(x0, x1, sh) | ((uint64_t)__funnelshift_r(x1, x2, sh) << 32);
+    };
     auto set_view = [&](uint32_t clip_lo_, uint32_t eff_, uint32_t clip_flag) {
         clip_lo = clip_lo_; eff = eff_;
         tflags = (rc ? GROOT_TRAV_RC : 0u) | clip_flag;
@@ -478,31 +514,46 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
     for (;;) {
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
-        if (!(bf | bs | bd)) break;
+        if (!(bf | bs | bd)) {
+            // every lane has finished its read: the wave takes its next 64 reads together.  Reads are sorted by
+            // (first seed window, orientation), so the 64 lanes start each round on near-identical work and stay
+            // in the same phase most of the time.
+            if (!__ballot(phase == PH_WAIT)) break;
+            if (phase == PH_WAIT) phase = PH_FETCH;
+            continue;
+        }
         const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
 #ifdef GROOT_WORK_COUNTERS
-        if (phase == run) dbg[run == PH_FETCH ? 0 : (run == PH_SCAN ? 1 : 2)]++;   // lane steps per phase
-        if (phase == run && run == PH_DFS && dist == 0) dbg[3]++;                  // performAlignment calls
+        if ((threadIdx.x & 63) == 0) dbg[run == PH_FETCH ? 0 : (run == PH_SCAN ? 1 : 2)]++;   // wave iterations per phase
+        if (phase == run) dbg[3]++;                                                              // lane steps
 #endif
         if (phase != run) continue;
 
         if (run == PH_FETCH) {
             if (!have_read) {
-                r += a.n_threads;
-                if (r >= a.n_reads) { phase = PH_DONE; continue; }
+                slot += a.n_threads;
+                if (slot >= a.n_reads) { phase = PH_DONE; continue; }
+                r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
                 const uint32_t sc = a.seed_count[r];
                 cnt = min(sc & 0x7FFFFFFFu, a.seed_slots);   // overflow already flagged; batch is re-run
-                if (cnt == 0) { a.trav_cnt[r] = 0; continue; }
+                if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
                 high_byte = sc >> 31;
                 const uint64_t o0 = a.seq_off[r];
                 len = (uint32_t)(a.seq_off[r + 1] - o0);
                 p = a.seq + o0;
+                if (LDSR && len + 12 > a.lds_stride_dw * 4) {  // longer than the max_len the batch was submitted with
+                    atomicOr(&a.ctr->flags, kFlagLongRead);
+                    a.trav_cnt[r] = 0;
+                    phase = PH_WAIT;
+                    continue;
+                }
                 q = len - ix.k + 1;                           // graphminion.go:60 kmerCount
                 read_id = a.first_read_id + r;
                 n_graphs = 0; ord = 0; last = -1;
                 done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
                 have_read = true;
+                lds_rc = 2;
             }
             // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
             uint32_t nw = kEmpty;
@@ -515,6 +566,7 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
                 mapped++;                                     // boss.go:195-200
                 if (n_graphs > 1) multimapped++;
                 have_read = false;
+                phase = PH_WAIT;
                 continue;
             }
             w = nw; last = nw;
@@ -563,6 +615,14 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
                 if (sc_pos >= sc_end) next_range();
                 continue;
             }
+            if (LDSR && lds_rc != rc) {                        // stage this orientation of the read once
+                for (uint32_t c8 = 0; c8 < len; c8 += 8) {
+                    const uint64_t v = read_chunk(p, len, rc, 0, c8);
+                    my_lds[c8 >> 2] = (uint32_t)v;
+                    my_lds[(c8 >> 2) + 1] = (uint32_t)(v >> 32);
+                }
+                lds_rc = rc;
+            }
             node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
             cur8 = pre8;
 #pragma unroll
@@ -580,12 +640,12 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
                 const uint64_t ga = coff == 0 ? rec.first8() : ld8(gb);
                 ok = prefix_ok(ga, cur8, min(nb, 8u));
                 for (uint32_t i = 8; ok && i < nb; i += 8)
-                    ok = prefix_ok(ld8(gb + i), read_chunk(p, len, rc, clip_lo, dist + i), nb - i);
+                    ok = prefix_ok(ld8(gb + i), dfs_chunk(dist + i), nb - i);
             }
             bool backtrack = !ok;
             if (ok) {
                 dist += nb; coff += nb;
-                cur8 = read_chunk(p, len, rc, clip_lo, dist);
+                cur8 = dfs_chunk(dist);
                 if (nb == take) {                              // node consumed (or read finished)
                     bool any = false;
 #pragma unroll
@@ -663,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
                     dist = (uint32_t)(hdr >> 48);
 #pragma unroll
                     for (int i = 0; i < PW; i++) mask[i] = a.stk_mask[si * PW + i];
-                    cur8 = read_chunk(p, len, rc, clip_lo, dist);
+                    cur8 = dfs_chunk(dist);
                     const Rec &pr = recs[pn];
                     const uint32_t deg = pr.deg;
                     uint32_t more = kEmpty;
