@@ -259,10 +259,10 @@ template <int PW> void build_node_records(const groot_index_view *v, std::vector
 // ---------------------------------------------------------------------------------------------
 // kernel dispatch by (sketch size, maxK) and path words
 // ---------------------------------------------------------------------------------------------
-template <int S, int MAXK> static void launch_seed_sm(const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
+template <int S, int MAXK, int M5> static void launch_seed_sm(const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
 {
-    if (dump) hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, true>), grid, dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, false>), grid, dim3(kBlock), lds, st, a);
+    if (dump) hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, true, M5>), grid, dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, false, M5>), grid, dim3(kBlock), lds, st, a);
 }
 
 static bool seed_supported(uint32_t s, uint32_t max_k)
@@ -276,17 +276,27 @@ static bool seed_supported(uint32_t s, uint32_t max_k)
 
 static void launch_seed(uint32_t s, const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
 {
+    // low 5 bits of k * multiSeed: kernels specialised on it replace the per-slot 64-bit multiplies by adds
+    const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
+    if (s == 21) {   // `groot index` default sketch size, for the common k-mer sizes
+        if (m5 == 6) return launch_seed_sm<21, 4, 6>(a, dump, grid, lds, st);     // k = 31 (default), 63
+        if (m5 == 10) return launch_seed_sm<21, 4, 10>(a, dump, grid, lds, st);   // k = 41
+        if (m5 == 14) return launch_seed_sm<21, 4, 14>(a, dump, grid, lds, st);   // k = 51
+        if (m5 == 2) return launch_seed_sm<21, 4, 2>(a, dump, grid, lds, st);     // k = 21
+    }
+    if (s == 20 && m5 == 6) return launch_seed_sm<20, 4, 6>(a, dump, grid, lds, st);    // travis e2e: -k 31 -s 20
+    if (s == 30 && m5 == 14) return launch_seed_sm<30, 4, 14>(a, dump, grid, lds, st);  // pipeline tests: k = 51, s = 30
     switch (s) {
-    case 8: launch_seed_sm<8, 4>(a, dump, grid, lds, st); break;
-    case 10: launch_seed_sm<10, 4>(a, dump, grid, lds, st); break;
-    case 16: launch_seed_sm<16, 4>(a, dump, grid, lds, st); break;
-    case 20: launch_seed_sm<20, 4>(a, dump, grid, lds, st); break;
-    case 21: launch_seed_sm<21, 4>(a, dump, grid, lds, st); break;
-    case 24: launch_seed_sm<24, 4>(a, dump, grid, lds, st); break;
-    case 30: launch_seed_sm<30, 4>(a, dump, grid, lds, st); break;
-    case 32: launch_seed_sm<32, 4>(a, dump, grid, lds, st); break;
-    case 42: launch_seed_sm<42, 4>(a, dump, grid, lds, st); break;
-    case 64: launch_seed_sm<64, 4>(a, dump, grid, lds, st); break;
+    case 8: launch_seed_sm<8, 4, -1>(a, dump, grid, lds, st); break;
+    case 10: launch_seed_sm<10, 4, -1>(a, dump, grid, lds, st); break;
+    case 16: launch_seed_sm<16, 4, -1>(a, dump, grid, lds, st); break;
+    case 20: launch_seed_sm<20, 4, -1>(a, dump, grid, lds, st); break;
+    case 21: launch_seed_sm<21, 4, -1>(a, dump, grid, lds, st); break;
+    case 24: launch_seed_sm<24, 4, -1>(a, dump, grid, lds, st); break;
+    case 30: launch_seed_sm<30, 4, -1>(a, dump, grid, lds, st); break;
+    case 32: launch_seed_sm<32, 4, -1>(a, dump, grid, lds, st); break;
+    case 42: launch_seed_sm<42, 4, -1>(a, dump, grid, lds, st); break;
+    case 64: launch_seed_sm<64, 4, -1>(a, dump, grid, lds, st); break;
     default: break;
     }
 }

@@ -81,7 +81,11 @@ constexpr uint32_t kLdsReads = 4096 + 192;       // staged read bytes (16-byte a
 // ---------------------------------------------------------------------------------------------
 // K1+K2
 // ---------------------------------------------------------------------------------------------
-template <int S, int MAXK, bool DUMP>
+// M5 >= 0: compile-time value of (k * multiSeed) & 31.  The MultiHash multipliers c_i = i ^ (k*multiSeed) of
+// slots i < 32 then equal C0 + (i ^ M5) with C0 = (k*multiSeed) & ~31, so h*c_i for all slots comes from ONE
+// 64-bit multiply (h*C0) and a running sum (+h per step) instead of a quarter-rate 64-bit multiply per slot.
+// M5 < 0: generic path (any k, any S).
+template <int S, int MAXK, bool DUMP, int M5>
 __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -156,11 +160,24 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
         for (uint32_t j = 0;;) {
             const uint64_t h = fh < rh ? fh : rh;          // canonical
             m[0] = h < m[0] ? h : m[0];
+            if (M5 >= 0 && S <= 32) {
+                uint64_t acc = h * (M & ~31ULL);           // = h * c_i for the slot with (i ^ M5) == 0
 #pragma unroll
-            for (int i = 1; i < S; i++) {
-                uint64_t t = h * ((uint64_t)i ^ M);
-                t ^= t >> GROOT_MULTI_SHIFT;
-                m[i] = t < m[i] ? t : m[i];
+                for (int d = 0; d < 32; d++) {
+                    const int i = d ^ (M5 & 31);
+                    if (i >= 1 && i < S) {
+                        const uint64_t t = acc ^ (acc >> GROOT_MULTI_SHIFT);
+                        m[i] = t < m[i] ? t : m[i];
+                    }
+                    acc += h;
+                }
+            } else {
+#pragma unroll
+                for (int i = 1; i < S; i++) {
+                    uint64_t t = h * ((uint64_t)i ^ M);
+                    t ^= t >> GROOT_MULTI_SHIFT;
+                    m[i] = t < m[i] ? t : m[i];
+                }
             }
             if (++j == nk) break;
             const unsigned prev = rd[j - 1], end = rd[j + k - 1];
