@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     const uint64_t M = (uint64_t)k * GROOT_MULTI_SEED;
     const uint32_t nk = len - k + 1;
     unsigned high = 0;                       // any byte > 'T': RevComplement would panic (seqio.go:126)
-    uint64_t first5 = 0;                     // first 5 bases of the read (for the scheduling key below)
+    uint64_t first5 = 0, last5 = 0;          // first / last 5 bases of the read (for the scheduling key below)
     auto sketch = [&](const unsigned char *rd) {
         uint64_t fh = 0, rh = 0;
         for (uint32_t j = 0; j < k; j++) {   // ntf64 / ntr64 of the first k-mer in one pass
@@ -185,6 +185,8 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
             fh = rol1(fh) ^ tabFout[prev] ^ tabF[end];
             rh = ror1(rh) ^ tabCout[prev & 7] ^ tabCin[end & 7];
         }
+        if (len >= 5)
+            for (uint32_t j = 0; j < 5; j++) last5 |= (uint64_t)rd[len - 1 - j] << (8 * j);   // reversed: base len-1 first
     };
     if (in_lds) sketch(lds_reads + (o0 - base16));   // LDS address space
     else sketch(a.seq + o0);                         // span too large for LDS: straight from HBM
@@ -274,12 +276,18 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     if (a.sort_key) {
         uint32_t key = kEmpty;
         if (n_hits) {
-            uint32_t likely_rc = 0;
-            if (len >= 5 && k <= len) {
-                const int code = kmer5_code(first5);
-                if (code >= 0) likely_rc = !((ix.win_kmer5[(size_t)min_win * 32 + (code >> 5)] >> (code & 31)) & 1u);
+            // can the forward read / its reverse complement be spelled from the window's level-1/2 start positions?
+            // (1,0) = forward read, (0,1) = reverse read that leaves the forward hierarchy after one probe,
+            // (1,1) = a full failing scan is possible, (0,0) = nothing will align: four classes of similar work
+            uint32_t fwd_no = 0, rc_no = 0;
+            if (len >= 5) {
+                const uint32_t *bits = ix.win_kmer5 + (size_t)min_win * 32;
+                const int cf = kmer5_code(first5);
+                if (cf >= 0) fwd_no = !((bits[cf >> 5] >> (cf & 31)) & 1u);
+                const int cl = kmer5_code(last5);          // codes A=0 C=1 T=2 G=3: complement = code ^ 2
+                if (cl >= 0) { const int cr = cl ^ 0x2AA; rc_no = !((bits[cr >> 5] >> (cr & 31)) & 1u); }
             }
-            key = (min_win << 1) | likely_rc;
+            key = (min_win << 2) | (fwd_no << 1) | rc_no;
         }
         a.sort_key[r] = key;
     }
