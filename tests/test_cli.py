@@ -1,0 +1,121 @@
+"""The flag-compatible command line (`groot-hip index|align`): cmd/index.go, cmd/align.go, and the e2e flow of
+testing/run_travis_tests.sh (index -w 150 -k 31 -s 20; align -t 0.99 on bla-b7-150bp-5x.fq)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from bamread import read_bam
+from conftest import DATA, REPO, read_fastq
+from groot_amd import device, host
+from oracle import oracle_py as O
+
+
+@pytest.fixture(scope="module")
+def cli(hip_lib):
+    import __graft_entry__ as g
+
+    return g.build_cli()
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, cwd=REPO, capture_output=True, timeout=600, **kw)
+
+
+def test_index_subcommand_and_align_without_gpu(cli, msa_dir, tmp_path):
+    idx_dir = str(tmp_path / "idx")
+    log = str(tmp_path / "index.log")
+    r = run([cli, "index", "-m", msa_dir, "-i", idx_dir, "--log", log, "-p", "4"])
+    assert r.returncode == 0, r.stderr
+    text = open(log).read()
+    for line in ("i am groot (version 1.1.2)", "starting the index subcommand", "\tk-mer size: 31", "\tsketch size: 21",
+                 "\tgraph window size: 100", "\tnumber of groot graphs built: 583", "\t\tgraphs sketched: 583"):
+        assert line in text, line
+    again = host.Index.load(os.path.join(idx_dir, "groot.gidx"))
+    assert (again.view.n_graphs, again.view.n_paths) == (583, 1749)
+    # required flags / bad inputs (cmd/index.go:57-61,161-163; cmd/align.go:56-60)
+    assert run([cli, "index", "-i", idx_dir]).returncode != 0
+    assert run([cli, "index", "-m", msa_dir, "-i", idx_dir, "-k", "200", "-w", "100", "--log", log]).returncode != 0
+    assert run([cli, "align", "-f", os.path.join(DATA, "bla-b7-150bp-5x.fq")]).returncode != 0
+    if device.device_count() == 0:
+        r = run([cli, "align", "-i", idx_dir, "-f", os.path.join(DATA, "bla-b7-150bp-5x.fq"), "--log", str(tmp_path / "a.log"),
+                 "-g", str(tmp_path / "graphs")])
+        assert r.returncode != 0 and b"no HIP device" in r.stderr     # never a CPU fallback
+
+
+@pytest.mark.gpu
+def test_align_subcommand_against_oracle(cli, argannot_index, perfect_reads, tmp_path):
+    idx_dir = tmp_path / "idx"
+    idx_dir.mkdir()
+    argannot_index.save(str(idx_dir / "groot.gidx"))
+    fq = os.path.join(DATA, "full-argannot-perfect-reads-small.fq.gz")
+    log, graphs, bam = str(tmp_path / "align.log"), str(tmp_path / "graphs"), str(tmp_path / "out.bam")
+    with open(bam, "wb") as out:
+        r = subprocess.run([cli, "align", "-i", str(idx_dir), "-f", fq, "--log", log, "-g", graphs, "--batch", "300"],
+                           cwd=REPO, stdout=out, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr
+    # oracle
+    cat, off = O.pack_reads([x[1] for x in perfect_reads])
+    orun = O.Run(argannot_index)
+    orun.batch(cat, off)
+    oal, oc = orun.alns(), orun.counts()
+    text, refs, recs = read_bam(bam)
+    assert len(recs) == len(oal) == oc["alignments"]
+    assert [n for n, _ in refs] == [argannot_index.path_name(p) for p in range(argannot_index.view.n_paths)]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for a, rec in zip(oal, recs):          # records come out in read order, ids ascending: the canonical order
+        name, s, q = perfect_reads[int(a["read_id"])]
+        if a["rc"]:
+            s, q = s.translate(comp)[::-1], q[::-1]
+        assert (rec["name"], rec["ref_id"], rec["pos"]) == (name.decode(), int(a["ref_id"]), int(a["pos"]))
+        assert rec["seq"].encode() == s and rec["qual"] == q and rec["cigar"] == "100M"
+        assert rec["flag"] == (0x10 if a["rc"] else 0) | (0x100 if a["secondary"] else 0) and rec["mapq"] == 30
+    logtxt = open(log).read()
+    for line in (f"\tnumber of reads received from input: {oc['received']}", "\tmean read length: 100",
+                 f"\ttotal number of unmapped reads: {oc['received'] - oc['mapped']}", f"\ttotal number of mapped reads: {oc['mapped']}",
+                 f"\t\tmapped to multiple graphs: {oc['multimapped']}", f"\ttotal number of exact alignments: {oc['alignments']}"):
+        assert line in logtxt, line
+    # weighted graphs: KC tags = int(KmerFreq) of the canonical replay, pruned at the default coverage 1.0
+    kf, kt = orun.weights(order=1)
+    gk, pk, nr = orun.prune(kf, 1.0)
+    assert f"\ttotal number of k-mers projected onto graphs: {int(kt.sum())}" in logtxt
+    a = argannot_index.arrays
+    files = sorted(os.listdir(graphs))
+    expect = []
+    for g in np.flatnonzero(gk):
+        nodes = range(int(a["graph_node_off"][g]), int(a["graph_node_off"][g + 1]))
+        if any(kf[n] > 0 and not nr[n] for n in nodes):
+            expect.append(f"groot-graph-{g}.gfa")
+    assert files == sorted(expect) and len(files) > 0
+    g = int(re.match(r"groot-graph-(\d+)\.gfa", files[0]).group(1))
+    kc = {}
+    for line in open(os.path.join(graphs, files[0])):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == "S":
+            kc[int(f[1])] = int(f[4][5:])
+    for n in range(int(a["graph_node_off"][g]), int(a["graph_node_off"][g + 1])):
+        if not nr[n]:
+            assert kc[int(a["node_seg_id"][n])] == int(kf[n])
+
+
+@pytest.mark.gpu
+def test_travis_e2e_flow(cli, msa_dir, tmp_path):
+    """testing/run_travis_tests.sh:12-56: index -w 150 -k 31 -s 20, align -t 0.99 on the 150 bp B-7 reads.
+    (`groot report` is outside the hot path; here: every alignment is on the Bla-B graph and the B-7 allele is
+    the only allele every read aligns to, as the travis assertion implies.)"""
+    idx_dir = str(tmp_path / "idx")
+    r = run([cli, "index", "-m", msa_dir, "-i", idx_dir, "-w", "150", "-k", "31", "-s", "20", "--log", str(tmp_path / "i.log"), "-p", "8"])
+    assert r.returncode == 0, r.stderr
+    bam, graphs = str(tmp_path / "o.bam"), str(tmp_path / "g")
+    r = run([cli, "align", "-i", idx_dir, "-f", os.path.join(DATA, "bla-b7-150bp-5x.fq"), "-t", "0.99", "--bam", bam, "-g", graphs,
+             "--log", str(tmp_path / "a.log")])
+    assert r.returncode == 0, r.stderr
+    text, refs, recs = read_bam(bam)
+    reads = read_fastq(os.path.join(DATA, "bla-b7-150bp-5x.fq"))
+    assert recs and all("(Bla)B-" in x["ref"] for x in recs)
+    # every simulated read aligns to the B-7 allele it came from (what `groot report` then turns into the one ARG)
+    b7 = {x["name"] for x in recs if x["ref"] == "argannot~~~(Bla)B-7~~~AF189304:1-747"}
+    assert b7 == {n.decode() for n, _, _ in reads}
+    assert all(x["cigar"] == "150M" for x in recs)
