@@ -389,6 +389,11 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
 // lanes in different reads / levels / depths never serialise each other's loops and every executed
 // instruction runs at the best available lane fill; a lane that finishes a read fetches the next one.
 enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
+#ifndef GROOT_REFILL
+#define GROOT_REFILL 64
+#endif
+constexpr int kRefill = GROOT_REFILL;          // waiting lanes that trigger a refill
+constexpr uint32_t kWaveChunk = 512;          // consecutive slots a wave takes before moving on
 
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
 __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
@@ -445,9 +450,12 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 #define GROOT_COUNT(i) ((void)0)
 #endif
 
-    uint32_t phase = PH_FETCH;
-    uint32_t slot = gtid - a.n_threads;                    // first fetch adds the stride
-    uint32_t r = 0;
+    uint32_t phase = PH_WAIT;
+    // reads are handed out per wavefront: chunks of kWaveChunk consecutive (sorted) slots, round-robin over the
+    // waves of the grid, consecutive slots to the lanes that ask together
+    const uint32_t n_waves = a.n_threads >> 6, wave_id = gtid >> 6;
+    uint32_t chunk_j = 0, chunk_pos = 0;                   // wave-uniform cursor
+    uint32_t slot = 0, r = 0;
     // ---- read ----
     bool have_read = false;
     const uint8_t *p = nullptr;
@@ -539,13 +547,32 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
     for (;;) {
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
-        if (!(bf | bs | bd)) {
-            // every lane has finished its read: the wave takes its next 64 reads together.  Reads are sorted by
-            // (first seed window, orientation), so the 64 lanes start each round on near-identical work and stay
-            // in the same phase most of the time.
-            if (!__ballot(phase == PH_WAIT)) break;
-            if (phase == PH_WAIT) phase = PH_FETCH;
-            continue;
+        {
+            // Lanes that finished their read wait until kRefill of them have gathered (or nothing else is left to
+            // run), then take the next consecutive slots together.  Reads are sorted by (first seed window,
+            // orientation class), so lanes that start together do near-identical work and share phases.
+            const unsigned long long bw = __ballot(phase == PH_WAIT);
+            const int cw = __popcll(bw);
+            if (cw >= kRefill || (cw && !(bf | bs | bd))) {
+                const uint64_t base = ((uint64_t)chunk_j * n_waves + wave_id) * kWaveChunk;
+                if (base >= a.n_reads) {                       // this wave's share is used up
+                    if (phase == PH_WAIT) phase = PH_DONE;
+                } else {
+                    const uint32_t room = kWaveChunk - chunk_pos;
+                    if (phase == PH_WAIT) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
+                        const uint64_t sl = base + chunk_pos + rank;
+                        if (rank < room) {
+                            if (sl < a.n_reads) { slot = (uint32_t)sl; phase = PH_FETCH; }
+                            else phase = PH_DONE;
+                        }
+                    }
+                    chunk_pos += min((uint32_t)cw, room);
+                    if (chunk_pos >= kWaveChunk) { chunk_pos = 0; chunk_j++; }
+                }
+                continue;
+            }
+            if (!(bf | bs | bd)) break;                         // no lane has work and none waits
         }
         const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
@@ -557,8 +584,6 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
 
         if (run == PH_FETCH) {
             if (!have_read) {
-                slot += a.n_threads;
-                if (slot >= a.n_reads) { phase = PH_DONE; continue; }
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
                 const uint32_t sc = a.seed_count[r];
                 cnt = min(sc & 0x7FFFFFFFu, a.seed_slots);   // overflow already flagged; batch is re-run

@@ -124,6 +124,32 @@ def test_small_graph_fixture_all_windows(testgfa_index):
         al.close()
 
 
+def test_wide_graph_uses_the_wide_node_records(tmp_path):
+    """a cluster with 260 alleles (5 path words): the 128-byte NodeRec<11> variant of the align kernel"""
+    rng = np.random.default_rng(11)
+    base = rng.choice(list(b"ACGT"), size=420).astype(np.uint8)
+    rows = []
+    for i in range(260):
+        s = base.copy()
+        for p in rng.choice(420, size=4, replace=False):
+            s[p] = rng.choice([c for c in b"ACGT" if c != s[p]])
+        row = bytearray(s.tobytes())
+        if i % 7 == 0:                       # a deletion
+            d = int(rng.integers(50, 360))
+            row[d:d + 3] = b"---"
+        rows.append(bytes(row))
+    f = tmp_path / "cluster-0.msa"
+    f.write_bytes(b"".join(b">*seq%d\n%s\n" % (i, r) if i == 0 else b">seq%d\n%s\n" % (i, r) for i, r in enumerate(rows)))
+    idx = host.Index.from_msa_files([str(f)])
+    assert idx.view.path_words == 5 and idx.view.n_paths == 260
+    cat, o, lens = synth.reference_sequences(idx)
+    seq, off, _ = synth.reads_np(cat, o, lens, 6000, 100)
+    al, counts, run = run_both(idx, seq, off)
+    got = assert_same(al, counts, run, idx)
+    assert counts["alignments"] > 10 * counts["mapped"] > 0      # many alleles share every window
+    al.close()
+
+
 def test_edge_cases(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 64, 100)
