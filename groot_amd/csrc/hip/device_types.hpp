@@ -45,6 +45,26 @@ template <int PW> struct alignas(16) NodeRec {
 static_assert(sizeof(NodeRec<3>) == 64, "node record must be one 64-byte line");
 static_assert(sizeof(NodeRec<11>) == 128, "wide node record must be 128 bytes");
 
+// lshe.Key of one window, the fields AlignRead needs, in one 32-byte record (one load instead of six)
+struct alignas(16) WinRec {
+    uint32_t graph;        // Key.GraphID
+    uint32_t node;         // global node index of Key.Node
+    uint32_t offset;       // Key.OffSet
+    uint32_t l1_hi;        // exclusive end of the level-1 offsets: min(len(node), OffSet + MergeSpan + WindowSize + 1)
+    uint32_t cn_off, cn_end;   // ContainedNodes range in cn_node
+    uint32_t seed_s0, seed_len;   // base offset / length of Key.Node
+};
+static_assert(sizeof(WinRec) == 32, "window record is two 16-byte words");
+
+// what the align stage needs to start a read, written by the seed stage in one 32-byte record
+struct alignas(16) ReadRec {
+    uint64_t seq_off;      // first base of the read in the batch buffer
+    uint32_t len;
+    uint32_t cnt_flags;    // seeds (bits 0..30) | read holds a byte > 'T' (bit 31)
+    uint32_t seed[4];      // the first four seed windows (all of them for 99.9% of reads); more: seed_win slots
+};
+static_assert(sizeof(ReadRec) == 32, "read record is two 16-byte words");
+
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
 
@@ -53,7 +73,8 @@ struct DeviceIndex {
     uint32_t k, s, w, num_window_kmers, n_windows, n_nodes, pw; // pw = path words on the device (>= view.path_words)
     const uint32_t *edges;          // only for nodes with more than 4 OutEdges (NodeRec embeds the rest)
     const uint8_t *bases;
-    const uint32_t *win_graph, *win_node, *win_offset, *win_merge_span, *win_cn_off, *cn_node;
+    const uint32_t *win_graph, *cn_node;
+    const WinRec *win_rec;          // [n_windows]
     const uint64_t *win_sketch;     // [n_windows*s]
     // per window: which 5-base read prefixes (2 bits per base, A=0 C=1 T=2 G=3) can be spelled from any
     // level-1 / level-2 start position of AlignRead (alignment.go:34-70); 1024 bits = 32 words per window
@@ -80,7 +101,8 @@ struct SeedArgs {
     uint32_t *seed_count;        // [n_reads]
     uint32_t *seed_win;          // [H][n_reads] slot-major
     uint64_t *sketch_out;        // [n_reads*s] or null
-    uint32_t *sort_key;          // [n_reads] (first seed window << 1 | likely reverse), kEmpty without seeds; or null
+    uint32_t *sort_key;          // [n_reads] (first seed window, orientation class), kEmpty without seeds; or null
+    ReadRec *read_rec;           // [n_reads]
     DeviceCounters *ctr;
 };
 
@@ -93,6 +115,7 @@ struct AlignArgs {
     const uint32_t *seed_count;
     const uint32_t *seed_win;
     const uint32_t *perm;        // [n_reads] processing order (reads sorted by sort_key) or null
+    const ReadRec *read_rec;     // [n_reads]
     uint32_t no_align, update_weights;
     const void *node_rec;        // NodeRec<pw>[n_nodes]
     uint32_t *attempts;          // [(max_q+1)*n_windows]

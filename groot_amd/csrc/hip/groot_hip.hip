@@ -50,12 +50,13 @@ struct groot_ctx {
     groot_stage_ms ms{};
 
     // index in HBM
-    DevBuf<uint32_t> win_kmer5, edges, win_graph, win_node, win_offset, win_merge_span, win_cn_off, cn_node,
+    DevBuf<uint32_t> win_kmer5, edges, win_graph, cn_node,
         band_keys, band_ids;
     DevBuf<uint8_t> bases, q_k, q_l;
     DevBuf<uint16_t> q_min_eq;
     DevBuf<uint64_t> win_sketch;
     DevBuf<unsigned char> node_rec;
+    DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
     DeviceIndex dix{};
 
@@ -69,6 +70,7 @@ struct groot_ctx {
     uint32_t seed_slots = 0;
     DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm;
     DevBuf<char> sort_tmp;
+    DevBuf<ReadRec> read_rec;
     DevBuf<uint64_t> sketches;
     DevBuf<DeviceCounters> ctr;
     DeviceCounters hctr{};
@@ -356,6 +358,7 @@ static int launch_seed_stage(groot_ctx *c)
     a.seed_win = c->seed_win.p;
     a.sketch_out = c->prm.keep_sketches ? c->sketches.p : nullptr;
     a.sort_key = c->sort_key.p;
+    a.read_rec = c->read_rec.p;
     a.ctr = c->ctr.p;
     const dim3 grid((c->n_reads + kBlock - 1) / kBlock);
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
@@ -387,6 +390,7 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     a.seed_count = c->seed_count.p;
     a.seed_win = c->seed_win.p;
     a.perm = c->perm.p;
+    a.read_rec = c->read_rec.p;
     a.no_align = c->prm.no_exact_align;
     a.update_weights = update_weights ? 1 : 0;
     a.attempts = c->attempts_ptr;
@@ -541,10 +545,17 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->win_kmer5, k5.data(), k5.size()));
     }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
-    HIP_TRY(c, upload(c->win_node, v->win_node, v->n_windows));
-    HIP_TRY(c, upload(c->win_offset, v->win_offset, v->n_windows));
-    HIP_TRY(c, upload(c->win_merge_span, v->win_merge_span, v->n_windows));
-    HIP_TRY(c, upload(c->win_cn_off, v->win_cn_off, (size_t)v->n_windows + 1));
+    {
+        std::vector<WinRec> wr(v->n_windows);
+        for (uint32_t w = 0; w < v->n_windows; w++) {
+            const uint32_t node = v->win_node[w];
+            const uint32_t nlen = v->node_seq_off[node + 1] - v->node_seq_off[node];
+            const uint64_t last = (uint64_t)v->win_offset[w] + v->win_merge_span[w] + v->window_size;
+            wr[w] = WinRec{v->win_graph[w], node, v->win_offset[w], (uint32_t)std::min<uint64_t>(nlen, last + 1), v->win_cn_off[w],
+                           v->win_cn_off[w + 1], v->node_seq_off[node], nlen};
+        }
+        HIP_TRY(c, upload(c->win_rec, wr.data(), wr.size()));
+    }
     HIP_TRY(c, upload(c->cn_node, v->cn_node, v->n_cn));
     HIP_TRY(c, upload(c->win_sketch, v->win_sketch, (size_t)v->n_windows * v->sketch_size, 2));
 
@@ -603,8 +614,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     x.k = v->kmer_size; x.s = s; x.w = v->window_size; x.num_window_kmers = v->num_window_kmers;
     x.n_windows = n; x.n_nodes = v->n_nodes; x.pw = c->pw;
     x.edges = c->edges.p; x.bases = c->bases.p;
-    x.win_kmer5 = c->win_kmer5.p; x.win_graph = c->win_graph.p; x.win_node = c->win_node.p; x.win_offset = c->win_offset.p;
-    x.win_merge_span = c->win_merge_span.p; x.win_cn_off = c->win_cn_off.p; x.cn_node = c->cn_node.p;
+    x.win_kmer5 = c->win_kmer5.p; x.win_graph = c->win_graph.p; x.win_rec = c->win_rec.p; x.cn_node = c->cn_node.p;
     x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
 
@@ -614,6 +624,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->seq_off.alloc((size_t)R + 1));
     HIP_TRY(c, c->seed_count.alloc(R));
     HIP_TRY(c, c->sort_key.alloc(R));
+    HIP_TRY(c, c->read_rec.alloc(R));
     HIP_TRY(c, c->sort_key_out.alloc(R));
     HIP_TRY(c, c->perm.alloc(R));
     {
@@ -933,7 +944,7 @@ int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     a.seq = c->seq.p; a.seq_off = c->seq_off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
-    a.sketch_out = sk.p; a.sort_key = nullptr; a.ctr = c->ctr.p;
+    a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.ctr = c->ctr.p;
     launch_seed(c->s, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
     HIP_TRY(c, hipGetLastError());
     DeviceCounters h{};

@@ -133,11 +133,15 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
         atomicOr(&a.ctr->flags, kFlagShortRead);
         atomicAdd(&a.ctr->short_reads, 1ULL);
         a.seed_count[r] = 0;
+        if (a.read_rec) { uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r); rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, 0); }
+        if (a.sort_key) a.sort_key[r] = kEmpty;
         return;
     }
     if (len > a.max_read_len) {
         atomicOr(&a.ctr->flags, kFlagLongRead);
         a.seed_count[r] = 0;
+        if (a.read_rec) { uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r); rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, 0); }
+        if (a.sort_key) a.sort_key[r] = kEmpty;
         return;
     }
     // ---- KHF sketch (khf.go:35-55): per slot i, min over k-mers of MultiHash_i(canonical ntHash) ----
@@ -199,8 +203,10 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     const uint32_t q = nk;                                 // kmerCount, boss.go:169
     const uint32_t min_eq = q <= ix.max_q ? ix.q_min_eq[q] : (uint32_t)S + 1;
     uint32_t min_win = kEmpty;
+    uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;   // first four seeds, for the read record
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
+        if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
         n_hits++;
         min_win = min(min_win, id);
     };
@@ -270,6 +276,11 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
         }
     }
     a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
+    if (a.read_rec) {
+        uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, n_hits | (high ? 0x80000000u : 0u));
+        rq[1] = make_uint4(s0, s1, s2, s3);
+    }
     // scheduling key for the align stage: reads are processed in (first seed window, likely orientation) order so
     // that neighbouring lanes walk the same graph nodes in step; reads without seeds sort to the end.  Processing
     // order only -- every output is addressed by read.
@@ -460,12 +471,13 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
     bool have_read = false;
     const uint8_t *p = nullptr;
     uint32_t len = 0, cnt = 0, q = 0, n_graphs = 0, ord = 0, read_id = 0;
+    uint32_t sd0 = kEmpty, sd1 = kEmpty, sd2 = kEmpty, sd3 = kEmpty;   // the read's first four seed windows
     uint32_t high_byte = 0;                                // RevComplement would panic on this read
     long long last = -1;                                   // last seed window handled (ascending window id order)
     uint32_t done_graph = kEmpty, cur_graph = kEmpty;
     bool group_rc_called = false;
     // ---- seed / hierarchy ----
-    uint32_t w = 0, g = 0, seed = 0, seed_s0 = 0, seed_len = 0, off0 = 0, l1_hi = 0, cn_cur = 0, cn_end = 0;
+    uint32_t w = 0, g = 0, seed = 0, seed_s0 = 0, seed_len = 0, off0 = 0, l1_hi = 0, cn_cur = 0, cn_begin = 0, cn_end = 0;
     uint32_t rc = 0, level = 1;
     uint32_t sc_node = 0, sc_s0 = 0, sc_len = 0, sc_pos = 0, sc_end = 0;   // range being scanned
     uint32_t clip_lo = 0, eff = 0, tflags = 0;
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
     // the current scan range is used up: move through the hierarchy until a non-empty range or the end
     auto next_range = [&]() {
         for (;;) {
-            if (level == 1) { level = 2; cn_cur = ix.win_cn_off[w]; }
+            if (level == 1) { level = 2; cn_cur = cn_begin; }
             else if (level == 2) cn_cur++;
             else if (level == 3) {
                 level = 4;                                  // 4. hard clip the last base (:87-103)
@@ -585,13 +597,15 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
         if (run == PH_FETCH) {
             if (!have_read) {
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
-                const uint32_t sc = a.seed_count[r];
+                const uint4 *rq = reinterpret_cast<const uint4 *>(a.read_rec + r);
+                const uint4 ra = rq[0], rb = rq[1];               // one 32-byte record per read
+                const uint32_t sc = ra.w;
                 cnt = min(sc & 0x7FFFFFFFu, a.seed_slots);   // overflow already flagged; batch is re-run
                 if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
                 high_byte = sc >> 31;
-                const uint64_t o0 = a.seq_off[r];
-                len = (uint32_t)(a.seq_off[r + 1] - o0);
-                p = a.seq + o0;
+                len = ra.z;
+                p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
+                sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
                 if (LDSR && len + 12 > a.lds_stride_dw * 4) {  // longer than the max_len the batch was submitted with
                     atomicOr(&a.ctr->flags, kFlagLongRead);
                     a.trav_cnt[r] = 0;
@@ -607,10 +621,16 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
             }
             // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
             uint32_t nw = kEmpty;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
-                if ((long long)cand > last && cand < nw) nw = cand;
-            }
+            if (cnt <= 4) {                                   // the seeds travel in the read record
+                if ((long long)sd0 > last && sd0 < nw) nw = sd0;
+                if (cnt > 1 && (long long)sd1 > last && sd1 < nw) nw = sd1;
+                if (cnt > 2 && (long long)sd2 > last && sd2 < nw) nw = sd2;
+                if (cnt > 3 && (long long)sd3 > last && sd3 < nw) nw = sd3;
+            } else
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
+                    if ((long long)cand > last && cand < nw) nw = cand;
+                }
             if (nw == kEmpty) {                               // every seed of the read handled
                 a.trav_cnt[r] = ord;
                 mapped++;                                     // boss.go:195-200
@@ -620,16 +640,17 @@ __global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
                 continue;
             }
             w = nw; last = nw;
-            g = ix.win_graph[w];
+            const uint4 *wq = reinterpret_cast<const uint4 *>(ix.win_rec + w);
+            const uint4 wa = wq[0], wb = wq[1];               // the whole lshe.Key in one 32-byte load
+            g = wa.x;
             if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
             if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
             if (a.update_weights) atomicAdd(&a.attempts[(size_t)q * ix.n_windows + w], 1u);   // :67 IncrementSubPath
             if (a.no_align) continue;                         // :70-72
-            seed = ix.win_node[w]; off0 = ix.win_offset[w];
-            seed_s0 = recs[seed].seq_off; seed_len = recs[seed].seq_len;
-            const uint64_t lastoff = (uint64_t)off0 + ix.win_merge_span[w] + ix.w;   // alignment.go:36
-            l1_hi = (uint32_t)min((uint64_t)seed_len, lastoff + 1);   // offsets past the node end fail at once (:199-201)
-            cn_end = ix.win_cn_off[w + 1];
+            seed = wa.y; off0 = wa.z;
+            l1_hi = wa.w;                                     // alignment.go:36 and :199-201, folded at open
+            cn_begin = wb.x; cn_end = wb.y;
+            seed_s0 = wb.z; seed_len = wb.w;
             begin_orientation(0);
         } else if (run == PH_SCAN) {
             if (sc_pos >= sc_end) { next_range(); continue; }   // only after a DFS that used the range's last offset
