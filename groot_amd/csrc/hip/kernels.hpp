@@ -440,8 +440,11 @@ template <int PW> struct RecRegs {
 // (lane-private slice of lds_stride_dw dwords, odd stride = conflict-free across lanes); DFS steps then read
 // their 8-base chunks with three ds_read_b32 + two alignbit instead of going back to the Infinity Cache /
 // HBM for the read's line and re-doing the reverse complement at every step.
+#ifndef GROOT_ALIGN_WAVES
+#define GROOT_ALIGN_WAVES 1
+#endif
 template <int PW, bool LDSR>
-__global__ __launch_bounds__(kBlock) void align_kernel(AlignArgs a)
+__global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignArgs a)
 {
     using Rec = NodeRec<PW>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_reads[];
