@@ -57,6 +57,7 @@ struct Args {
     std::string cmd, index_dir, msa_dir, log_file = "groot.log", graph_dir, bam_out;
     std::vector<std::string> fastq;
     int proc = 1, gpu = 0;
+    bool gpu_given = false;
     uint32_t k = 31, s = 21, w = 100, x = 8, y = 4, max_span = 30, batch = 1u << 20;
     double threshold = 0.99, min_kmer_cov = 1.0;
     bool no_align = false, fasta = false;
@@ -80,6 +81,7 @@ void usage()
     fprintf(stderr,
             "groot-hip %s (MI355X-native groot align hot path)\n\n"
             "  groot-hip index -m <msaDir> -i <indexDir> [-k 31] [-s 21] [-w 100] [-x 8] [-y 4] [--maxSketchSpan 30] [-p N] [--log F]\n"
+            "                  [--gpu 0]      (sketch the graph windows on that GPU instead of the host)\n"
             "  groot-hip align -i <indexDir> -f <fastq>[,<fastq>...] [-t 0.99] [-c 1.0] [-g <graphDir>] [--noAlign] [-p N] [--log F]\n"
             "                  [--gpu 0] [--batch 1048576] [--bam out.bam]      (BAM goes to stdout unless --bam)\n",
             groot_host_version());
@@ -118,7 +120,7 @@ Args parse(int argc, char **argv)
         else if (f == "--noAlign") a.no_align = true;
         else if (f == "--fasta") a.fasta = true;
         else if (f == "--profiling") {}
-        else if (f == "--gpu") a.gpu = atoi(v().c_str());
+        else if (f == "--gpu") { a.gpu = atoi(v().c_str()); a.gpu_given = true; }
         else if (f == "--batch") a.batch = (uint32_t)atol(v().c_str());
         else if (f == "--bam") a.bam_out = v();
         else if (f == "-h" || f == "--help") { usage(); exit(0); }
@@ -182,7 +184,35 @@ int run_index(const Args &a)   // cmd/index.go:57-133
     p.kmer_size = a.k; p.sketch_size = a.s; p.window_size = a.w; p.num_part = a.x; p.max_k = a.y; p.max_sketch_span = a.max_span;
     p.n_threads = a.proc > 0 ? (uint32_t)a.proc : 0;
     groot_index *idx = nullptr;
-    if (groot_index_build_msa_dir(a.msa_dir.c_str(), &p, &idx)) die("%s", groot_host_last_error());
+    if (a.gpu_given) {
+        // window sketches on the GPU: a ctx opened on an index view without graphs is a pure RunMinHash engine
+        logf("\tsketching graph windows on GPU %d", a.gpu);
+        groot_index_view empty;
+        memset(&empty, 0, sizeof empty);
+        empty.kmer_size = a.k; empty.sketch_size = a.s; empty.window_size = a.w; empty.num_part = a.x; empty.max_k = a.y;
+        empty.num_window_kmers = a.w - a.k + 1; empty.path_words = 1;
+        groot_params prm;
+        groot_params_default(&prm);
+        prm.max_read_len = std::max<uint32_t>(a.w, 64);
+        prm.max_batch_reads = 1u << 16;
+        groot_ctx *ctx = nullptr;
+        if (groot_hip_open(&ctx, a.gpu, &empty, &prm)) die("%s", groot_hip_last_error(nullptr));
+        struct Sk { groot_ctx *ctx; uint32_t s, max_n; } sk{ctx, a.s, prm.max_batch_reads};
+        auto fn = [](void *user, const uint8_t *seq, const uint64_t *off, uint32_t n, uint64_t *out) -> int {
+            Sk *k = (Sk *)user;
+            std::vector<uint64_t> rel;
+            for (uint32_t i = 0; i < n; i += k->max_n) {
+                const uint32_t m = std::min(k->max_n, n - i);
+                rel.resize(m + 1);
+                for (uint32_t j = 0; j <= m; j++) rel[j] = off[i + j] - off[i];
+                if (groot_hip_sketch(k->ctx, seq + off[i], rel.data(), m, out + (size_t)i * k->s)) return -1;
+            }
+            return 0;
+        };
+        const int rc = groot_index_build_msa_dir_with(a.msa_dir.c_str(), &p, fn, &sk, &idx);
+        if (rc) die("%s (%s)", groot_host_last_error(), groot_hip_last_error(ctx));
+        groot_hip_close(ctx);
+    } else if (groot_index_build_msa_dir(a.msa_dir.c_str(), &p, &idx)) die("%s", groot_host_last_error());
     groot_index_view v;
     groot_index_get_view(idx, &v);
     uint32_t masked = 0;

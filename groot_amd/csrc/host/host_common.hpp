@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -71,7 +72,8 @@ struct RawGraph {
 int read_msa_file(const std::string &file, RawGraph &out);   // gfa.ReadMSA + gfa.MSA2GFA
 int read_gfa_file(const std::string &file, RawGraph &out);   // graph.LoadGFA
 int create_groot_graph(const RawGraph &raw, uint32_t id, Graph &g);                 // graph.go:37-147
-int window_graph(Graph &g, unsigned w, unsigned k, unsigned s);                     // graph.go:229-396
+struct WindowSketcher { groot_sketch_fn fn; void *user; std::mutex *mu; };
+int window_graph(Graph &g, unsigned w, unsigned k, unsigned s, const WindowSketcher *sketcher = nullptr);   // graph.go:229-396
 
 } // namespace groot
 

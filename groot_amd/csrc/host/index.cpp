@@ -18,6 +18,7 @@
 #include <dirent.h>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <thread>
 #include <unordered_map>
@@ -339,7 +340,7 @@ int create_groot_graph(const RawGraph &raw, uint32_t id, Graph &g)
 // ---------------------------------------------------------------------------------------------
 // WindowGraph (graph.go:229-396)
 // ---------------------------------------------------------------------------------------------
-int window_graph(Graph &g, unsigned w, unsigned k, unsigned s)
+int window_graph(Graph &g, unsigned w, unsigned k, unsigned s, const WindowSketcher *sketcher)
 {
     g.windows.clear();
     // key "g%dn%do%d" -> windows at that node+offset, in arrival order (paths ascending = one
@@ -363,17 +364,33 @@ int window_graph(Graph &g, unsigned w, unsigned k, unsigned s)
                         }
             if (it != plen) return set_error(GROOT_E_FORMAT, "windowing did not traverse entire path");
         }
-        // per-k-mer MultiHash values once per path (a k-mer's ntHash does not depend on where the
-        // rolling started), then each window's KHF sketch = per-slot min over its w-k+1 k-mers
-        if (!nthash_all((const uint8_t *)pseq.data(), pseq.size(), k, kh))
-            return set_error(GROOT_E_INVALID, "k-mer size %u does not fit path of length %u", k, plen);
-        const size_t nk = kh.size();
-        std::vector<uint64_t> mh(nk * s);
-        for (size_t j = 0; j < nk; j++) {
-            mh[j * s] = kh[j];
-            for (unsigned i = 1; i < s; i++) mh[j * s + i] = multihash(kh[j], i, k);
-        }
         const uint32_t num_windows = plen - w + 1, wk = w - k + 1;
+        std::vector<uint64_t> mh, all_sk;
+        if (sketcher && sketcher->fn) {
+            // external sketcher (the device's RunMinHash mirror): every window of the path as one batch
+            std::vector<uint8_t> cat((size_t)num_windows * w);
+            std::vector<uint64_t> offs64(num_windows + 1);
+            for (uint32_t i = 0; i < num_windows; i++) {
+                memcpy(cat.data() + (size_t)i * w, pseq.data() + i, w);
+                offs64[i] = (uint64_t)i * w;
+            }
+            offs64[num_windows] = (uint64_t)num_windows * w;
+            all_sk.resize((size_t)num_windows * s);
+            std::lock_guard<std::mutex> lock(*sketcher->mu);
+            if (sketcher->fn(sketcher->user, cat.data(), offs64.data(), num_windows, all_sk.data()))
+                return set_error(GROOT_E_DEVICE, "window sketch callback failed");
+        } else {
+            // per-k-mer MultiHash values once per path (a k-mer's ntHash does not depend on where the
+            // rolling started), then each window's KHF sketch = per-slot min over its w-k+1 k-mers
+            if (!nthash_all((const uint8_t *)pseq.data(), pseq.size(), k, kh))
+                return set_error(GROOT_E_INVALID, "k-mer size %u does not fit path of length %u", k, plen);
+            const size_t nk = kh.size();
+            mh.resize(nk * s);
+            for (size_t j = 0; j < nk; j++) {
+                mh[j * s] = kh[j];
+                for (unsigned i = 1; i < s; i++) mh[j * s + i] = multihash(kh[j], i, k);
+            }
+        }
         Window holder;
         bool sketch_sent = false;
         std::vector<uint64_t> sk(s);
@@ -394,9 +411,12 @@ int window_graph(Graph &g, unsigned w, unsigned k, unsigned s)
             lst.push_back(std::move(out));
         };
         for (uint32_t i = 0; i < num_windows; i++) {
-            for (unsigned x = 0; x < s; x++) sk[x] = UINT64_MAX;
-            for (uint32_t j = i; j < i + wk; j++)
-                for (unsigned x = 0; x < s; x++) sk[x] = std::min(sk[x], mh[(size_t)j * s + x]);
+            if (!all_sk.empty()) std::copy(all_sk.begin() + (size_t)i * s, all_sk.begin() + (size_t)(i + 1) * s, sk.begin());
+            else {
+                for (unsigned x = 0; x < s; x++) sk[x] = UINT64_MAX;
+                for (uint32_t j = i; j < i + wk; j++)
+                    for (unsigned x = 0; x < s; x++) sk[x] = std::min(sk[x], mh[(size_t)j * s + x]);
+            }
             bool merge = false;
             if (i != 0) {
                 if (holder.sketch != sk) { emit(); sketch_sent = true; }   // :303-305
@@ -525,7 +545,8 @@ static int check_params(const groot_index_params *p)
     return GROOT_OK;
 }
 
-static int build_from_files(const char *const *files, uint32_t n_files, const groot_index_params *p, bool gfa, groot_index **out)
+static int build_from_files(const char *const *files, uint32_t n_files, const groot_index_params *p, bool gfa, groot_index **out,
+                            const WindowSketcher *sketcher = nullptr)
 {
     if (int rc = check_params(p)) return rc;
     if (!files || !n_files || !out) return set_error(GROOT_E_INVALID, "no input files");
@@ -546,7 +567,7 @@ static int build_from_files(const char *const *files, uint32_t n_files, const gr
                 // src/pipeline/index.go:58-66: mask graphs holding a sequence shorter than the window
                 for (uint32_t len : graphs[i].path_len)
                     if (len < p->window_size) { graphs[i].masked = true; break; }
-                if (!graphs[i].masked) rc = window_graph(graphs[i], p->window_size, p->kmer_size, p->sketch_size);
+                if (!graphs[i].masked) rc = window_graph(graphs[i], p->window_size, p->kmer_size, p->sketch_size, sketcher);
             }
             if (rc) { rcs[i] = rc; errs[i] = groot_host_last_error(); }
         }
@@ -604,6 +625,11 @@ int groot_index_build_gfa_files(const char *const *files, uint32_t n, const groo
 
 int groot_index_build_msa_dir(const char *msa_dir, const groot_index_params *p, groot_index **out)
 {
+    return groot_index_build_msa_dir_with(msa_dir, p, nullptr, nullptr, out);
+}
+
+int groot_index_build_msa_dir_with(const char *msa_dir, const groot_index_params *p, groot_sketch_fn fn, void *user, groot_index **out)
+{
     if (!msa_dir) return set_error(GROOT_E_INVALID, "null msa dir");
     DIR *d = opendir(msa_dir);
     if (!d) return set_error(GROOT_E_IO, "cannot open directory %s", msa_dir);
@@ -620,7 +646,9 @@ int groot_index_build_msa_dir(const char *msa_dir, const groot_index_params *p, 
     for (auto &n : names) full.push_back(std::string(msa_dir) + "/" + n);
     std::vector<const char *> ptrs;
     for (auto &f : full) ptrs.push_back(f.c_str());
-    return build_from_files(ptrs.data(), (uint32_t)ptrs.size(), p, false, out);
+    std::mutex mu;
+    WindowSketcher sk{fn, user, &mu};
+    return build_from_files(ptrs.data(), (uint32_t)ptrs.size(), p, false, out, fn ? &sk : nullptr);
 }
 
 void groot_index_get_view(const groot_index *idx, groot_index_view *view)

@@ -79,10 +79,29 @@ class Index:
         return cls._build(lib().groot_index_build_gfa_files, list(files), params or index_params())
 
     @classmethod
-    def from_msa_dir(cls, msa_dir, params=None):
+    def from_msa_dir(cls, msa_dir, params=None, sketcher=None):
+        """sketcher: optional callable (seq_concat uint8[], seq_off uint64[n+1]) -> uint64[n, s] that computes
+        the window sketches (e.g. device.Aligner.sketch): groot_index_build_msa_dir_with"""
         out = C.c_void_p()
         p = params or index_params()
-        _check(lib().groot_index_build_msa_dir(msa_dir.encode(), C.byref(p), C.byref(out)))
+        if sketcher is None:
+            _check(lib().groot_index_build_msa_dir(msa_dir.encode(), C.byref(p), C.byref(out)))
+            return cls(out.value)
+        s = p.sketch_size
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64))
+
+        def cb(_user, seq, off, n, dst):
+            try:
+                o = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+                sq = np.ctypeslib.as_array(seq, shape=(int(o[n]),)).copy()
+                res = np.ascontiguousarray(sketcher(sq, o), dtype=np.uint64)
+                np.ctypeslib.as_array(dst, shape=(n * s,))[:] = res.reshape(-1)
+                return 0
+            except Exception:
+                return -1
+
+        fn = FN(cb)
+        _check(lib().groot_index_build_msa_dir_with(msa_dir.encode(), C.byref(p), fn, None, C.byref(out)))
         return cls(out.value)
 
     @classmethod

@@ -58,6 +58,13 @@ void groot_index_params_default(groot_index_params *p);
  * cluster*.msa in msa_dir, graph ids = position in the lexically sorted file list
  * (filepath.Glob, cmd/index.go:143). */
 int groot_index_build_msa_dir(const char *msa_dir, const groot_index_params *p, groot_index **out);
+/* Same, with the window sketches (Sequence.RunMinHash on every path window, graph.go:292-296) computed by a
+ * caller-supplied batch function -- e.g. groot_hip_sketch, which makes `groot index` sketch on the GPU while this
+ * library stays free of device code.  fn gets n sequences (seq_off has n+1 entries) and fills out[n*sketch_size];
+ * it is called from one thread at a time and returns 0 on success. */
+typedef int (*groot_sketch_fn)(void *user, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n, uint64_t *out);
+int groot_index_build_msa_dir_with(const char *msa_dir, const groot_index_params *p, groot_sketch_fn fn, void *user,
+                                   groot_index **out);
 int groot_index_build_msa_files(const char *const *files, uint32_t n_files, const groot_index_params *p,
                                 groot_index **out);
 /* same pipeline starting from GFA files (graph.LoadGFA + CreateGrootGraph, graphio.go:115-138,

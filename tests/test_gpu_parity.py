@@ -150,6 +150,29 @@ def test_wide_graph_uses_the_wide_node_records(tmp_path):
     al.close()
 
 
+def test_index_build_with_gpu_sketches(msa_dir, argannot_index, tmp_path):
+    """`groot index` with the window sketches from the device (groot_hip_sketch via the builder's callback, and
+    `groot-hip index --gpu 0`): bit-identical to the host-built index"""
+    import subprocess
+
+    import __graft_entry__ as g
+    from _ffi_empty import empty_view_index
+
+    eng = device.Aligner(empty_view_index(31, 21, 100), max_batch_reads=1 << 16, max_read_len=128)
+    idx = host.Index.from_msa_dir(msa_dir, sketcher=eng.sketch)
+    eng.close()
+    for k, arr in argannot_index.arrays.items():
+        assert np.array_equal(arr, idx.arrays[k]), k
+    cli = g.build_cli()
+    out = tmp_path / "idx"
+    r = subprocess.run([cli, "index", "-m", msa_dir, "-i", str(out), "--gpu", "0", "--log", str(tmp_path / "i.log"), "-p", "8"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    again = host.Index.load(str(out / "groot.gidx"))
+    for k, arr in argannot_index.arrays.items():
+        assert np.array_equal(arr, again.arrays[k]), k
+
+
 def test_edge_cases(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 64, 100)
