@@ -293,6 +293,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
 
     groot_bam *bam = nullptr;
     if (!a.no_align && groot_bam_open(a.bam_out.empty() ? nullptr : a.bam_out.c_str(), &v, nullptr, &bam)) die("%s", groot_host_last_error());
+    if (bam) groot_bam_set_threads(bam, a.proc > 0 ? (uint32_t)a.proc : 0);   // -p: BGZF write concurrency
 
     std::vector<const char *> files;
     for (auto &f : a.fastq) files.push_back(f.c_str());
@@ -306,9 +307,9 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     std::vector<uint64_t> seq_off(a.batch + 1), name_off(a.batch + 1);
     std::vector<groot_trav> travs;
     std::vector<uint64_t> masks;
-    std::vector<groot_aln> alns;
-    std::vector<groot_aln_record> recs;
-    std::vector<uint8_t> rc_seq, rc_qual;
+
+
+
     uint64_t received = 0, length_total = 0, mapped = 0, multimapped = 0, alignments = 0;
     uint32_t first_id = 0;
     for (;;) {
@@ -324,45 +325,13 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         if (!a.no_align && c.travs) {
             travs.resize(c.travs);
             masks.resize(c.travs * v.path_words);
-            uint64_t nt = 0, na = 0;
+            uint64_t nt = 0;
             if (groot_hip_read_travs(ctx, travs.data(), masks.data(), c.travs, &nt)) die("%s", groot_hip_last_error(ctx));
-            alns.resize(c.alignments);
-            if (groot_host_expand_alns(&v, travs.data(), masks.data(), nt, alns.data(), alns.size(), &na)) die("%s", groot_host_last_error());
-            // records of one read share its (possibly reverse-complemented) Seq/Qual
-            recs.clear();
-            uint64_t i = 0;
-            while (i < na) {
-                const uint32_t r = alns[i].read_id - first_id;
-                const uint64_t s0 = seq_off[r], len = seq_off[r + 1] - s0;
-                uint64_t j = i;
-                while (j < na && alns[j].read_id == alns[i].read_id) j++;
-                bool any_rc = false;
-                for (uint64_t t = i; t < j; t++) any_rc |= alns[t].rc != 0;
-                if (any_rc) {   // seqio.go:120-133
-                    rc_seq.resize(len); rc_qual.resize(len);
-                    for (uint64_t b = 0; b < len; b++) {
-                        const uint8_t ch = seq[s0 + len - 1 - b];
-                        rc_seq[b] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'N' ? 'N' : 0;
-                        rc_qual[b] = qual[s0 + len - 1 - b];
-                    }
-                }
-                const size_t base = recs.size();
-                for (uint64_t t = i; t < j; t++) {
-                    groot_aln_record rec;
-                    rec.name = names.data() + name_off[r];
-                    rec.name_len = (uint32_t)(name_off[r + 1] - name_off[r]);
-                    rec.seq = alns[t].rc ? rc_seq.data() : seq.data() + s0;
-                    rec.qual = alns[t].rc ? rc_qual.data() : qual.data() + s0;
-                    rec.seq_len = (uint32_t)len - alns[t].start_clip - alns[t].end_clip;   // alignment.go:117-122
-                    rec.ref_id = alns[t].ref_id; rec.pos = alns[t].pos;
-                    rec.start_clip = alns[t].start_clip; rec.end_clip = alns[t].end_clip;
-                    rec.reverse = alns[t].rc; rec.secondary = alns[t].secondary;
-                    recs.push_back(rec);
-                }
-                if (groot_bam_write(bam, recs.data() + base, recs.size() - base)) die("%s", groot_host_last_error());
-                recs.clear();
-                i = j;
-            }
+            // traversal records -> sam.Records -> BGZF, in parallel over chunks of traversals
+            groot_read_batch rb{seq.data(), qual.data(), seq_off.data(), names.data(), name_off.data(), (uint32_t)n, first_id};
+            uint64_t nrec = 0;
+            if (groot_bam_write_travs(bam, &v, &rb, travs.data(), masks.data(), nt, &nrec)) die("%s", groot_host_last_error());
+            if (nrec != c.alignments) die("internal error: %llu records written, %llu alignments counted", (unsigned long long)nrec, (unsigned long long)c.alignments);
         }
         first_id += (uint32_t)n;
     }

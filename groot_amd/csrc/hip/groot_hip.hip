@@ -365,16 +365,17 @@ static int launch_seed_stage(groot_ctx *c)
     launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
     // processing order of the align stage: reads sorted by (first seed window, likely orientation)
-    unsigned end_bit = 2;
+    unsigned end_bit = 3;                                   // 2 class bits + one bit above the largest window id
     for (uint32_t v = c->n_windows; v; v >>= 1) end_bit++;
     end_bit = std::min(32u, end_bit);
     size_t tmp_bytes = 0;
+    // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
+    // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
     HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p, c->n_reads, 0,
-                                         32, c->stream));
+                                         end_bit, c->stream));
     if (tmp_bytes > c->sort_tmp.n) HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes));
     HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p,
-                                         c->n_reads, 0, 32, c->stream));
-    (void)end_bit;
+                                         c->n_reads, 0, end_bit, c->stream));
     return GROOT_OK;
 }
 

@@ -8,8 +8,10 @@
 // bin = reg2bin(pos, end).
 #include "host_common.hpp"
 
+#include <atomic>
 #include <cstring>
 #include <ctime>
+#include <thread>
 #include <zlib.h>
 
 using namespace groot;
@@ -20,34 +22,43 @@ struct groot_bam {
     std::vector<uint8_t> block;   // uncompressed bytes waiting for the next BGZF block
     std::vector<uint8_t> out;
     uint32_t n_ref = 0;
+    unsigned threads = 1;         // BGZF workers for large groot_bam_write calls (bam.NewWriter's write concurrency)
 };
 
 static const size_t kBgzfBlock = 0xff00;   // max uncompressed payload per block
 
-static int flush_block(groot_bam *b, const uint8_t *data, size_t n)
+// one BGZF member for data[0..n) into out; returns its size or a negative error
+static long compress_block(const uint8_t *data, size_t n, std::vector<uint8_t> &out)
 {
-    b->out.resize(18 + compressBound((uLong)n) + 8);
+    out.resize(18 + compressBound((uLong)n) + 8);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return set_error(GROOT_E_NOMEM, "deflateInit2 failed");
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return GROOT_E_NOMEM;
     zs.next_in = const_cast<Bytef *>(data);
     zs.avail_in = (uInt)n;
-    zs.next_out = b->out.data() + 18;
-    zs.avail_out = (uInt)(b->out.size() - 18 - 8);
+    zs.next_out = out.data() + 18;
+    zs.avail_out = (uInt)(out.size() - 18 - 8);
     const int rc = deflate(&zs, Z_FINISH);
     const size_t clen = zs.total_out;
     deflateEnd(&zs);
-    if (rc != Z_STREAM_END) return set_error(GROOT_E_IO, "deflate failed");
+    if (rc != Z_STREAM_END) return GROOT_E_IO;
     static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-    memcpy(b->out.data(), hdr, 16);
+    memcpy(out.data(), hdr, 16);
     const size_t total = 18 + clen + 8;
-    if (total > 0x10000) return set_error(GROOT_E_IO, "BGZF block too large");
+    if (total > 0x10000) return GROOT_E_IO;
     const uint16_t bsize = (uint16_t)(total - 1);
-    b->out[16] = (uint8_t)bsize; b->out[17] = (uint8_t)(bsize >> 8);
+    out[16] = (uint8_t)bsize; out[17] = (uint8_t)(bsize >> 8);
     const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isize = (uint32_t)n;
-    memcpy(b->out.data() + 18 + clen, &crc, 4);
-    memcpy(b->out.data() + 18 + clen + 4, &isize, 4);
-    if (fwrite(b->out.data(), 1, total, b->f) != total) return set_error(GROOT_E_IO, "BAM write failed");
+    memcpy(out.data() + 18 + clen, &crc, 4);
+    memcpy(out.data() + 18 + clen + 4, &isize, 4);
+    return (long)total;
+}
+
+static int flush_block(groot_bam *b, const uint8_t *data, size_t n)
+{
+    const long total = compress_block(data, n, b->out);
+    if (total < 0) return set_error((int)total, "BGZF compression failed");
+    if (fwrite(b->out.data(), 1, (size_t)total, b->f) != (size_t)total) return set_error(GROOT_E_IO, "BAM write failed");
     return GROOT_OK;
 }
 
@@ -125,18 +136,32 @@ int groot_bam_open(const char *path, const groot_index_view *ix, const char *dat
     return GROOT_OK;
 }
 
-int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
+static size_t record_size(const groot_aln_record &r)
 {
-    if (!b || (n && !recs)) return set_error(GROOT_E_INVALID, "null argument");
-    static const char *code = "=ACMGRSVTWYHKDBN";
-    uint8_t nt16[256];
-    memset(nt16, 15, sizeof nt16);
-    for (int i = 0; i < 16; i++) { nt16[(uint8_t)code[i]] = (uint8_t)i; nt16[(uint8_t)tolower(code[i])] = (uint8_t)i; }
-    std::vector<uint8_t> buf;
-    for (uint64_t i = 0; i < n; i++) {
+    const uint32_t nc = 1 + (r.start_clip ? 1 : 0) + (r.end_clip ? 1 : 0);
+    return 4 + 32 + (r.name_len + 1) + 4 * nc + (r.seq_len + 1) / 2 + r.seq_len;
+}
+
+struct Nt16 {
+    uint8_t t[256];
+    Nt16()
+    {
+        static const char *code = "=ACMGRSVTWYHKDBN";
+        memset(t, 15, sizeof t);
+        for (int i = 0; i < 16; i++) { t[(uint8_t)code[i]] = (uint8_t)i; t[(uint8_t)tolower(code[i])] = (uint8_t)i; }
+    }
+};
+
+// appends the BAM encoding of recs[i0, i1) to buf
+static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i1, std::vector<uint8_t> &buf)
+{
+    static const Nt16 nt;
+    const uint8_t *nt16 = nt.t;
+    const uint8_t *prev_seq = nullptr;
+    uint32_t prev_len = 0;
+    size_t prev_at = 0;   // where the previous record's packed sequence sits in buf
+    for (uint64_t i = i0; i < i1; i++) {
         const groot_aln_record &r = recs[i];
-        if (r.ref_id >= b->n_ref) return set_error(GROOT_E_INVALID, "record %llu: reference id out of range", (unsigned long long)i);
-        if (r.name_len > 254) return set_error(GROOT_E_FORMAT, "read name longer than 254 characters");
         uint32_t cigar[3];
         uint32_t nc = 0;
         if (r.start_clip) cigar[nc++] = ((uint32_t)r.start_clip << 4) | 5;   // H (alignment.go:132-134)
@@ -146,8 +171,9 @@ int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
         const int bin = reg2bin(r.pos, (int64_t)r.pos + (r.seq_len ? r.seq_len : 1));
         const uint32_t l_name = r.name_len + 1;
         const uint32_t body = 32 + l_name + 4 * nc + (r.seq_len + 1) / 2 + r.seq_len;
-        buf.resize(4 + body);
-        uint8_t *p = buf.data();
+        const size_t at = buf.size();
+        buf.resize(at + 4 + body);
+        uint8_t *p = buf.data() + at;
         auto w32 = [&](uint32_t v) { memcpy(p, &v, 4); p += 4; };
         w32(body);
         w32(r.ref_id);
@@ -160,15 +186,186 @@ int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
         w32(0);                                                               // tlen
         memcpy(p, r.name, r.name_len); p += r.name_len; *p++ = 0;
         for (uint32_t c = 0; c < nc; c++) w32(cigar[c]);
-        for (uint32_t j = 0; j < r.seq_len; j += 2) {
-            const uint8_t hi = nt16[r.seq[j]], lo = j + 1 < r.seq_len ? nt16[r.seq[j + 1]] : 0;
-            *p++ = (uint8_t)(hi << 4 | lo);
+        const size_t seq_at = (size_t)(p - buf.data());
+        if (r.seq == prev_seq && r.seq_len == prev_len) {
+            // the records of one read share Seq/Qual (one per path of the traversal): reuse the packed bases
+            memcpy(p, buf.data() + prev_at, (r.seq_len + 1) / 2);
+            p += (r.seq_len + 1) / 2;
+        } else {
+            for (uint32_t j = 0; j < r.seq_len; j += 2) {
+                const uint8_t hi = nt16[r.seq[j]], lo = j + 1 < r.seq_len ? nt16[r.seq[j + 1]] : 0;
+                *p++ = (uint8_t)(hi << 4 | lo);
+            }
         }
+        prev_seq = r.seq; prev_len = r.seq_len; prev_at = seq_at;
         if (r.qual) memcpy(p, r.qual, r.seq_len);                             // raw bytes, not Phred-33 corrected (:121)
         else memset(p, 0xff, r.seq_len);
-        p += r.seq_len;
-        if (int rc = put(b, buf.data(), buf.size())) return rc;
     }
+}
+
+int groot_bam_set_threads(groot_bam *b, uint32_t n_threads)
+{
+    if (!b) return set_error(GROOT_E_INVALID, "null argument");
+    b->threads = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    return GROOT_OK;
+}
+
+int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
+{
+    if (!b || (n && !recs)) return set_error(GROOT_E_INVALID, "null argument");
+    for (uint64_t i = 0; i < n; i++) {
+        if (recs[i].ref_id >= b->n_ref) return set_error(GROOT_E_INVALID, "record %llu: reference id out of range", (unsigned long long)i);
+        if (recs[i].name_len > 254) return set_error(GROOT_E_FORMAT, "read name longer than 254 characters");
+    }
+    if (b->threads > 1 && n >= 1024) {
+        // large call: cut the records into BGZF-block-sized chunks at record boundaries; workers format + deflate
+        // their chunks, the blocks are written in order (what bam.NewWriter's write concurrency does)
+        if (!b->block.empty()) {
+            if (int rc = flush_block(b, b->block.data(), b->block.size())) return rc;
+            b->block.clear();
+        }
+        std::vector<uint64_t> cut{0};
+        size_t acc = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            const size_t sz = record_size(recs[i]);
+            if (acc && acc + sz > kBgzfBlock) { cut.push_back(i); acc = 0; }
+            acc += sz;
+        }
+        cut.push_back(n);
+        const size_t n_chunks = cut.size() - 1;
+        std::vector<std::vector<uint8_t>> outs(n_chunks);
+        std::vector<long> sizes(n_chunks, 0);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            std::vector<uint8_t> raw;
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                raw.clear();
+                format_records(recs, cut[c], cut[c + 1], raw);
+                if (raw.size() > kBgzfBlock) {   // a single huge record: fall back to splitting its bytes
+                    sizes[c] = -1000 - (long)c;
+                    continue;
+                }
+                sizes[c] = compress_block(raw.data(), raw.size(), outs[c]);
+            }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(b->threads, n_chunks);
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (size_t c = 0; c < n_chunks; c++) {
+            if (sizes[c] <= -1000) {             // oversized single record: serial path keeps the stream valid
+                std::vector<uint8_t> raw;
+                format_records(recs, cut[c], cut[c + 1], raw);
+                if (int rc = put(b, raw.data(), raw.size())) return rc;
+                if (!b->block.empty()) {
+                    if (int rc = flush_block(b, b->block.data(), b->block.size())) return rc;
+                    b->block.clear();
+                }
+                continue;
+            }
+            if (sizes[c] < 0) return set_error((int)sizes[c], "BGZF compression failed");
+            if (fwrite(outs[c].data(), 1, (size_t)sizes[c], b->f) != (size_t)sizes[c]) return set_error(GROOT_E_IO, "BAM write failed");
+        }
+        return GROOT_OK;
+    }
+    std::vector<uint8_t> buf;
+    format_records(recs, 0, n, buf);
+    return put(b, buf.data(), buf.size());
+}
+
+int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_read_batch *rb, const groot_trav *travs,
+                          const uint64_t *masks, uint64_t n_trav, uint64_t *n_records)
+{
+    if (!b || !ix || !rb || (n_trav && (!travs || !masks))) return set_error(GROOT_E_INVALID, "null argument");
+    if (n_records) *n_records = 0;
+    if (!n_trav) return GROOT_OK;
+    if (!b->block.empty()) {
+        if (int rc = flush_block(b, b->block.data(), b->block.size())) return rc;
+        b->block.clear();
+    }
+    const uint32_t pw = ix->path_words;
+    const uint64_t kChunk = 256;                                  // traversals per task
+    const size_t n_chunks = (size_t)((n_trav + kChunk - 1) / kChunk);
+    std::vector<std::vector<uint8_t>> outs(n_chunks);
+    std::vector<int> errs(n_chunks, 0);
+    std::vector<uint64_t> nrec(n_chunks, 0);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        std::vector<uint8_t> raw, blk, rcs, rcq;
+        std::vector<groot_aln_record> recs;
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            raw.clear();
+            const uint64_t t0 = c * kChunk, t1 = std::min<uint64_t>(n_trav, t0 + kChunk);
+            for (uint64_t t = t0; t < t1; t++) {
+                const groot_trav &tr = travs[t];
+                const uint32_t r = tr.read_id - rb->first_read_id;
+                if (r >= rb->n_reads || tr.node >= ix->n_nodes || tr.graph_id >= ix->n_graphs) { errs[c] = GROOT_E_INVALID; break; }
+                const uint64_t s0 = rb->seq_off[r], len = rb->seq_off[r + 1] - s0;
+                const uint8_t *sq = rb->seq + s0, *ql = rb->qual ? rb->qual + s0 : nullptr;
+                if (tr.flags & GROOT_TRAV_RC) {                   // seqio.go:120-133
+                    rcs.resize(len); rcq.resize(len);
+                    for (uint64_t i = 0; i < len; i++) {
+                        const uint8_t ch = sq[len - 1 - i];
+                        rcs[i] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'N' ? 'N' : 0;
+                        rcq[i] = ql ? ql[len - 1 - i] : 0xff;
+                    }
+                    sq = rcs.data(); ql = rb->qual ? rcq.data() : nullptr;
+                }
+                const uint8_t sc = (tr.flags & GROOT_TRAV_START_CLIP) ? 1 : 0, ec = (tr.flags & GROOT_TRAV_END_CLIP) ? 1 : 0;
+                bool first = (tr.flags & GROOT_TRAV_FIRST) != 0;
+                recs.clear();
+                const uint32_t np0 = ix->node_np_off[tr.node], np1 = ix->node_np_off[tr.node + 1];
+                for (uint32_t w = 0; w < pw; w++) {
+                    uint64_t m = masks[t * pw + w];
+                    while (m) {
+                        const uint32_t p = w * 64 + (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        uint32_t pos = 0;
+                        for (uint32_t j = np0; j < np1; j++)
+                            if (ix->np_path[j] == p) { pos = ix->np_pos[j] + tr.offset; break; }   // alignment.go:296
+                        groot_aln_record rec;
+                        rec.name = rb->names + rb->name_off[r];
+                        rec.name_len = (uint32_t)(rb->name_off[r + 1] - rb->name_off[r]);
+                        rec.seq = sq; rec.qual = ql;
+                        rec.seq_len = (uint32_t)len - sc - ec;                                    // alignment.go:117-122
+                        rec.ref_id = ix->graph_path_off[tr.graph_id] + p;
+                        rec.pos = pos; rec.start_clip = sc; rec.end_clip = ec;
+                        rec.reverse = (tr.flags & GROOT_TRAV_RC) ? 1 : 0;
+                        rec.secondary = first ? 0 : 1;                                            // alignment.go:147-149
+                        first = false;
+                        if (rec.name_len > 254 || rec.ref_id >= b->n_ref) { errs[c] = GROOT_E_FORMAT; break; }
+                        recs.push_back(rec);
+                    }
+                }
+                if (errs[c]) break;
+                nrec[c] += recs.size();
+                format_records(recs.data(), 0, recs.size(), raw);   // rcs/rcq stay valid until here
+            }
+            if (errs[c]) continue;
+            for (size_t o = 0; o < raw.size(); o += kBgzfBlock) {   // records may span BGZF blocks
+                const long sz = compress_block(raw.data() + o, std::min(kBgzfBlock, raw.size() - o), blk);
+                if (sz < 0) { errs[c] = (int)sz; break; }
+                outs[c].insert(outs[c].end(), blk.begin(), blk.begin() + sz);
+            }
+        }
+    };
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(b->threads, n_chunks));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    uint64_t total = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (errs[c]) return set_error(errs[c], "could not build the BAM records of traversal chunk %zu", c);
+        if (!outs[c].empty() && fwrite(outs[c].data(), 1, outs[c].size(), b->f) != outs[c].size()) return set_error(GROOT_E_IO, "BAM write failed");
+        total += nrec[c];
+    }
+    if (n_records) *n_records = total;
     return GROOT_OK;
 }
 

@@ -156,6 +156,21 @@ typedef struct groot_aln_record {  /* one sam.Record of alignment.go:118-155 */
  * VN:1.1.2, @RG ID:readsID ... (boss.go:55-84).  path NULL or "-" = stdout.  date NULL = now. */
 int groot_bam_open(const char *path, const groot_index_view *idx, const char *date, groot_bam **out);
 int groot_bam_write(groot_bam *bam, const groot_aln_record *recs, uint64_t n);
+/* BGZF write concurrency for large groot_bam_write calls (bam.NewWriter's third argument, boss.go:99); 0 = all cores */
+int groot_bam_set_threads(groot_bam *bam, uint32_t n_threads);
+/* Fast path of the collector: straight from the device's traversal records of one batch to BAM records (the
+ * expansion of groot_host_expand_alns, the record fields of alignment.go:113-156 and the BGZF compression run in
+ * parallel over chunks of traversals; output order = traversal order = read order).  The batch arrays are the ones
+ * groot_fastq_next_batch filled. */
+typedef struct groot_read_batch {
+    const uint8_t *seq, *qual;     /* concatenated Seq / Qual (same offsets)           */
+    const uint64_t *seq_off;       /* [n_reads+1]                                       */
+    const char *names;             /* concatenated read.ID[1:]                          */
+    const uint64_t *name_off;      /* [n_reads+1]                                       */
+    uint32_t n_reads, first_read_id;
+} groot_read_batch;
+int groot_bam_write_travs(groot_bam *bam, const groot_index_view *idx, const groot_read_batch *batch, const groot_trav *travs,
+                          const uint64_t *masks, uint64_t n_trav, uint64_t *n_records);
 int groot_bam_close(groot_bam *bam);
 
 #ifdef __cplusplus

@@ -253,3 +253,72 @@ def test_bam_writer_roundtrip(small_index, tmp_path):
         assert r["seq"].encode() == s and r["qual"] == q and r["cigar"] == "100M" and r["mapq"] == 30
         assert r["flag"] == (0x10 if a["rc"] else 0) | (0x100 if a["secondary"] else 0)
         assert (r["next_ref"], r["next_pos"], r["tlen"]) == (-1, -1, 0)
+
+
+def test_bam_fast_path_equals_record_path(small_index, tmp_path):
+    """groot_bam_write_travs (parallel traversal -> record -> BGZF) writes the same records as expand + write"""
+    import ctypes as C
+
+    from groot_amd import _ffi
+
+    cat, off, lens = synth.reference_sequences(small_index)
+    seq, so, _ = synth.reads_np(cat, off, lens, 3000, 100)
+    qual = np.frombuffer(bytes(33 + (i * 13) % 41 for i in range(len(seq))), dtype=np.uint8).copy()
+    names = b"".join(b"r%d" % i for i in range(3000))
+    noff = np.zeros(3001, dtype=np.uint64)
+    noff[1:] = np.cumsum([len(b"r%d" % i) for i in range(3000)])
+    batch = {"seq": seq, "qual": qual, "seq_off": so, "names": np.frombuffer(names, dtype=np.uint8).copy(), "name_off": noff}
+    run = O.Run(small_index)
+    run.batch(seq, so, first_read_id=100)
+    al = run.alns().astype(device.ALN_DTYPE)
+    # traversal form of the same alignments: one traversal per (read, graph, first-node) group is enough for the
+    # writer, so derive them from the expanded records (path set = the group's path ids)
+    pw = small_index.view.path_words
+    a = small_index.arrays
+    travs, masks = [], []
+    i = 0
+    while i < len(al):
+        j = i
+        m = np.zeros(pw, dtype=np.uint64)
+        while j < len(al) and al["read_id"][j] == al["read_id"][i] and al["graph_id"][j] == al["graph_id"][i] and (j == i or al["secondary"][j]):
+            p = int(al["path_id"][j])
+            if m[p // 64] >> np.uint64(p % 64) & np.uint64(1):
+                break
+            m[p // 64] |= np.uint64(1) << np.uint64(p % 64)
+            j += 1
+        # first node of the alignment: the node of path p that holds pos
+        g, p0, pos = int(al["graph_id"][i]), int(al["path_id"][i]), int(al["pos"][i])
+        node = off_in = None
+        for n in range(int(a["graph_node_off"][g]), int(a["graph_node_off"][g + 1])):
+            for jj in range(int(a["node_np_off"][n]), int(a["node_np_off"][n + 1])):
+                if a["np_path"][jj] == p0 and a["np_pos"][jj] <= pos < a["np_pos"][jj] + (a["node_seq_off"][n + 1] - a["node_seq_off"][n]):
+                    node, off_in = n, pos - int(a["np_pos"][jj])
+        flags = (1 if al["rc"][i] else 0) | (2 if al["start_clip"][i] else 0) | (4 if al["end_clip"][i] else 0) | 8
+        travs.append((int(al["read_id"][i]), g, node, off_in, len(travs) & 0xFFFF, flags, 0))
+        masks.append(m)
+        i = j
+    tr = np.array(travs, dtype=device.TRAV_DTYPE)
+    mk = np.array(masks, dtype=np.uint64)
+    exp = device.expand_alns(small_index, tr, mk)
+    if not all(np.array_equal(exp[f], al[f]) for f in al.dtype.names):
+        pytest.skip("alignment groups of this sample are not expressible as one traversal each")
+    slow, fast = str(tmp_path / "slow.bam"), str(tmp_path / "fast.bam")
+    bw = host.BamWriter(slow, small_index, date="2020-01-01T00:00:00Z")
+    bw.write(al, batch, first_read_id=100)
+    bw.close()
+    H = host.lib()
+    h = C.c_void_p()
+    host._check(H.groot_bam_open(fast.encode(), C.byref(small_index.view), b"2020-01-01T00:00:00Z", C.byref(h)))
+    host._check(H.groot_bam_set_threads(h, C.c_uint32(4)))
+
+    class RB(C.Structure):
+        _fields_ = [("seq", C.c_void_p), ("qual", C.c_void_p), ("seq_off", C.c_void_p), ("names", C.c_void_p), ("name_off", C.c_void_p),
+                    ("n_reads", C.c_uint32), ("first_read_id", C.c_uint32)]
+
+    rb = RB(seq.ctypes.data, qual.ctypes.data, so.ctypes.data, batch["names"].ctypes.data, noff.ctypes.data, 3000, 100)
+    nrec = C.c_uint64()
+    host._check(H.groot_bam_write_travs(h, C.byref(small_index.view), C.byref(rb), tr.ctypes.data_as(C.c_void_p), _ffi.as_ptr(mk, C.c_uint64),
+                                        C.c_uint64(len(tr)), C.byref(nrec)))
+    host._check(H.groot_bam_close(h))
+    assert nrec.value == len(al)
+    assert read_bam(slow) == read_bam(fast)
