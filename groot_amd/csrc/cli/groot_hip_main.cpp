@@ -13,9 +13,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <sys/stat.h>
 #include <vector>
 
@@ -301,24 +304,59 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     if (groot_fastq_open(files.empty() ? nullptr : files.data(), (uint32_t)files.size(), &fq)) die("%s", groot_host_last_error());
     logf("now streaming reads...");
 
+    // DataStreamer/FastqHandler run ahead of the mapper (the reference connects them with buffered channels,
+    // pipeline.go:5): a reader thread parses batch i+1 while batch i is on the GPU and in the BAM writer
     const uint64_t seq_cap = (uint64_t)a.batch * prm.max_read_len, name_cap = (uint64_t)a.batch * 256;
-    std::vector<uint8_t> seq(seq_cap), qual(seq_cap);
-    std::vector<char> names(name_cap);
-    std::vector<uint64_t> seq_off(a.batch + 1), name_off(a.batch + 1);
+    struct Batch {
+        std::vector<uint8_t> seq, qual;
+        std::vector<char> names;
+        std::vector<uint64_t> seq_off, name_off;
+        int64_t n = 0;
+        std::string err;
+    } bufs[2];
+    for (auto &bf : bufs) {
+        bf.seq.resize(seq_cap); bf.qual.resize(seq_cap); bf.names.resize(name_cap);
+        bf.seq_off.resize(a.batch + 1); bf.name_off.resize(a.batch + 1);
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    int filled[2] = {0, 0};      // 0 = free for the reader, 1 = ready for the mapper
+    bool reader_done = false;
+    std::thread reader([&]() {
+        for (int slot = 0;; slot ^= 1) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return filled[slot] == 0; });
+            }
+            Batch &bf = bufs[slot];
+            bf.n = groot_fastq_next_batch(fq, a.batch, bf.seq.data(), bf.qual.data(), bf.seq_off.data(), seq_cap, bf.names.data(),
+                                          bf.name_off.data(), name_cap);
+            if (bf.n < 0) bf.err = groot_host_last_error();
+            const bool last = bf.n <= 0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                filled[slot] = 1;
+                if (last) reader_done = true;
+            }
+            cv.notify_all();
+            if (last) break;
+        }
+    });
     std::vector<groot_trav> travs;
     std::vector<uint64_t> masks;
-
-
-
     uint64_t received = 0, length_total = 0, mapped = 0, multimapped = 0, alignments = 0;
     uint32_t first_id = 0;
-    for (;;) {
-        const int64_t n = groot_fastq_next_batch(fq, a.batch, seq.data(), qual.data(), seq_off.data(), seq_cap, names.data(),
-                                                 name_off.data(), name_cap);
-        if (n < 0) die("%s", groot_host_last_error());
+    for (int slot = 0;; slot ^= 1) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return filled[slot] == 1; });
+        }
+        Batch &bf = bufs[slot];
+        const int64_t n = bf.n;
+        if (n < 0) { reader.join(); die("%s", bf.err.c_str()); }
         if (n == 0) break;
-        length_total += seq_off[n];
-        if (groot_hip_submit(ctx, seq.data(), seq_off.data(), (uint32_t)n, first_id)) die("%s", groot_hip_last_error(ctx));
+        length_total += bf.seq_off[n];
+        if (groot_hip_submit(ctx, bf.seq.data(), bf.seq_off.data(), (uint32_t)n, first_id)) die("%s", groot_hip_last_error(ctx));
         groot_counts c;
         if (groot_hip_wait(ctx, &c)) die("%s", groot_hip_last_error(ctx));   // the reference's panics become fatal errors
         received += c.received; mapped += c.mapped; multimapped += c.multimapped; alignments += c.alignments;
@@ -328,13 +366,20 @@ int run_align(const Args &a)   // cmd/align.go:54-163
             uint64_t nt = 0;
             if (groot_hip_read_travs(ctx, travs.data(), masks.data(), c.travs, &nt)) die("%s", groot_hip_last_error(ctx));
             // traversal records -> sam.Records -> BGZF, in parallel over chunks of traversals
-            groot_read_batch rb{seq.data(), qual.data(), seq_off.data(), names.data(), name_off.data(), (uint32_t)n, first_id};
+            groot_read_batch rb{bf.seq.data(), bf.qual.data(), bf.seq_off.data(), bf.names.data(), bf.name_off.data(), (uint32_t)n, first_id};
             uint64_t nrec = 0;
             if (groot_bam_write_travs(bam, &v, &rb, travs.data(), masks.data(), nt, &nrec)) die("%s", groot_host_last_error());
             if (nrec != c.alignments) die("internal error: %llu records written, %llu alignments counted", (unsigned long long)nrec, (unsigned long long)c.alignments);
         }
         first_id += (uint32_t)n;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            filled[slot] = 0;
+        }
+        cv.notify_all();
     }
+    reader.join();
+    (void)reader_done;
     groot_fastq_close(fq);
     if (received == 0) die("no fastq reads received");                                           // sketch.go:275-277
     logf("\tnumber of reads received from input: %llu", (unsigned long long)received);           // sketch.go:278-280
