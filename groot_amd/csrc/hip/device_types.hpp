@@ -101,7 +101,8 @@ struct SeedArgs {
     uint32_t *seed_count;        // [n_reads]
     uint32_t *seed_win;          // [H][n_reads] slot-major
     uint64_t *sketch_out;        // [n_reads*s] or null
-    uint32_t *sort_key;          // [n_reads] (first seed window, orientation class), kEmpty without seeds; or null
+    uint32_t *sort_key;          // [n_reads] (node span class, first seed window, orientation class), kEmpty without seeds; or null
+    uint32_t sort_span_bits;     // top bits of sort_key that hold min(contained nodes of the window, 2^bits-1); 0 = none
     ReadRec *read_rec;           // [n_reads]
     DeviceCounters *ctr;
 };

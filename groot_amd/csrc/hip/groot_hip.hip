@@ -360,14 +360,17 @@ static int launch_seed_stage(groot_ctx *c)
     a.sort_key = c->sort_key.p;
     a.read_rec = c->read_rec.p;
     a.ctr = c->ctr.p;
+    // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
+    // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
+    unsigned win_bits = 3;                                  // 2 class bits + one bit above the largest window id
+    for (uint32_t v = c->n_windows; v; v >>= 1) win_bits++;
+    win_bits = std::min(32u, win_bits);
+    a.sort_span_bits = std::min(6u, 32u - win_bits);
+    const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((c->n_reads + kBlock - 1) / kBlock);
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
     launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
-    // processing order of the align stage: reads sorted by (first seed window, likely orientation)
-    unsigned end_bit = 3;                                   // 2 class bits + one bit above the largest window id
-    for (uint32_t v = c->n_windows; v; v >>= 1) end_bit++;
-    end_bit = std::min(32u, end_bit);
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are

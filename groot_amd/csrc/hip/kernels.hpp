@@ -299,6 +299,13 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
                 if (cl >= 0) { const int cr = cl ^ 0x2AA; rc_no = !((bits[cr >> 5] >> (cr & 31)) & 1u); }
             }
             key = (min_win << 2) | (fwd_no << 1) | rc_no;
+            if (a.sort_span_bits) {
+                // windows spanning a similar number of nodes need similar numbers of DFS steps: grouping them first keeps the
+                // lanes of a wave in step (the order never changes results, only how well the align stage fills its waves)
+                const WinRec wr = ix.win_rec[min_win];
+                const uint32_t nn = min(wr.cn_end - wr.cn_off, (1u << a.sort_span_bits) - 1u);
+                key |= nn << (32u - a.sort_span_bits);
+            }
         }
         a.sort_key[r] = key;
     }
