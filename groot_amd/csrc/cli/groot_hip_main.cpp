@@ -254,7 +254,10 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     if (a.fastq.empty()) logf("\tinput file: using STDIN");
     if (!is_dir(a.index_dir)) die("no directory found at %s", a.index_dir.c_str());
     const std::string gidx = a.index_dir + "/groot.gidx";
-    if (!is_file(gidx)) die("no file found at %s (build it with `groot-hip index`; Go gob indexes are not readable yet)", gidx.c_str());
+    // an index directory of the reference itself (cmd/align.go:181-182: groot.gg + groot.lshe) is read through the gob reader
+    const std::string gg = a.index_dir + "/groot.gg", lshe = a.index_dir + "/groot.lshe";
+    const bool have_gob = is_file(gg) && is_file(lshe);
+    if (!is_file(gidx) && !have_gob) die("no file found at %s (nor groot.gg + groot.lshe)", gidx.c_str());
     std::string graph_dir = a.graph_dir;
     if (graph_dir.empty()) {   // cmd/align.go:24: ./groot-graphs-<timestamp>
         char ts[32];
@@ -270,7 +273,8 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     for (auto &f : a.fastq) logf("\tinput file: %s", f.c_str());
     logf("loading the index information...");
     groot_index *idx = nullptr;
-    if (groot_index_load(gidx.c_str(), &idx)) die("%s", groot_host_last_error());
+    if (is_file(gidx) ? groot_index_load(gidx.c_str(), &idx) : groot_index_load_gob(gg.c_str(), lshe.c_str(), &idx))
+        die("%s", groot_host_last_error());
     groot_index_view v;
     groot_index_get_view(idx, &v);
     logf("\tk-mer size: %u", v.kmer_size);

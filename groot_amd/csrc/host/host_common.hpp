@@ -77,6 +77,13 @@ int window_graph(Graph &g, unsigned w, unsigned k, unsigned s, const WindowSketc
 
 } // namespace groot
 
+struct groot_index;
+namespace groot {
+int check_index_params(const groot_index_params *p);
+// Store + windows -> flat arrays of include/groot_index.h (window ids in canonical order: graphs ascending, then Graph::windows order)
+int flatten_graphs(std::vector<Graph> &graphs, const groot_index_params &p, groot_index **out);
+} // namespace groot
+
 // owning storage behind the C handle
 struct groot_index {
     groot_index_view v{};

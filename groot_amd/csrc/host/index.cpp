@@ -471,7 +471,7 @@ void groot_index::bind()
     v.win_sketch = win_sketch.data();
 }
 
-static int flatten(std::vector<Graph> &graphs, const groot_index_params &p, groot_index **out)
+int groot::flatten_graphs(std::vector<Graph> &graphs, const groot_index_params &p, groot_index **out)
 {
     auto idx = new groot_index();
     auto &v = idx->v;
@@ -535,7 +535,7 @@ static int flatten(std::vector<Graph> &graphs, const groot_index_params &p, groo
     return GROOT_OK;
 }
 
-static int check_params(const groot_index_params *p)
+int groot::check_index_params(const groot_index_params *p)
 {
     if (!p) return set_error(GROOT_E_INVALID, "null index params");
     if (p->kmer_size == 0 || p->kmer_size > 64) return set_error(GROOT_E_UNSUPPORTED, "k-mer size must be in [1,64]");
@@ -548,7 +548,7 @@ static int check_params(const groot_index_params *p)
 static int build_from_files(const char *const *files, uint32_t n_files, const groot_index_params *p, bool gfa, groot_index **out,
                             const WindowSketcher *sketcher = nullptr)
 {
-    if (int rc = check_params(p)) return rc;
+    if (int rc = check_index_params(p)) return rc;
     if (!files || !n_files || !out) return set_error(GROOT_E_INVALID, "no input files");
     std::vector<Graph> graphs(n_files);
     std::vector<std::string> errs(n_files);
@@ -580,7 +580,7 @@ static int build_from_files(const char *const *files, uint32_t n_files, const gr
     size_t n_sketched = 0;
     for (auto &g : graphs) n_sketched += g.masked ? 0 : 1;
     if (!n_sketched) return set_error(GROOT_E_INVALID, "could not create and sketch any graphs");
-    return flatten(graphs, *p, out);
+    return flatten_graphs(graphs, *p, out);
 }
 
 // ---- .gidx file: header + raw arrays ---------------------------------------------------------

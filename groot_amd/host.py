@@ -110,6 +110,14 @@ class Index:
         _check(lib().groot_index_load(path.encode(), C.byref(out)))
         return cls(out.value)
 
+    @classmethod
+    def load_gob(cls, index_dir):
+        """an index directory written by the reference's `groot index`: groot.gg + groot.lshe (cmd/align.go:93-107)"""
+        out = C.c_void_p()
+        _check(lib().groot_index_load_gob(os.path.join(index_dir, "groot.gg").encode(), os.path.join(index_dir, "groot.lshe").encode(),
+                                          C.byref(out)))
+        return cls(out.value)
+
     def save(self, path):
         _check(lib().groot_index_save(self._h, path.encode()))
 
@@ -133,6 +141,18 @@ class Index:
             if local_path in ps:
                 out.append(self.node_seq(n))
         return b"".join(out)
+
+
+def gob_to_json(data):
+    """every top-level value of a Go encoding/gob stream, decoded by the reader behind Index.load_gob"""
+    import json
+
+    b = np.frombuffer(bytes(data), dtype=np.uint8)
+    need = C.c_uint64(0)
+    _check(lib().groot_gob_to_json(_ffi.as_ptr(b, C.c_uint8), C.c_uint64(len(b)), None, C.c_uint64(0), C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(lib().groot_gob_to_json(_ffi.as_ptr(b, C.c_uint8), C.c_uint64(len(b)), buf, C.c_uint64(need.value), C.byref(need)))
+    return json.loads(buf.value.decode())
 
 
 def window_sketch(seq, k, s):

@@ -73,6 +73,18 @@ int groot_index_build_gfa_files(const char *const *files, uint32_t n_files, cons
                                 groot_index **out);
 int groot_index_save(const groot_index *idx, const char *path);   /* flat little-endian .gidx file */
 int groot_index_load(const char *path, groot_index **out);
+/* replaces Info.Load + ContainmentIndex.Load (src/pipeline/runtime.go:75-91, src/lshe/lshe.go:95-120; called at
+ * cmd/align.go:93-107): reads an index directory written by the reference's `groot index` -- the Go encoding/gob
+ * streams <dir>/groot.gg (pipeline.Info incl. graph.Store) and <dir>/groot.lshe (lshe.ContainmentIndex with its
+ * WindowLookup map) -- into the flat index.  Window ids are assigned in the canonical order (GraphID, Key.Node,
+ * Key.OffSet, the "-<i>" suffix of the WindowLookup key, src/pipeline/index.go:195-203).  GROOT_E_FORMAT for a stream
+ * that does not decode or whose cross references do not resolve. */
+int groot_index_load_gob(const char *gg_path, const char *lshe_path, groot_index **out);
+/* renders every top-level value of a gob stream as JSON text (structs as objects holding the fields present on the
+ * wire, maps as [[key,value],...]): the decoder behind groot_index_load_gob, exposed for inspection and for the
+ * known-answer tests on the byte vectors of the gob documentation.  *needed = bytes incl. the terminating NUL; the
+ * text is written only when cap >= *needed. */
+int groot_gob_to_json(const uint8_t *data, uint64_t n, char *out, uint64_t cap, uint64_t *needed);
 void groot_index_get_view(const groot_index *idx, groot_index_view *view);
 void groot_index_free(groot_index *idx);
 

@@ -119,3 +119,14 @@ def test_travis_e2e_flow(cli, msa_dir, tmp_path):
     b7 = {x["name"] for x in recs if x["ref"] == "argannot~~~(Bla)B-7~~~AF189304:1-747"}
     assert b7 == {n.decode() for n, _, _ in reads}
     assert all(x["cigar"] == "150M" for x in recs)
+    # the same index as a directory of the reference's own files (groot.gg + groot.lshe, cmd/align.go:93-107)
+    import gobenc
+
+    gob_dir = str(tmp_path / "gobidx")
+    gobenc.write_index_dir(host.Index.load(os.path.join(idx_dir, "groot.gidx")), gob_dir, shuffle_seed=3)
+    bam2 = str(tmp_path / "o2.bam")
+    r = run([cli, "align", "-i", gob_dir, "-f", os.path.join(DATA, "bla-b7-150bp-5x.fq"), "-t", "0.99", "--bam", bam2,
+             "-g", str(tmp_path / "g2"), "--log", str(tmp_path / "a2.log")])
+    assert r.returncode == 0, r.stderr
+    text2, refs2, recs2 = read_bam(bam2)
+    assert refs2 == refs and recs2 == recs
