@@ -413,7 +413,8 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB (<= 2 workgroups... per CU budget)
     {
-        const uint32_t stride = ((c->batch_max_len + 16) / 4) | 1u;
+        // 8 zero bytes, then the read in whole 16-byte pieces up to 12 bytes past its end; odd dword stride = no bank conflicts
+        const uint32_t stride = (2 + 4 * ((c->batch_max_len + 27) / 16)) | 1u;
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
     a.ctr = c->ctr.p;
@@ -802,8 +803,8 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
     }
     c->n_trav = c->hctr.n_trav;
 #ifdef GROOT_WORK_COUNTERS
-    fprintf(stderr, "[groot work] wave_iters fetch=%llu scan=%llu dfs=%llu lane_steps=%llu\n", c->hctr.dbg[0], c->hctr.dbg[1],
-            c->hctr.dbg[2], c->hctr.dbg[3]);
+    for (int e = 0; e < 32; e++)
+        if (c->hctr.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, c->hctr.dbg[e], c->hctr.dbg[32 + e]);
 #endif
     if (c->profiling) {
         (void)hipEventElapsedTime(&c->ms.h2d, c->ev[0], c->ev[1]);

@@ -457,7 +457,6 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_reads[];
     __shared__ unsigned long long red[4];
     uint32_t *my_lds = lds_reads + (size_t)threadIdx.x * a.lds_stride_dw;
-    uint32_t lds_rc = 2;                                   // orientation currently staged (2 = none)
     const DeviceIndex &ix = a.ix;
     const Rec *recs = reinterpret_cast<const Rec *>(a.node_rec);
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
@@ -465,10 +464,10 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     if (a.ctr->flags & kFlagSeedOverflow) return;
     unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
 #ifdef GROOT_WORK_COUNTERS
-    unsigned long long dbg[4] = {0, 0, 0, 0};
-#define GROOT_COUNT(i) (dbg[i]++)
+    uint32_t ev = 0;                                       // events of this lane in the current wave iteration
+#define GROOT_EV(i) (ev |= 1u << (i))
 #else
-#define GROOT_COUNT(i) ((void)0)
+#define GROOT_EV(i) ((void)0)
 #endif
 
     uint32_t phase = PH_WAIT;
@@ -500,18 +499,22 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     for (int i = 0; i < PW; i++) mask[i] = 0;
 
     // oriented bases [d, d+8) of the current view during DFS
+    // LDSR: the lane's slice holds 8 zero bytes, then the read as it came (forward), staged when the read was fetched.
+    // Oriented bases [i, i+8) are slice bytes [8+i, 16+i) forward, or the reverse complement of slice bytes [len-i, len-i+8).
     auto dfs_chunk = [&](uint32_t d) -> uint64_t {
         if (!LDSR) return read_chunk(p, len, rc, clip_lo, d);
         const uint32_t i = d + clip_lo;
-        const uint32_t *wp = my_lds + (i >> 2);
+        const uint32_t o = rc ? len - i : 8u + i;
+        const uint32_t *wp = my_lds + (o >> 2);
         const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2];
-        const uint32_t sh = (i & 3u) * 8u;
-        return (uint64_t)__funnelshift_r(x0, x1, sh) | ((uint64_t)__funnelshift_r(x1, x2, sh) << 32);
+        const uint32_t sh = (o & 3u) * 8u;
+        const uint64_t v = (uint64_t)__funnelshift_r(x0, x1, sh) | ((uint64_t)__funnelshift_r(x1, x2, sh) << 32);
+        return rc ? revcomp8(v) : v;
     };
     auto set_view = [&](uint32_t clip_lo_, uint32_t eff_, uint32_t clip_flag) {
         clip_lo = clip_lo_; eff = eff_;
         tflags = (rc ? GROOT_TRAV_RC : 0u) | clip_flag;
-        pre8 = read_chunk(p, len, rc, clip_lo, 0);
+        pre8 = dfs_chunk(0);
     };
     auto scan_range = [&](uint32_t node, uint32_t s0, uint32_t nlen, uint32_t from, uint32_t to) {
         sc_node = node; sc_s0 = s0; sc_len = nlen; sc_pos = from; sc_end = to;
@@ -567,6 +570,16 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     };
 
     for (;;) {
+#ifdef GROOT_WORK_COUNTERS
+        for (int e = 0; e < 32; e++) {                         // convergent point: tally the previous iteration
+            const unsigned long long b = __ballot((ev >> e) & 1u);
+            if (b && (threadIdx.x & 63) == 0) {
+                atomicAdd(&a.ctr->dbg[e], 1ull);
+                atomicAdd(&a.ctr->dbg[32 + e], (unsigned long long)__popcll(b));
+            }
+        }
+        ev = 0;
+#endif
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
         {
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
                         const uint64_t sl = base + chunk_pos + rank;
                         if (rank < room) {
-                            if (sl < a.n_reads) { slot = (uint32_t)sl; phase = PH_FETCH; }
+                            if (sl < a.n_reads) { slot = (uint32_t)sl; phase = PH_FETCH; GROOT_EV(20); }
                             else phase = PH_DONE;
                         }
                     }
@@ -598,14 +611,12 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
         }
         const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
-#ifdef GROOT_WORK_COUNTERS
-        if ((threadIdx.x & 63) == 0) dbg[run == PH_FETCH ? 0 : (run == PH_SCAN ? 1 : 2)]++;   // wave iterations per phase
-        if (phase == run) dbg[3]++;                                                              // lane steps
-#endif
         if (phase != run) continue;
+        GROOT_EV(run);                                          // events 0,1,2: a step of FETCH / SCAN / DFS
 
         if (run == PH_FETCH) {
             if (!have_read) {
+                GROOT_EV(3);
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
                 const uint4 *rq = reinterpret_cast<const uint4 *>(a.read_rec + r);
                 const uint4 ra = rq[0], rb = rq[1];               // one 32-byte record per read
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 len = ra.z;
                 p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
                 sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
-                if (LDSR && len + 12 > a.lds_stride_dw * 4) {  // longer than the max_len the batch was submitted with
+                if (LDSR && 2 + 4 * ((len + 27) >> 4) > a.lds_stride_dw) {   // longer than the max_len the batch was submitted with
                     atomicOr(&a.ctr->flags, kFlagLongRead);
                     a.trav_cnt[r] = 0;
                     phase = PH_WAIT;
@@ -627,7 +638,23 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 n_graphs = 0; ord = 0; last = -1;
                 done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
                 have_read = true;
-                lds_rc = 2;
+                if (LDSR) {                                   // stage the read: 64 bytes per pass, the four loads in flight together
+                    my_lds[0] = 0; my_lds[1] = 0;
+                    for (uint32_t b = 0; b < len; b += 64) {       // reads at most 15 bytes past the read's end
+                        const uint4 *src = reinterpret_cast<const uint4 *>(p + b);   // unaligned 16-byte global loads
+                        const bool h1 = b + 16 < len, h2 = b + 32 < len, h3 = b + 48 < len;
+                        uint4 v0, v1 = {}, v2 = {}, v3 = {};
+                        __builtin_memcpy(&v0, src, 16);
+                        if (h1) __builtin_memcpy(&v1, src + 1, 16);
+                        if (h2) __builtin_memcpy(&v2, src + 2, 16);
+                        if (h3) __builtin_memcpy(&v3, src + 3, 16);
+                        uint32_t *d = my_lds + 2 + (b >> 2);
+                        d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w;
+                        if (h1) { d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w; }
+                        if (h2) { d[8] = v2.x; d[9] = v2.y; d[10] = v2.z; d[11] = v2.w; }
+                        if (h3) { d[12] = v3.x; d[13] = v3.y; d[14] = v3.z; d[15] = v3.w; }
+                    }
+                }
             }
             // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
             uint32_t nw = kEmpty;
@@ -642,6 +669,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                     if ((long long)cand > last && cand < nw) nw = cand;
                 }
             if (nw == kEmpty) {                               // every seed of the read handled
+                GROOT_EV(4);
                 a.trav_cnt[r] = ord;
                 mapped++;                                     // boss.go:195-200
                 if (n_graphs > 1) multimapped++;
@@ -661,13 +689,14 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             l1_hi = wa.w;                                     // alignment.go:36 and :199-201, folded at open
             cn_begin = wb.x; cn_end = wb.y;
             seed_s0 = wb.z; seed_len = wb.w;
+            GROOT_EV(5);
             begin_orientation(0);
         } else if (run == PH_SCAN) {
-            if (sc_pos >= sc_end) { next_range(); continue; }   // only after a DFS that used the range's last offset
-            // up to 12 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
+            if (sc_pos >= sc_end) { GROOT_EV(6); next_range(); continue; }   // only after a DFS that used the range's last offset
+            // up to 16 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
             const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
             const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
-            const uint32_t npos = min(12u, sc_end - sc_pos);
+            const uint32_t npos = min(16u, sc_end - sc_pos);
             const int room = (int)(sc_len - sc_pos);          // bases from sc_pos to the node end
             uint64_t c_lo = low_bytes((int)npos), c_hi = low_bytes((int)npos - 8);
             const uint32_t kf = min(4u, eff);
@@ -680,10 +709,11 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 c_lo &= match_or_n(window8(w0, w1, b), rb) | ~need_lo;
                 c_hi &= match_or_n(window8(w1, w2, b), rb) | ~need_hi;
             }
-            uint32_t j = 12;
+            uint32_t j = 16;
             if (c_lo) j = (uint32_t)__builtin_ctzll(c_lo) >> 3;
             else if (c_hi) j = 8 + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
             if (j >= npos) {
+                GROOT_EV(7);
                 sc_pos += npos;
                 if (sc_pos >= sc_end) next_range();           // set up the next range now: no empty step
                 continue;
@@ -693,27 +723,43 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             const uint32_t off = sc_pos + j;
             sc_pos = off + 1;
             if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
+                GROOT_EV(8);
                 if (sc_pos >= sc_end) next_range();
                 continue;
-            }
-            if (LDSR && lds_rc != rc) {                        // stage this orientation of the read once
-                for (uint32_t c8 = 0; c8 < len; c8 += 8) {
-                    const uint64_t v = read_chunk(p, len, rc, 0, c8);
-                    my_lds[c8 >> 2] = (uint32_t)v;
-                    my_lds[(c8 >> 2) + 1] = (uint32_t)(v >> 32);
-                }
-                lds_rc = rc;
             }
             node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
             cur8 = pre8;
 #pragma unroll
             for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
             phase = PH_DFS;
+            GROOT_EV(10);
         } else {
             // ---- DFS: match up to 16 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
             RecRegs<PW> rec;
             rec.load(recs + cur);
+            if (coff != 0 && !(cur == node0 && coff == noff0 && dist == 0)) GROOT_EV(18);
             const uint32_t take = min(rec.seq_len() - coff, eff - dist);
+#ifdef GROOT_DFS_V2
+            // all of the node that this read covers, 32 bases per pass: the four 8-base loads of a pass (graph side from
+            // HBM/L2, read side from LDS) are issued together, so a pass costs one memory round trip, not four
+            uint32_t nb = 0;
+            bool ok = true;
+            {
+                const uint8_t *gb = ix.bases + rec.seq_off() + coff;
+                while (nb < take && nb < GROOT_DFS_V2) {
+                    const uint32_t m = take - nb;                                  // bases left in this node
+                    const uint64_t g0 = (nb == 0 && coff == 0) ? rec.first8() : ld8(gb + nb);
+                    const uint64_t g1 = m > 8 ? ld8(gb + nb + 8) : 0, g2 = m > 16 ? ld8(gb + nb + 16) : 0, g3 = m > 24 ? ld8(gb + nb + 24) : 0;
+                    const uint64_t r0 = nb == 0 ? cur8 : dfs_chunk(dist + nb);
+                    const uint64_t r1 = m > 8 ? dfs_chunk(dist + nb + 8) : 0, r2 = m > 16 ? dfs_chunk(dist + nb + 16) : 0,
+                                   r3 = m > 24 ? dfs_chunk(dist + nb + 24) : 0;
+                    ok = prefix_ok(g0, r0, m) && (m <= 8 || prefix_ok(g1, r1, m - 8)) && (m <= 16 || prefix_ok(g2, r2, m - 16)) &&
+                         (m <= 24 || prefix_ok(g3, r3, m - 24));
+                    if (!ok) break;
+                    nb += min(m, 32u);
+                }
+            }
+#else
             const uint32_t nb = min(take, 32u);
             bool ok = true;
             if (nb) {
@@ -723,17 +769,24 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 for (uint32_t i = 8; ok && i < nb; i += 8)
                     ok = prefix_ok(ld8(gb + i), dfs_chunk(dist + i), nb - i);
             }
+#endif
             bool backtrack = !ok;
+            if (!ok) GROOT_EV(12);
+            if (take > 8) GROOT_EV(11);
+            if (take > 32) GROOT_EV(21);
             if (ok) {
                 dist += nb; coff += nb;
                 cur8 = dfs_chunk(dist);
                 if (nb == take) {                              // node consumed (or read finished)
+                    GROOT_EV(13);
                     bool any = false;
 #pragma unroll
                     for (int i = 0; i < PW; i++) { mask[i] &= rec.mask(i); any |= mask[i] != 0; }
                     const uint32_t rdeg = rec.deg();
                     if (dist == eff || rdeg == 0) {             // :229-236 report the traversal
                         if (any) {
+                            GROOT_EV(14);
+                            if (ord) GROOT_EV(19);
                             groot_trav t;
                             t.read_id = read_id; t.graph_id = g; t.node = node0; t.offset = noff0;
                             t.ord = (uint16_t)ord;
@@ -776,6 +829,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                         if (first == kEmpty) backtrack = true;
                         else {
                             if (more != kEmpty) {              // further candidates stay pending
+                                GROOT_EV(15);
                                 const size_t si = (size_t)sp * a.n_threads + gtid;
                                 a.stk_hdr[si] = (uint64_t)cur | ((uint64_t)more << 32) | ((uint64_t)dist << 48);
 #pragma unroll
@@ -794,10 +848,12 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 }
             }
             if (backtrack) {
+                GROOT_EV(16);
                 if (sp == 0) {                                 // performAlignment is over
                     if (emitted) { done_graph = g; phase = PH_FETCH; }   // alignment found for (read, graph)
                     else phase = PH_SCAN;
                 } else {                                       // resume at the newest pending neighbour
+                    GROOT_EV(17);
                     const size_t si = (size_t)(sp - 1) * a.n_threads + gtid;
                     const uint64_t hdr = a.stk_hdr[si];
                     const uint32_t pn = (uint32_t)hdr, e = (uint32_t)(hdr >> 32) & 0xFFFFu;
@@ -827,12 +883,6 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
         }
     }
 
-#ifdef GROOT_WORK_COUNTERS
-    for (int i = 0; i < 4; i++) {
-        const unsigned long long v = block_sum(dbg[i], red);
-        if (threadIdx.x == 0 && v) atomicAdd(&a.ctr->dbg[i], v);
-    }
-#endif
     alns = block_sum(alns, red);
     mapped = block_sum(mapped, red);
     multimapped = block_sum(multimapped, red);
