@@ -60,10 +60,16 @@ static_assert(sizeof(WinRec) == 32, "window record is two 16-byte words");
 struct alignas(16) ReadRec {
     uint64_t seq_off;      // first base of the read in the batch buffer
     uint32_t len;
-    uint32_t cnt_flags;    // seeds (bits 0..30) | read holds a byte > 'T' (bit 31)
+    uint32_t cnt_flags;    // seeds (bits 0..23) | kRec* verdicts of the seed stage on the FIRST seed window | byte > 'T' (bit 31)
     uint32_t seed[4];      // the first four seed windows (all of them for 99.9% of reads); more: seed_win slots
 };
 static_assert(sizeof(ReadRec) == 32, "read record is two 16-byte words");
+
+// cnt_flags bits 24..29: the hierarchy level(s) of AlignRead that cannot produce a start position for the forward read
+// (F) / its reverse complement (R) in the read's first seed window, as established by the seed stage
+constexpr uint32_t kRecCountMask = 0x00FFFFFFu;
+constexpr uint32_t kRecNo12F = 1u << 24, kRecNo3F = 1u << 25, kRecNo4F = 1u << 26;   // R = F << 3
+constexpr uint32_t kPrefixWords = 256;   // words per window in DeviceIndex::win_prefix
 
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
@@ -76,9 +82,9 @@ struct DeviceIndex {
     const uint32_t *win_graph, *cn_node;
     const WinRec *win_rec;          // [n_windows]
     const uint64_t *win_sketch;     // [n_windows*s]
-    // per window: which 5-base read prefixes (2 bits per base, A=0 C=1 T=2 G=3) can be spelled from any
-    // level-1 / level-2 start position of AlignRead (alignment.go:34-70); 1024 bits = 32 words per window
-    const uint32_t *win_kmer5;
+    // per window: which read prefixes (6-mer codes of oriented bases [0,6) and [6,12), 2 bits per base A=0 C=1 T=2 G=3)
+    // can be spelled from any level-1 / level-2 start position of AlignRead (alignment.go:34-70): 2 x 4096 bits
+    const uint32_t *win_prefix;
     // lookup structures
     const ExactEntry *exact;        // open addressing, exact_mask+1 slots
     uint32_t exact_mask;

@@ -50,7 +50,7 @@ struct groot_ctx {
     groot_stage_ms ms{};
 
     // index in HBM
-    DevBuf<uint32_t> win_kmer5, edges, win_graph, cn_node,
+    DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
         band_keys, band_ids;
     DevBuf<uint8_t> bases, q_k, q_l;
     DevBuf<uint16_t> q_min_eq;
@@ -70,7 +70,7 @@ struct groot_ctx {
     uint32_t seed_slots = 0;
     DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm;
     DevBuf<char> sort_tmp;
-    DevBuf<ReadRec> read_rec;
+    DevBuf<ReadRec> read_rec, read_rec_sorted;
     DevBuf<uint64_t> sketches;
     DevBuf<DeviceCounters> ctr;
     DeviceCounters hctr{};
@@ -185,47 +185,111 @@ uint32_t round_pw(uint32_t pw)
 // offsets 0..10, :47-70) to have any chance: the spellings of 5 bases from each such start position,
 // following every OutEdge at node ends ('N' spells anything; a sink before 5 bases accepts anything, as
 // dfsRecursive reports a traversal that runs off the graph, :229).  Sound: never clears a spellable prefix.
-struct Kmer5Builder {
+// Which read prefixes can AlignRead's levels 1-2 start on?  Two tables per window: 6-mer codes (2 bits per base,
+// A=0 C=1 T=2 G=3) of oriented read bases [0,6) and [6,12) that some level-1 / level-2 start position of the window
+// (alignment.go:34-70) can spell -- following every out-edge, with the graph's 'N' and the graph ends (a read may
+// hang off a sink, alignment.go:229-236) as wildcards.  Sound filters: a read whose code is absent from either table
+// cannot pass performAlignment from any of those starts.
+struct PrefixTables {
+    static constexpr int K = 6, T = 2;
     const groot_index_view *v;
-    uint32_t *bits;   // 32 words of the current window
-    void set_all(int code, int have)   // every completion of the `have` bases already in code
-    {
-        const int free_bits = 2 * (5 - have);
-        for (int x = 0; x < (1 << free_bits); x++) {
-            const int c = code | (x << (2 * have));
-            bits[c >> 5] |= 1u << (c & 31);
-        }
-    }
-    void walk(uint32_t node, uint32_t off, int code, int have)
-    {
-        const uint32_t s0 = v->node_seq_off[node], len = v->node_seq_off[node + 1] - s0;
-        while (off < len && have < 5) {
-            const uint8_t b = v->bases[s0 + off];
-            if (b == 'N') {
-                for (int c = 0; c < 4; c++) walk_from(node, off + 1, code | (c << (2 * have)), have + 1);
-                return;
+    // per table and graph position: the codes spelled from there, as (code | have << 12); have < K = the walk fell off
+    // a sink after `have` coded bases and every completion counts
+    std::vector<uint32_t> start[T];      // [n_bases + 1]
+    std::vector<uint16_t> ent[T];
+
+    struct Walker {
+        const groot_index_view *v;
+        int d0;                          // first coded depth of this table
+        std::vector<uint16_t> *out;
+        void walk(uint32_t node, uint32_t off, int depth, int code)
+        {
+            const uint32_t s0 = v->node_seq_off[node], len = v->node_seq_off[node + 1] - s0;
+            while (off < len && depth < d0 + K) {
+                if (depth >= d0) {
+                    const uint8_t b = v->bases[s0 + off];
+                    if (b == 'N') {
+                        for (int c = 0; c < 4; c++) walk(node, off + 1, depth + 1, code | (c << (2 * (depth - d0))));
+                        return;
+                    }
+                    code |= (int)((b >> 1) & 3) << (2 * (depth - d0));
+                }
+                depth++; off++;
             }
-            code |= (int)((b >> 1) & 3) << (2 * have);
-            have++; off++;
+            if (depth == d0 + K) { out->push_back((uint16_t)(code | (K << 12))); return; }
+            const uint32_t e0 = v->node_edge_off[node], e1 = v->node_edge_off[node + 1];
+            if (e0 == e1) { out->push_back((uint16_t)(code | (std::max(0, depth - d0) << 12))); return; }
+            for (uint32_t e = e0; e < e1; e++) walk(v->edges[e], 0, depth, code);
         }
-        if (have == 5) { bits[code >> 5] |= 1u << (code & 31); return; }
-        const uint32_t e0 = v->node_edge_off[node], e1 = v->node_edge_off[node + 1];
-        if (e0 == e1) { set_all(code, have); return; }
-        for (uint32_t e = e0; e < e1; e++) walk(v->edges[e], 0, code, have);
-    }
-    void walk_from(uint32_t node, uint32_t off, int code, int have) { walk(node, off, code, have); }
-    void window(uint32_t w, uint32_t *out)
+    };
+
+    void positions(unsigned nt)
     {
-        bits = out;
+        // pass 1 per node (threads take nodes round-robin), then stitched into one CSR per table
+        std::vector<std::vector<uint16_t>> per_node[T];
+        std::vector<std::vector<uint32_t>> per_node_cnt[T];
+        for (int t = 0; t < T; t++) { per_node[t].resize(v->n_nodes); per_node_cnt[t].resize(v->n_nodes); }
+        std::vector<std::thread> th;
+        for (unsigned x = 0; x < nt; x++)
+            th.emplace_back([&, x]() {
+                for (uint32_t n = x; n < v->n_nodes; n += nt) {
+                    const uint32_t len = v->node_seq_off[n + 1] - v->node_seq_off[n];
+                    for (int t = 0; t < T; t++) {
+                        Walker wk{v, t * K, &per_node[t][n]};
+                        per_node_cnt[t][n].resize(len);
+                        for (uint32_t o = 0; o < len; o++) {
+                            const size_t before = per_node[t][n].size();
+                            wk.walk(n, o, 0, 0);
+                            auto &e = per_node[t][n];
+                            std::sort(e.begin() + before, e.end());
+                            e.erase(std::unique(e.begin() + before, e.end()), e.end());
+                            per_node_cnt[t][n][o] = (uint32_t)(e.size() - before);
+                        }
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < T; t++) {
+            start[t].assign(v->n_bases + 1, 0);
+            size_t total = 0;
+            for (uint32_t n = 0; n < v->n_nodes; n++) total += per_node[t][n].size();
+            ent[t].reserve(total);
+            for (uint32_t n = 0; n < v->n_nodes; n++) {      // node order = order of `bases`
+                const uint32_t s0 = v->node_seq_off[n];
+                uint32_t run = (uint32_t)ent[t].size();
+                for (size_t o = 0; o < per_node_cnt[t][n].size(); o++) { start[t][s0 + o] = run; run += per_node_cnt[t][n][o]; }
+                ent[t].insert(ent[t].end(), per_node[t][n].begin(), per_node[t][n].end());
+            }
+            start[t][v->n_bases] = (uint32_t)ent[t].size();
+        }
+    }
+    // nodes are stored back to back in `bases` and the CSR was filled in that order: p's entries end where p+1's begin
+    void add(int t, size_t pos, uint32_t *bits) const
+    {
+        for (uint32_t i = start[t][pos]; i < start[t][pos + 1]; i++) {
+            const int code = ent[t][i] & 0xFFF, have = ent[t][i] >> 12;
+            if (have >= K) { bits[code >> 5] |= 1u << (code & 31); continue; }
+            const int free_bits = 2 * (K - have);
+            for (int x = 0; x < (1 << free_bits); x++) {
+                const int c = (code & ((1 << (2 * have)) - 1)) | (x << (2 * have));
+                bits[c >> 5] |= 1u << (c & 31);
+            }
+        }
+    }
+    void window(uint32_t w, uint32_t *out) const     // out: T * 128 words
+    {
         const uint32_t seed = v->win_node[w], off0 = v->win_offset[w];
         const uint32_t seed_len = v->node_seq_off[seed + 1] - v->node_seq_off[seed];
         const uint64_t last = (uint64_t)off0 + v->win_merge_span[w] + v->window_size;
         const uint32_t hi = (uint32_t)std::min<uint64_t>(seed_len, last + 1);
-        for (uint32_t o = off0; o < hi; o++) walk(seed, o, 0, 0);
-        for (uint32_t c = v->win_cn_off[w]; c < v->win_cn_off[w + 1]; c++) {
-            const uint32_t n = v->cn_node[c];
-            const uint32_t nlen = v->node_seq_off[n + 1] - v->node_seq_off[n];
-            for (uint32_t o = 0; o < std::min(nlen, 11u); o++) walk(n, o, 0, 0);
+        for (int t = 0; t < T; t++) {
+            uint32_t *bits = out + t * 128;
+            for (uint32_t o = off0; o < hi; o++) add(t, (size_t)v->node_seq_off[seed] + o, bits);
+            for (uint32_t c = v->win_cn_off[w]; c < v->win_cn_off[w + 1]; c++) {
+                const uint32_t n = v->cn_node[c];
+                const uint32_t nlen = v->node_seq_off[n + 1] - v->node_seq_off[n];
+                for (uint32_t o = 0; o < std::min(nlen, 11u); o++) add(t, (size_t)v->node_seq_off[n] + o, bits);
+            }
         }
     }
 };
@@ -379,6 +443,8 @@ static int launch_seed_stage(groot_ctx *c)
     if (tmp_bytes > c->sort_tmp.n) HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes));
     HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p,
                                          c->n_reads, 0, end_bit, c->stream));
+    hipLaunchKernelGGL(gather_recs_kernel, grid, dim3(kBlock), 0, c->stream, c->perm.p, c->read_rec.p, c->read_rec_sorted.p, c->n_reads);
+    HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
 
@@ -394,7 +460,7 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     a.seed_count = c->seed_count.p;
     a.seed_win = c->seed_win.p;
     a.perm = c->perm.p;
-    a.read_rec = c->read_rec.p;
+    a.read_rec = c->read_rec_sorted.p;   // in perm order (gather_recs_kernel)
     a.no_align = c->prm.no_exact_align;
     a.update_weights = update_weights ? 1 : 0;
     a.attempts = c->attempts_ptr;
@@ -538,16 +604,18 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->node_rec, recs.data(), recs.size()));
     }
     {
-        std::vector<uint32_t> k5((size_t)v->n_windows * 32, 0);
-        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<uint32_t> k5((size_t)v->n_windows * kPrefixWords, 0);
+        const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        PrefixTables pt;
+        pt.v = v;
+        pt.positions(nt);
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
-                Kmer5Builder b{v, nullptr};
-                for (uint32_t w = t; w < v->n_windows; w += nt) b.window(w, k5.data() + (size_t)w * 32);
+                for (uint32_t w = t; w < v->n_windows; w += nt) pt.window(w, k5.data() + (size_t)w * kPrefixWords);
             });
         for (auto &x : th) x.join();
-        HIP_TRY(c, upload(c->win_kmer5, k5.data(), k5.size()));
+        HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
     {
@@ -619,7 +687,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     x.k = v->kmer_size; x.s = s; x.w = v->window_size; x.num_window_kmers = v->num_window_kmers;
     x.n_windows = n; x.n_nodes = v->n_nodes; x.pw = c->pw;
     x.edges = c->edges.p; x.bases = c->bases.p;
-    x.win_kmer5 = c->win_kmer5.p; x.win_graph = c->win_graph.p; x.win_rec = c->win_rec.p; x.cn_node = c->cn_node.p;
+    x.win_prefix = c->win_prefix.p; x.win_graph = c->win_graph.p; x.win_rec = c->win_rec.p; x.cn_node = c->cn_node.p;
     x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
 
@@ -630,6 +698,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->seed_count.alloc(R));
     HIP_TRY(c, c->sort_key.alloc(R));
     HIP_TRY(c, c->read_rec.alloc(R));
+    HIP_TRY(c, c->read_rec_sorted.alloc(R));
     HIP_TRY(c, c->sort_key_out.alloc(R));
     HIP_TRY(c, c->perm.alloc(R));
     {

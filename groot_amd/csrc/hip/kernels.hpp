@@ -57,17 +57,79 @@ __host__ __device__ __forceinline__ uint64_t sketch_hash_step(uint64_t h, uint64
 }
 #define GROOT_SKETCH_HASH_INIT 0x9E3779B97F4A7C15ULL
 
-// 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 10-bit code of the first 5 bases of r8,
+// 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 12-bit code of the first 6 bases of r8,
 // or -1 if one of them is not ACGT (such a base can still meet the graph's 'N' wildcard)
-__host__ __device__ __forceinline__ int kmer5_code(uint64_t r8)
+__host__ __device__ __forceinline__ int kmer6_code(uint64_t r8)
 {
     int code = 0;
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
         const unsigned b = (unsigned)(r8 >> (8 * i)) & 0xFF;
         if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return -1;
         code |= (int)((b >> 1) & 3) << (2 * i);
     }
     return code;
+}
+// DeviceIndex::win_prefix of one window: can no level-1/2 start position spell oriented read bases [0,12) = (c0, c1)?
+__device__ __forceinline__ bool prefix_absent(const uint32_t *tab, uint64_t c0, uint64_t c1, uint32_t eff)
+{
+    if (eff < 6) return false;
+    const int a = kmer6_code(c0);
+    if (a >= 0 && !((tab[a >> 5] >> (a & 31)) & 1u)) return true;
+    if (eff < 12) return false;
+    const int b = kmer6_code((c0 >> 48) | (c1 << 16));
+    return b >= 0 && !((tab[128 + (b >> 5)] >> (b & 31)) & 1u);
+}
+
+// ---- 8 bases at a time (SWAR on the ASCII bytes; little endian: byte 0 = first base) ----
+constexpr uint64_t kLo7 = 0x7F7F7F7F7F7F7F7FULL, kHi1 = 0x8080808080808080ULL, kOnes = 0x0101010101010101ULL;
+
+__device__ __forceinline__ uint64_t ld8(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);   // unaligned 8-byte global load
+    return v;
+}
+// bit 7 of byte i set iff byte i of x is non-zero
+__device__ __forceinline__ uint64_t nonzero_bytes(uint64_t x) { return (((x & kLo7) + kLo7) | x) & kHi1; }
+// bit 7 of byte i set iff graph base i differs from read base i and is not the 'N' wildcard (alignment.go:212-222)
+__device__ __forceinline__ uint64_t mismatch8(uint64_t g, uint64_t r)
+{
+    return nonzero_bytes(g ^ r) & nonzero_bytes(g ^ (kOnes * 'N'));
+}
+// reverse-complement 8 read bytes: v holds read bytes [e-7, e]; result byte 0 = comp(read[e]).
+// A<->T differ by 0x15, C<->G by 0x04, and bit 1 of the ASCII code tells the two pairs apart.  Bytes
+// other than ACGT map to bytes other than ACGT, i.e. they never equal a graph base -- the same outcome as
+// complementBases' 0 (and 'N' only ever meets the graph's wildcard).
+__device__ __forceinline__ uint64_t revcomp8(uint64_t v)
+{
+    const uint64_t r = __builtin_bswap64(v);
+    const uint64_t cg = (r >> 1) & kOnes;
+    return r ^ ((cg * 0x04) | ((cg ^ kOnes) * 0x15));
+}
+
+// 8 oriented read bases starting at logical index d of the view (rc, clip_lo); bytes past the view's
+// end are don't-care (callers mask them).  Never reads before p: the batch buffer may start there.
+__device__ __forceinline__ uint64_t read_chunk(const uint8_t *p, uint32_t len, uint32_t rc, uint32_t clip_lo, uint32_t d)
+{
+    const uint32_t i = d + clip_lo;
+    if (!rc) return ld8(p + i);
+    const int e = (int)len - 1 - (int)i;                 // oriented base 0 = comp(read[e])
+    const uint64_t v = e >= 7 ? ld8(p + (e - 7)) : (e >= 0 ? ld8(p) << (8 * (7 - e)) : 0);
+    return revcomp8(v);
+}
+
+// first m (<= 8) bases equal under the 'N' wildcard rule?
+__device__ __forceinline__ bool prefix_ok(uint64_t g8, uint64_t r8, uint32_t m)
+{
+    const uint64_t mm = mismatch8(g8, r8);
+    return m >= 8 ? mm == 0 : (mm & ((1ULL << (8 * m)) - 1)) == 0;
+}
+
+// bytes [j, j+8) of the 16-byte little-endian window (lo, hi)
+__device__ __forceinline__ uint64_t window8(uint64_t lo, uint64_t hi, uint32_t j)
+{
+    const uint32_t sh = 8 * j;
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
 // LDS layout of sketch_seed_kernel (bytes)
@@ -151,12 +213,10 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
     const uint64_t M = (uint64_t)k * GROOT_MULTI_SEED;
     const uint32_t nk = len - k + 1;
     unsigned high = 0;                       // any byte > 'T': RevComplement would panic (seqio.go:126)
-    uint64_t first5 = 0, last5 = 0;          // first / last 5 bases of the read (for the scheduling key below)
     auto sketch = [&](const unsigned char *rd) {
         uint64_t fh = 0, rh = 0;
         for (uint32_t j = 0; j < k; j++) {   // ntf64 / ntr64 of the first k-mer in one pass
             const unsigned b = rd[j];
-            if (j < 5) first5 |= (uint64_t)b << (8 * j);
             high |= b > 'T';
             fh = rol1(fh) ^ tabF[b];
             rh ^= rol64(tabC[b & 7], j);
@@ -189,8 +249,6 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
             fh = rol1(fh) ^ tabFout[prev] ^ tabF[end];
             rh = ror1(rh) ^ tabCout[prev & 7] ^ tabCin[end & 7];
         }
-        if (len >= 5)
-            for (uint32_t j = 0; j < 5; j++) last5 |= (uint64_t)rd[len - 1 - j] << (8 * j);   // reversed: base len-1 first
     };
     if (in_lds) sketch(lds_reads + (o0 - base16));   // LDS address space
     else sketch(a.seq + o0);                         // span too large for LDS: straight from HBM
@@ -276,44 +334,65 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
         }
     }
     a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
-    if (a.read_rec) {
-        uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, n_hits | (high ? 0x80000000u : 0u));
-        rq[1] = make_uint4(s0, s1, s2, s3);
-    }
     // scheduling key for the align stage: reads are processed in (first seed window, likely orientation) order so
     // that neighbouring lanes walk the same graph nodes in step; reads without seeds sort to the end.  Processing
     // order only -- every output is addressed by read.
+    // What the align stage will find for the read's first seed window, per orientation: levels 1-2 cannot start
+    // anywhere (prefix tables), the level-3 / level-4 single start position fails its first comparison (alignment.go:72-103).
+    // The align stage skips exactly these steps; the sort key groups reads whose orientations have work left, so that
+    // neighbouring lanes walk the same graph nodes in step.  Processing order only -- every output is addressed by read.
+    uint32_t verdicts = 0;
     if (a.sort_key) {
         uint32_t key = kEmpty;
         if (n_hits) {
-            // can the forward read / its reverse complement be spelled from the window's level-1/2 start positions?
-            // (1,0) = forward read, (0,1) = reverse read that leaves the forward hierarchy after one probe,
-            // (1,1) = a full failing scan is possible, (0,0) = nothing will align: four classes of similar work
-            uint32_t fwd_no = 0, rc_no = 0;
-            if (len >= 5) {
-                const uint32_t *bits = ix.win_kmer5 + (size_t)min_win * 32;
-                const int cf = kmer5_code(first5);
-                if (cf >= 0) fwd_no = !((bits[cf >> 5] >> (cf & 31)) & 1u);
-                const int cl = kmer5_code(last5);          // codes A=0 C=1 T=2 G=3: complement = code ^ 2
-                if (cl >= 0) { const int cr = cl ^ 0x2AA; rc_no = !((bits[cr >> 5] >> (cr & 31)) & 1u); }
+            const WinRec wr = ix.win_rec[min_win];
+            const uint32_t *tab = ix.win_prefix + (size_t)min_win * kPrefixWords;
+            const uint8_t *p = a.seq + o0;
+            const bool in_node = wr.offset < wr.seed_len;         // else levels 3-4 are skipped (alignment.go:199-201)
+            const uint64_t g8 = in_node ? ld8(ix.bases + wr.seed_s0 + wr.offset) : 0;
+            const uint32_t m34 = min(min(wr.seed_len - wr.offset, len - 1), 8u);
+            uint32_t dead = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 2; t++) {
+                const uint64_t c0 = read_chunk(p, len, t, 0, 0), c1 = read_chunk(p, len, t, 0, 8);
+                uint32_t vt = prefix_absent(tab, c0, c1, len) ? kRecNo12F : 0u;
+                if (!in_node || !prefix_ok(g8, (c0 >> 8) | (c1 << 56), m34)) vt |= kRecNo3F;    // read[1:] at (seed, OffSet)
+                if (!in_node || !prefix_ok(g8, c0, m34)) vt |= kRecNo4F;                         // read[:len-1] there
+                if (vt == (kRecNo12F | kRecNo3F | kRecNo4F)) dead |= 2u >> t;
+                verdicts |= vt << (3 * t);
             }
-            key = (min_win << 2) | (fwd_no << 1) | rc_no;
+            key = (min_win << 2) | dead;
             if (a.sort_span_bits) {
-                // windows spanning a similar number of nodes need similar numbers of DFS steps: grouping them first keeps the
-                // lanes of a wave in step (the order never changes results, only how well the align stage fills its waves)
-                const WinRec wr = ix.win_rec[min_win];
+                // windows spanning a similar number of nodes need similar numbers of DFS steps
                 const uint32_t nn = min(wr.cn_end - wr.cn_off, (1u << a.sort_span_bits) - 1u);
                 key |= nn << (32u - a.sort_span_bits);
             }
         }
         a.sort_key[r] = key;
     }
+    if (a.read_rec) {
+        uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (high ? 0x80000000u : 0u));
+        rq[1] = make_uint4(s0, s1, s2, s3);
+    }
     if (n_hits) {
         atomicAdd(&a.ctr->seeds, (unsigned long long)n_hits);
         atomicMax(&a.ctr->max_seeds, n_hits);
         if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
     }
+}
+
+// read records in processing order: the align stage then fetches slot-consecutive (coalesced) records instead of
+// chasing perm[slot] -> read_rec[read]
+__global__ __launch_bounds__(kBlock) void gather_recs_kernel(const uint32_t *__restrict__ perm, const ReadRec *__restrict__ in,
+                                                             ReadRec *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + perm[i]);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + i);
+    const uint4 x = src[0], y = src[1];
+    dst[0] = x; dst[1] = y;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,58 +409,6 @@ __device__ __forceinline__ unsigned comp_base(unsigned b)
     case 'N': return 'N';
     default: return 0;
     }
-}
-
-// ---- 8 bases at a time (SWAR on the ASCII bytes; little endian: byte 0 = first base) ----
-constexpr uint64_t kLo7 = 0x7F7F7F7F7F7F7F7FULL, kHi1 = 0x8080808080808080ULL, kOnes = 0x0101010101010101ULL;
-
-__device__ __forceinline__ uint64_t ld8(const uint8_t *p)
-{
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);   // unaligned 8-byte global load
-    return v;
-}
-// bit 7 of byte i set iff byte i of x is non-zero
-__device__ __forceinline__ uint64_t nonzero_bytes(uint64_t x) { return (((x & kLo7) + kLo7) | x) & kHi1; }
-// bit 7 of byte i set iff graph base i differs from read base i and is not the 'N' wildcard (alignment.go:212-222)
-__device__ __forceinline__ uint64_t mismatch8(uint64_t g, uint64_t r)
-{
-    return nonzero_bytes(g ^ r) & nonzero_bytes(g ^ (kOnes * 'N'));
-}
-// reverse-complement 8 read bytes: v holds read bytes [e-7, e]; result byte 0 = comp(read[e]).
-// A<->T differ by 0x15, C<->G by 0x04, and bit 1 of the ASCII code tells the two pairs apart.  Bytes
-// other than ACGT map to bytes other than ACGT, i.e. they never equal a graph base -- the same outcome as
-// complementBases' 0 (and 'N' only ever meets the graph's wildcard).
-__device__ __forceinline__ uint64_t revcomp8(uint64_t v)
-{
-    const uint64_t r = __builtin_bswap64(v);
-    const uint64_t cg = (r >> 1) & kOnes;
-    return r ^ ((cg * 0x04) | ((cg ^ kOnes) * 0x15));
-}
-
-// 8 oriented read bases starting at logical index d of the view (rc, clip_lo); bytes past the view's
-// end are don't-care (callers mask them).  Never reads before p: the batch buffer may start there.
-__device__ __forceinline__ uint64_t read_chunk(const uint8_t *p, uint32_t len, uint32_t rc, uint32_t clip_lo, uint32_t d)
-{
-    const uint32_t i = d + clip_lo;
-    if (!rc) return ld8(p + i);
-    const int e = (int)len - 1 - (int)i;                 // oriented base 0 = comp(read[e])
-    const uint64_t v = e >= 7 ? ld8(p + (e - 7)) : (e >= 0 ? ld8(p) << (8 * (7 - e)) : 0);
-    return revcomp8(v);
-}
-
-// first m (<= 8) bases equal under the 'N' wildcard rule?
-__device__ __forceinline__ bool prefix_ok(uint64_t g8, uint64_t r8, uint32_t m)
-{
-    const uint64_t mm = mismatch8(g8, r8);
-    return m >= 8 ? mm == 0 : (mm & ((1ULL << (8 * m)) - 1)) == 0;
-}
-
-// bytes [j, j+8) of the 16-byte little-endian window (lo, hi)
-__device__ __forceinline__ uint64_t window8(uint64_t lo, uint64_t hi, uint32_t j)
-{
-    const uint32_t sh = 8 * j;
-    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
 // sum v over the workgroup; result valid in thread 0
@@ -482,6 +509,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     uint32_t len = 0, cnt = 0, q = 0, n_graphs = 0, ord = 0, read_id = 0;
     uint32_t sd0 = kEmpty, sd1 = kEmpty, sd2 = kEmpty, sd3 = kEmpty;   // the read's first four seed windows
     uint32_t high_byte = 0;                                // RevComplement would panic on this read
+    uint32_t cls = 0;                                      // kRec* verdicts of the read record >> 24; bit 6: they apply to w
     long long last = -1;                                   // last seed window handled (ascending window id order)
     uint32_t done_graph = kEmpty, cur_graph = kEmpty;
     bool group_rc_called = false;
@@ -519,19 +547,20 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     auto scan_range = [&](uint32_t node, uint32_t s0, uint32_t nlen, uint32_t from, uint32_t to) {
         sc_node = node; sc_s0 = s0; sc_len = nlen; sc_pos = from; sc_end = to;
     };
-    auto begin_orientation = [&](uint32_t t) {             // 1. seed offset shuffling (alignment.go:34-45)
+    // verdict of the seed stage for the current orientation (f = kRecNo12F / kRecNo3F / kRecNo4F)
+    auto verdict = [&](uint32_t f) -> bool { return (cls & 0x40u) && ((cls >> (rc ? 3 : 0)) & (f >> 24)); };
+    // 1. seed offset shuffling (alignment.go:34-45).  Returns true when levels 1 and 2 cannot start anywhere for this
+    // orientation (prefix tables): the ranges are left empty and the caller moves on through the hierarchy.
+    auto start_orientation = [&](uint32_t t) -> bool {
         rc = t; level = 1;
         set_view(0, len, 0);
         scan_range(seed, seed_s0, seed_len, off0, l1_hi);
         phase = PH_SCAN;
-        // can any level-1/2 start position spell the first 5 bases of this orientation?  If not, both
-        // levels are known to fail: leave an empty level-2 range so the next step moves on to level 3.
-        if (eff >= 5) {
-            const int code = kmer5_code(pre8);
-            if (code >= 0 && !((ix.win_kmer5[(size_t)w * 32 + (code >> 5)] >> (code & 31)) & 1u)) {
-                level = 2; cn_cur = cn_end; sc_pos = sc_end = 0;
-            }
-        }
+        bool no;
+        if (cls & 0x40u) no = verdict(kRecNo12F);
+        else no = prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff >= 12 ? dfs_chunk(8) : 0, eff);
+        if (no) { level = 2; cn_cur = cn_end; sc_pos = sc_end = 0; }
+        return no;
     };
     // the current scan range is used up: move through the hierarchy until a non-empty range or the end
     auto next_range = [&]() {
@@ -540,6 +569,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             else if (level == 2) cn_cur++;
             else if (level == 3) {
                 level = 4;                                  // 4. hard clip the last base (:87-103)
+                if (verdict(kRecNo4F)) continue;            // its single start position fails the first comparison
                 set_view(0, len - 1, GROOT_TRAV_END_CLIP);
                 scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
                 return;
@@ -549,8 +579,9 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                     group_rc_called = true;
                     if (high_byte) panics++;                 // seqio.go:126 index out of range
                 }
-                if (rc == 0) begin_orientation(1);
-                else phase = PH_FETCH;                       // both orientations failed: next mapping
+                if (rc == 0) {
+                    if (start_orientation(1)) continue;
+                } else phase = PH_FETCH;                     // both orientations failed: next mapping
                 return;
             }
             if (level == 2) {                               // 2. seed node shuffling (:47-70): offsets 0..10
@@ -562,6 +593,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 }
                 level = 3;                                  // 3. hard clip the first base (:72-85)
                 if (off0 >= seed_len) { level = 4; continue; }   // :199-201 holds for levels 3 and 4 alike
+                if (verdict(kRecNo3F)) continue;
                 set_view(1, len - 1, GROOT_TRAV_START_CLIP);
                 scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
                 return;
@@ -618,10 +650,11 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             if (!have_read) {
                 GROOT_EV(3);
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
-                const uint4 *rq = reinterpret_cast<const uint4 *>(a.read_rec + r);
+                const uint4 *rq = reinterpret_cast<const uint4 *>(a.read_rec + slot);   // records are in slot order
                 const uint4 ra = rq[0], rb = rq[1];               // one 32-byte record per read
                 const uint32_t sc = ra.w;
-                cnt = min(sc & 0x7FFFFFFFu, a.seed_slots);   // overflow already flagged; batch is re-run
+                cnt = min(sc & kRecCountMask, a.seed_slots);   // overflow already flagged; batch is re-run
+                cls = a.perm ? (sc >> 24) & 0x3Fu : 0x80u;     // bit 7: no verdicts without the seed stage's sort keys
                 if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
                 high_byte = sc >> 31;
                 len = ra.z;
@@ -677,6 +710,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 phase = PH_WAIT;
                 continue;
             }
+            cls = (cls & 0xBFu) | ((last < 0 && !(cls & 0x80u)) ? 0x40u : 0u);   // bit 6: w is the read's first seed window
             w = nw; last = nw;
             const uint4 *wq = reinterpret_cast<const uint4 *>(ix.win_rec + w);
             const uint4 wa = wq[0], wb = wq[1];               // the whole lshe.Key in one 32-byte load
@@ -690,7 +724,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             cn_begin = wb.x; cn_end = wb.y;
             seed_s0 = wb.z; seed_len = wb.w;
             GROOT_EV(5);
-            begin_orientation(0);
+            if (start_orientation(0)) next_range();
         } else if (run == PH_SCAN) {
             if (sc_pos >= sc_end) { GROOT_EV(6); next_range(); continue; }   // only after a DFS that used the range's last offset
             // up to 16 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
@@ -739,27 +773,6 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             rec.load(recs + cur);
             if (coff != 0 && !(cur == node0 && coff == noff0 && dist == 0)) GROOT_EV(18);
             const uint32_t take = min(rec.seq_len() - coff, eff - dist);
-#ifdef GROOT_DFS_V2
-            // all of the node that this read covers, 32 bases per pass: the four 8-base loads of a pass (graph side from
-            // HBM/L2, read side from LDS) are issued together, so a pass costs one memory round trip, not four
-            uint32_t nb = 0;
-            bool ok = true;
-            {
-                const uint8_t *gb = ix.bases + rec.seq_off() + coff;
-                while (nb < take && nb < GROOT_DFS_V2) {
-                    const uint32_t m = take - nb;                                  // bases left in this node
-                    const uint64_t g0 = (nb == 0 && coff == 0) ? rec.first8() : ld8(gb + nb);
-                    const uint64_t g1 = m > 8 ? ld8(gb + nb + 8) : 0, g2 = m > 16 ? ld8(gb + nb + 16) : 0, g3 = m > 24 ? ld8(gb + nb + 24) : 0;
-                    const uint64_t r0 = nb == 0 ? cur8 : dfs_chunk(dist + nb);
-                    const uint64_t r1 = m > 8 ? dfs_chunk(dist + nb + 8) : 0, r2 = m > 16 ? dfs_chunk(dist + nb + 16) : 0,
-                                   r3 = m > 24 ? dfs_chunk(dist + nb + 24) : 0;
-                    ok = prefix_ok(g0, r0, m) && (m <= 8 || prefix_ok(g1, r1, m - 8)) && (m <= 16 || prefix_ok(g2, r2, m - 16)) &&
-                         (m <= 24 || prefix_ok(g3, r3, m - 24));
-                    if (!ok) break;
-                    nb += min(m, 32u);
-                }
-            }
-#else
             const uint32_t nb = min(take, 32u);
             bool ok = true;
             if (nb) {
@@ -769,7 +782,6 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 for (uint32_t i = 8; ok && i < nb; i += 8)
                     ok = prefix_ok(ld8(gb + i), dfs_chunk(dist + i), nb - i);
             }
-#endif
             bool backtrack = !ok;
             if (!ok) GROOT_EV(12);
             if (take > 8) GROOT_EV(11);
