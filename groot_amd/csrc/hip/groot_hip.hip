@@ -484,7 +484,7 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
     a.ctr = c->ctr.p;
-    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, kOvfShards * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 1) * sizeof(uint32_t), c->stream));   // + the chunk cursor
     launch_align(c->pw, a, dim3(blocks), c->stream);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
@@ -713,7 +713,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->mask_first.alloc((size_t)R * c->pw));
     HIP_TRY(c, c->trav_cnt.alloc(R));
     HIP_TRY(c, c->trav_off.alloc(R));
-    HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards));
+    HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 1));
     if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 4))) return rc;
     if (int rc = alloc_ovf(c, std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     #ifndef GROOT_ALIGN_BLOCKS_PER_CU

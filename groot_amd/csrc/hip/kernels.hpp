@@ -438,7 +438,10 @@ enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
 #define GROOT_REFILL 64
 #endif
 constexpr int kRefill = GROOT_REFILL;          // waiting lanes that trigger a refill
-constexpr uint32_t kWaveChunk = 512;          // consecutive slots a wave takes before moving on
+#ifndef GROOT_WAVE_CHUNK
+#define GROOT_WAVE_CHUNK 128
+#endif
+constexpr uint32_t kWaveChunk = GROOT_WAVE_CHUNK;   // consecutive slots a wave takes before asking for more
 
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
 __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
@@ -500,8 +503,14 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     uint32_t phase = PH_WAIT;
     // reads are handed out per wavefront: chunks of kWaveChunk consecutive (sorted) slots, round-robin over the
     // waves of the grid, consecutive slots to the lanes that ask together
-    const uint32_t n_waves = a.n_threads >> 6, wave_id = gtid >> 6;
-    uint32_t chunk_j = 0, chunk_pos = 0;                   // wave-uniform cursor
+    // (a wavefront that runs out takes the next chunk from a global cursor: no static shares, so no wave idles while
+    // another still holds several chunks)
+    auto take_chunk = [&]() -> uint32_t {
+        uint32_t c = 0;
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(a.ovf_cnt + kOvfShards, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    };
+    uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor
     uint32_t slot = 0, r = 0;
     // ---- read ----
     bool have_read = false;
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
             if (cw >= kRefill || (cw && !(bf | bs | bd))) {
-                const uint64_t base = ((uint64_t)chunk_j * n_waves + wave_id) * kWaveChunk;
+                const uint64_t base = (uint64_t)chunk_j * kWaveChunk;
                 if (base >= a.n_reads) {                       // this wave's share is used up
                     if (phase == PH_WAIT) phase = PH_DONE;
                 } else {
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                         }
                     }
                     chunk_pos += min((uint32_t)cw, room);
-                    if (chunk_pos >= kWaveChunk) { chunk_pos = 0; chunk_j++; }
+                    if (chunk_pos >= kWaveChunk) { chunk_pos = 0; chunk_j = take_chunk(); }
                 }
                 continue;
             }
