@@ -141,11 +141,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k_ms, a_ms, s_ms = [], [], []
+    k_ms, a_ms, s_ms, g_ms = [], [], [], []
     for _ in range(args.steps):
         counts = step()
         ms = al.stage_ms()
-        k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"])
+        k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"]); g_ms.append(ms["schedule"])
     if dist is not None:
         dist.all_reduce(d_att)  # per-(kmerCount, window) IncrementSubPath counts: the only exchange
     torch.cuda.synchronize()
@@ -169,7 +169,7 @@ def main():
         pw = index.view.path_words
         seed_bytes = R * (READ_LEN + 8 + 4) + 4 * counts["seeds"]
         align_bytes = R * (READ_LEN + 8 + 4 + 4) + 4 * counts["seeds"] + (20 + 8 * pw) * counts["travs"] + 4 * counts["seeds"]
-        kernels = {"sketch_seed_kernel<21,4,false>": (seed_ms, seed_bytes), "align_kernel<3>": (align_ms, align_bytes)}
+        kernels = {"sketch_seed_kernel<21,4,false,6>": (seed_ms, seed_bytes), "align_kernel<3,true>": (align_ms, align_bytes)}
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -187,7 +187,7 @@ def main():
             "config": {"workload": "configs[2]: full pipeline incl. on-GPU graph-traversal alignment, 100 bp error-free reads sampled from arg-annot.90, index k=31 s=21 w=100 x=8 y=4, t=0.99",
                        "reads_per_gpu_per_step": R, "read_len": READ_LEN, "parallelism": f"reads sharded x{world}, index replicated",
                        "per_step_counts": counts,
-                       "stage_ms": {"sketch_seed": seed_ms, "align": align_ms, "order": order_ms}},
+                       "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
                          "note": "integer hashing / graph walking: the binding ceiling is VALU issue, not HBM (DESIGN.md)",

@@ -435,6 +435,7 @@ static int launch_seed_stage(groot_ctx *c)
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
     launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
@@ -877,7 +878,8 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
 #endif
     if (c->profiling) {
         (void)hipEventElapsedTime(&c->ms.h2d, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&c->ms.sketch_seed, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->ms.sketch_seed, c->ev[1], c->ev[5]);
+        (void)hipEventElapsedTime(&c->ms.schedule, c->ev[5], c->ev[2]);
         (void)hipEventElapsedTime(&c->ms.align, c->ev[2], c->ev[3]);
         (void)hipEventElapsedTime(&c->ms.sort, c->ev[3], c->ev[4]);
         (void)hipEventElapsedTime(&c->ms.total, c->ev[0], c->ev[4]);

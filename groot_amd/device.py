@@ -33,7 +33,7 @@ class Counts(C.Structure):
 
 
 class StageMs(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total")]
+    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule")]
 
 
 _lib = None

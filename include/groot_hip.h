@@ -65,9 +65,11 @@ typedef struct groot_counts {
     uint64_t short_reads;    /* reads shorter than k (reference panics, boss.go:164-166)             */
 } groot_counts;
 
-/* per-stage device time of the last batch, HIP events on the ctx stream (ms); 0 if profiling off */
+/* per-stage device time of the last batch, HIP events on the ctx stream (ms); 0 if profiling off.
+ * sketch_seed = the sketch+seed kernel alone; schedule = radix sort of the processing order + record gather;
+ * align = the align kernel; sort = ordering of the traversal records into (read, ord) order */
 typedef struct groot_stage_ms {
-    float h2d, sketch_seed, align, sort, total;
+    float h2d, sketch_seed, align, sort, total, schedule;
 } groot_stage_ms;
 
 int groot_hip_device_count(int *n);
