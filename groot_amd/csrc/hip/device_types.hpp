@@ -28,7 +28,8 @@ struct DeviceCounters {
     unsigned int max_seeds;     // largest per-read seed count seen
     unsigned int flags;
     unsigned int pad;
-    unsigned long long dbg[64]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it
+    unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
+                                 // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };
 
 // Everything a DFS step needs about one graph node in one aligned record (64 B for PW<=3, 128 B for PW=11):

@@ -407,6 +407,9 @@ static int alloc_ovf(groot_ctx *c, uint32_t cap_per_shard)
     return GROOT_OK;
 }
 
+#ifndef GROOT_SPAN_BITS
+#define GROOT_SPAN_BITS 6
+#endif
 static int launch_seed_stage(groot_ctx *c)
 {
     SeedArgs a{};
@@ -429,7 +432,7 @@ static int launch_seed_stage(groot_ctx *c)
     unsigned win_bits = 3;                                  // 2 class bits + one bit above the largest window id
     for (uint32_t v = c->n_windows; v; v >>= 1) win_bits++;
     win_bits = std::min(32u, win_bits);
-    a.sort_span_bits = std::min(6u, 32u - win_bits);
+    a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((c->n_reads + kBlock - 1) / kBlock);
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
@@ -875,6 +878,11 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
 #ifdef GROOT_WORK_COUNTERS
     for (int e = 0; e < 32; e++)
         if (c->hctr.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, c->hctr.dbg[e], c->hctr.dbg[32 + e]);
+    for (int h = 0; h < 2; h++) {
+        fprintf(stderr, "[groot work] %s (buckets of 2 iterations):", h ? "round length" : "lane finish");
+        for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", c->hctr.dbg[64 + 64 * h + b]);
+        fprintf(stderr, "\n");
+    }
 #endif
     if (c->profiling) {
         (void)hipEventElapsedTime(&c->ms.h2d, c->ev[0], c->ev[1]);

@@ -363,9 +363,10 @@ __global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
             }
             key = (min_win << 2) | dead;
             if (a.sort_span_bits) {
-                // windows spanning a similar number of nodes need similar numbers of DFS steps
+                // windows spanning a similar number of nodes need similar numbers of DFS steps: keep them together, and
                 const uint32_t nn = min(wr.cn_end - wr.cn_off, (1u << a.sort_span_bits) - 1u);
-                key |= nn << (32u - a.sort_span_bits);
+                // longest walks first: the slow chunks are handed out early and the short ones fill the tail of the launch
+                key |= (((1u << a.sort_span_bits) - 1u) - nn) << (32u - a.sort_span_bits);
             }
         }
         a.sort_key[r] = key;
@@ -438,6 +439,10 @@ enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
 #define GROOT_REFILL 64
 #endif
 constexpr int kRefill = GROOT_REFILL;          // waiting lanes that trigger a refill
+#ifndef GROOT_REFILL_A
+#define GROOT_REFILL_A 0x7FFFFFFF          // ... for the first A iterations after a refill, then B lanes are enough
+#define GROOT_REFILL_B 64
+#endif
 #ifndef GROOT_WAVE_CHUNK
 #define GROOT_WAVE_CHUNK 128
 #endif
@@ -495,6 +500,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
 #ifdef GROOT_WORK_COUNTERS
     uint32_t ev = 0;                                       // events of this lane in the current wave iteration
+    uint32_t wc_iter = 0, wc_round0 = 0;                   // wave iterations so far / at the last refill
 #define GROOT_EV(i) (ev |= 1u << (i))
 #else
 #define GROOT_EV(i) ((void)0)
@@ -511,6 +517,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
     };
     uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor
+    uint32_t round_it = 0;                                 // wave iterations since the last refill
     uint32_t slot = 0, r = 0;
     // ---- read ----
     bool have_read = false;
@@ -620,6 +627,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             }
         }
         ev = 0;
+        wc_iter++;
 #endif
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
@@ -629,7 +637,15 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             // orientation class), so lanes that start together do near-identical work and share phases.
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
-            if (cw >= kRefill || (cw && !(bf | bs | bd))) {
+            // a round that drags on is down to its stragglers: stop holding the finished lanes back for them
+            round_it++;
+            const int need = round_it <= GROOT_REFILL_A ? kRefill : GROOT_REFILL_B;
+            if (cw >= need || (cw && !(bf | bs | bd))) {
+                round_it = 0;
+#ifdef GROOT_WORK_COUNTERS
+                if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
+                wc_round0 = wc_iter;
+#endif
                 const uint64_t base = (uint64_t)chunk_j * kWaveChunk;
                 if (base >= a.n_reads) {                       // this wave's share is used up
                     if (phase == PH_WAIT) phase = PH_DONE;
@@ -712,6 +728,9 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 }
             if (nw == kEmpty) {                               // every seed of the read handled
                 GROOT_EV(4);
+#ifdef GROOT_WORK_COUNTERS
+                atomicAdd(&a.ctr->dbg[64 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // when in its round the lane finished
+#endif
                 a.trav_cnt[r] = ord;
                 mapped++;                                     // boss.go:195-200
                 if (n_graphs > 1) multimapped++;
