@@ -796,7 +796,12 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             phase = PH_DFS;
             GROOT_EV(10);
         } else {
-            // ---- DFS: match up to 16 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
+            // ---- DFS: match up to 32 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
+            // The lanes stay in here for as long as the scheduling rule above would pick the phase again (lanes only leave
+            // it for FETCH or SCAN, both counted below), which saves the ballots and the refill logic per step.
+            int nd, nf, ns;
+            do {
+            if (phase == PH_DFS) {
             RecRegs<PW> rec;
             rec.load(recs + cur);
             if (coff != 0 && !(cur == node0 && coff == noff0 && dist == 0)) GROOT_EV(18);
@@ -920,6 +925,11 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                     else a.stk_hdr[si] = (uint64_t)pn | ((uint64_t)more << 32) | ((uint64_t)dist << 48);
                 }
             }
+            }
+            nd = __popcll(__ballot(phase == PH_DFS));
+            nf = cf + __popcll(__ballot(phase == PH_FETCH));
+            ns = cs + __popcll(__ballot(phase == PH_SCAN));
+            } while (nd > 0 && nd >= ns && nd >= nf);
         }
     }
 
