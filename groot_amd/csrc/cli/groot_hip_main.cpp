@@ -57,7 +57,9 @@ void logf(const char *fmt, ...)
 }
 
 struct Args {
-    std::string cmd, index_dir, msa_dir, log_file = "groot.log", graph_dir, bam_out;
+    std::string cmd, index_dir, msa_dir, log_file = "groot.log", graph_dir, bam_out, bam_file;
+    double cov_cutoff = 0.97;
+    bool low_cov = false;
     std::vector<std::string> fastq;
     int proc = 1, gpu = 0;
     bool gpu_given = false;
@@ -86,7 +88,8 @@ void usage()
             "  groot-hip index -m <msaDir> -i <indexDir> [-k 31] [-s 21] [-w 100] [-x 8] [-y 4] [--maxSketchSpan 30] [-p N] [--log F]\n"
             "                  [--gpu 0]      (sketch the graph windows on that GPU instead of the host)\n"
             "  groot-hip align -i <indexDir> -f <fastq>[,<fastq>...] [-t 0.99] [-c 1.0] [-g <graphDir>] [--noAlign] [-p N] [--log F]\n"
-            "                  [--gpu 0] [--batch 1048576] [--bam out.bam]      (BAM goes to stdout unless --bam)\n",
+            "                  [--gpu 0] [--batch 1048576] [--bam out.bam]      (BAM goes to stdout unless --bam)\n"
+            "  groot-hip report [--bamFile x.bam] [-c 0.97] [--lowCov] [--log F]      (BAM from stdin unless --bamFile)\n",
             groot_host_version());
 }
 
@@ -118,6 +121,9 @@ Args parse(int argc, char **argv)
         else if (f == "--maxSketchSpan") a.max_span = (uint32_t)atoi(v().c_str());
         else if (f == "-f" || f == "--fastq") { for (auto &x : split(v(), ',')) a.fastq.push_back(x); }
         else if (f == "-t" || f == "--contThresh") a.threshold = atof(v().c_str());
+        else if (a.cmd == "report" && (f == "-c" || f == "--covCutoff")) a.cov_cutoff = atof(v().c_str());
+        else if (f == "--bamFile") a.bam_file = v();
+        else if (f == "--lowCov") a.low_cov = true;
         else if (f == "-c" || f == "--minKmerCov") a.min_kmer_cov = atof(v().c_str());
         else if (f == "-g" || f == "--graphDir") a.graph_dir = v();
         else if (f == "--noAlign") a.no_align = true;
@@ -447,6 +453,30 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     return rc;
 }
 
+// cmd/report.go:104-129
+int run_report(const Args &a)
+{
+    start_logging(a);
+    logf("i am groot (version %s)", groot_host_version());
+    logf("starting the report subcommand");
+    logf("checking parameters...");
+    if (a.bam_file.empty()) logf("\tBAM file: using STDIN");
+    else {
+        if (!is_file(a.bam_file)) die("BAM file does not exist: %s", a.bam_file.c_str());
+        const size_t dot = a.bam_file.rfind('.');
+        if (dot == std::string::npos || a.bam_file.substr(dot + 1) != "bam") die("the BAM file does not have a `.bam` extension: %s", a.bam_file.c_str());
+        logf("\tBAM file: %s", a.bam_file.c_str());
+    }
+    if (a.cov_cutoff > 1.0) die("supplied coverage cutoff exceeds 1.0 (100%%): %g", a.cov_cutoff);
+    logf("\tcoverage cutoff: %.2f", a.cov_cutoff);
+    logf("\tprocessors: %d", a.proc);
+    uint64_t n = 0;
+    if (groot_host_report(a.bam_file.empty() ? nullptr : a.bam_file.c_str(), a.cov_cutoff, a.low_cov ? 1 : 0, nullptr, &n))
+        die("%s", groot_host_last_error());
+    logf("finished");
+    return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -454,6 +484,7 @@ int main(int argc, char **argv)
     Args a = parse(argc, argv);
     if (a.cmd == "index") return run_index(a);
     if (a.cmd == "align") return run_align(a);
+    if (a.cmd == "report") return run_report(a);
     if (a.cmd == "version") { printf("%s\n", groot_host_version()); return 0; }
     usage();
     return 1;

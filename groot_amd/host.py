@@ -258,6 +258,26 @@ class BamWriter:
                 pass
 
 
+def report(bam_path, cov_cutoff=0.97, low_cov=False, out_path=None):
+    """`groot report` (src/reporting/reporting.go): list of (name, read count, length, coverage cigar)"""
+    import tempfile
+
+    tmp = None
+    if out_path is None:
+        fd, tmp = tempfile.mkstemp(suffix=".report")
+        os.close(fd)
+    n = C.c_uint64(0)
+    try:
+        _check(lib().groot_host_report(bam_path.encode(), C.c_double(cov_cutoff), C.c_int(1 if low_cov else 0), (out_path or tmp).encode(),
+                                       C.byref(n)))
+        rows = [ln.rstrip("\n").split("\t") for ln in open(out_path or tmp)]
+    finally:
+        if tmp:
+            os.unlink(tmp)
+    assert len(rows) == n.value
+    return [(r[0], int(r[1]), int(r[2]), r[3]) for r in rows]
+
+
 def save_gfa(index, graph, kmer_freq, path_kept, node_removed, total_kmers, file_name, timestamp=None):
     """GrootGraph.SaveGraphAsGFA (src/graph/graphio.go:19-112); returns True if a file was written"""
     kf = np.ascontiguousarray(kmer_freq, dtype=np.float64)

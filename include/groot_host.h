@@ -185,6 +185,13 @@ int groot_bam_write_travs(groot_bam *bam, const groot_index_view *idx, const gro
                           const uint64_t *masks, uint64_t n_trav, uint64_t *n_records);
 int groot_bam_close(groot_bam *bam);
 
+/* ---- after the hot path: the reference's own consumer of the BAM ---------------------------------- */
+/* `groot report` (src/reporting/reporting.go:33-173, cmd/report.go:104-129): breadth of coverage per reference from the
+ * BAM of `groot align` (bam_path NULL = stdin).  One line "name\tread count\tlength\tcoverage cigar" per reference whose
+ * covered fraction is >= cov_cutoff, written to out_path (NULL = stdout) in BAM header order; low_cov != 0 uses the
+ * cutoff 0.97 and drops references with internal uncovered stretches (cmd/report.go:119-122, reporting.go:151-153). */
+int groot_host_report(const char *bam_path, double cov_cutoff, int low_cov, const char *out_path, uint64_t *n_reported);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,11 @@ def test_travis_e2e_flow(cli, msa_dir, tmp_path):
     b7 = {x["name"] for x in recs if x["ref"] == "argannot~~~(Bla)B-7~~~AF189304:1-747"}
     assert b7 == {n.decode() for n, _, _ in reads}
     assert all(x["cigar"] == "150M" for x in recs)
+    # run_travis_tests.sh:36-56: `groot report -c 0.97` must list exactly one gene, (Bla)B-7
+    r = run([cli, "report", "--bamFile", bam, "-c", "0.97", "--log", str(tmp_path / "r.log")])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == 1 and lines[0].split("\t")[0] == "argannot~~~(Bla)B-7~~~AF189304:1-747"
     # the same index as a directory of the reference's own files (groot.gg + groot.lshe, cmd/align.go:93-107)
     import gobenc
 
