@@ -196,6 +196,47 @@ def test_edge_cases(small_index):
     al.close()
 
 
+@pytest.mark.parametrize("threshold", [0.99, 0.9])
+def test_mutated_reads_stress(small_index, threshold):
+    """substrings of every length 40..160 in both orientations with a wrong first / last / inner base, an N, or both
+    ends wrong: every level of the AlignRead hierarchy (and the seed stage's verdict bits that skip levels) is hit"""
+    cat, o, lens = synth.reference_sequences(small_index)
+    rng = np.random.default_rng(20240 + int(threshold * 100))
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    reads = []
+    for i in range(12000):
+        s = int(rng.integers(0, len(lens)))
+        L = int(rng.integers(40, 161))
+        if lens[s] < L:
+            L = int(lens[s])
+        st = int(rng.integers(0, lens[s] - L + 1))
+        r = bytearray(cat[int(o[s]) + st:int(o[s]) + st + L].tobytes())
+        kind = i % 8
+        flip = lambda b: b"ACGT"[(b"ACGT".index(bytes([b])) + 1 + int(rng.integers(0, 3))) % 4] if bytes([b]) in b"ACGT" else ord("A")
+        if kind == 1:
+            r[0] = flip(r[0])
+        elif kind == 2:
+            r[-1] = flip(r[-1])
+        elif kind == 3:
+            r[0] = flip(r[0]); r[-1] = flip(r[-1])
+        elif kind == 4:
+            j = int(rng.integers(1, L - 1)); r[j] = flip(r[j])
+        elif kind == 5:
+            r[int(rng.integers(0, L))] = ord("N")
+        elif kind == 6:
+            r[0] = ord("N")
+        r = bytes(r)
+        if rng.integers(0, 2):
+            r = r.translate(comp)[::-1]
+        reads.append(r)
+    seq, off = O.pack_reads(reads)
+    al, counts, run = run_both(small_index, seq, off, threshold=threshold)
+    got = assert_same(al, counts, run, small_index)
+    clips = (int(got["start_clip"].sum()), int(got["end_clip"].sum()))
+    assert clips[0] > 0 and clips[1] > 0, clips                  # both hard-clip levels produced records
+    al.close()
+
+
 def test_error_behaviour_matches_reference_panics(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)
