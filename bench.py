@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-align", action="store_true", help="diagnostic: --noAlign mode (weights only, no BAM records)")
+    ap.add_argument("--background", type=float, default=0.0,
+                    help="diagnostic: fraction of reads replaced by uniform random ACGT (metagenome-like input, SURVEY 8d)")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +119,15 @@ def main():
     d_seq = torch.zeros(R * READ_LEN + 64, dtype=torch.uint8, device=dev)
     d_seq[: R * READ_LEN] = torch.cat(chunks)
     del chunks
+    if args.background > 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x67726F6F74 + rank)
+        rows = d_seq[: R * READ_LEN].view(R, READ_LEN)
+        for c0 in range(0, R, CH):
+            n = min(CH, R - c0)
+            bg = torch.rand(n, generator=g, device=dev) < args.background
+            rnd = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n, READ_LEN), generator=g, device=dev)]
+            rows[c0:c0 + n] = torch.where(bg[:, None], rnd, rows[c0:c0 + n])
     d_off = torch.arange(0, R + 1, dtype=torch.int64, device=dev) * READ_LEN
     torch.cuda.synchronize()
 
@@ -185,7 +196,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: full pipeline incl. on-GPU graph-traversal alignment, 100 bp error-free reads sampled from arg-annot.90, index k=31 s=21 w=100 x=8 y=4, t=0.99",
-                       "reads_per_gpu_per_step": R, "read_len": READ_LEN, "parallelism": f"reads sharded x{world}, index replicated",
+                       "reads_per_gpu_per_step": R, "read_len": READ_LEN, **({"background_fraction": args.background} if args.background > 0 else {}), "parallelism": f"reads sharded x{world}, index replicated",
                        "per_step_counts": counts,
                        "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -134,7 +134,7 @@ struct AlignArgs {
     uint32_t *trav_cnt;          // [n_reads] traversals emitted for read r
     groot_trav *ovf_trav;        // [kOvfShards][ovf_cap]
     uint64_t *ovf_mask;          // [kOvfShards*ovf_cap*pw]
-    uint32_t *ovf_cnt;           // [kOvfShards] list lengths, then [kOvfShards] = next chunk of sorted slots to hand out
+    uint32_t *ovf_cnt;           // [kOvfShards] list lengths, then [kOvfShards], [kOvfShards+1] = cursors over the sorted slots (align_kernel)
     uint32_t ovf_cap;
     // DFS stacks: entry d of thread t lives at [d*n_threads + t]
     uint64_t *stk_hdr;

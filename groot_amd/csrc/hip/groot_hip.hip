@@ -488,7 +488,7 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
     a.ctr = c->ctr.p;
-    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 1) * sizeof(uint32_t), c->stream));   // + the chunk cursor
+    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
     launch_align(c->pw, a, dim3(blocks), c->stream);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
@@ -717,7 +717,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->mask_first.alloc((size_t)R * c->pw));
     HIP_TRY(c, c->trav_cnt.alloc(R));
     HIP_TRY(c, c->trav_off.alloc(R));
-    HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 1));
+    HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
     if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 4))) return rc;
     if (int rc = alloc_ovf(c, std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     #ifndef GROOT_ALIGN_BLOCKS_PER_CU
@@ -878,6 +878,7 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
 #ifdef GROOT_WORK_COUNTERS
     for (int e = 0; e < 32; e++)
         if (c->hctr.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, c->hctr.dbg[e], c->hctr.dbg[32 + e]);
+    fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", c->hctr.dbg[63]);
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "[groot work] %s (buckets of 2 iterations):", h ? "round length" : "lane finish");
         for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", c->hctr.dbg[64 + 64 * h + b]);

@@ -446,7 +446,10 @@ constexpr int kRefill = GROOT_REFILL;          // waiting lanes that trigger a r
 #ifndef GROOT_WAVE_CHUNK
 #define GROOT_WAVE_CHUNK 128
 #endif
-constexpr uint32_t kWaveChunk = GROOT_WAVE_CHUNK;   // consecutive slots a wave takes before asking for more
+constexpr uint32_t kWaveChunk = GROOT_WAVE_CHUNK;   // consecutive slots a wave takes before asking for more (multiple of 64)
+#ifndef GROOT_SMALL_CHUNK_SHARE
+#define GROOT_SMALL_CHUNK_SHARE(n) ((n) >> 3)
+#endif
 
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
 __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
@@ -511,12 +514,31 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     // waves of the grid, consecutive slots to the lanes that ask together
     // (a wavefront that runs out takes the next chunk from a global cursor: no static shares, so no wave idles while
     // another still holds several chunks)
+    // Rounds of 64 slots are handed out through two cursors.  The first eighth of the order holds the longest walks (one
+    // round of them can take a quarter of the launch): cursor 0 hands those out one round at a time; once it has run past
+    // them, cursor 1 hands out the rest kWaveChunk slots at a time.  (Only atomics touch the cursors: an atomic LOAD at
+    // agent scope in this loop halves the kernel's speed.)
+    const uint32_t n_rounds = (a.n_reads + 63u) >> 6;
+    const uint32_t head_rounds = GROOT_SMALL_CHUNK_SHARE(n_rounds);
+    uint32_t chunk_len = 0;                                // slots in the current chunk (wave-uniform)
+    bool head_done = head_rounds == 0;                     // wave-uniform
     auto take_chunk = [&]() -> uint32_t {
         uint32_t c = 0;
-        if ((threadIdx.x & 63) == 0) c = atomicAdd(a.ovf_cnt + kOvfShards, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t u = 1;
+            if (!head_done) c = atomicAdd(a.ovf_cnt + kOvfShards, 1u);
+            if (head_done || c >= head_rounds) {
+                u = kWaveChunk / 64u;
+                c = head_rounds + atomicAdd(a.ovf_cnt + kOvfShards + 1, u);
+            }
+            c |= u << 28;
+        }
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        chunk_len = (c >> 28) * 64u;
+        if (chunk_len > 64u) head_done = true;
+        return c & 0x0FFFFFFFu;
     };
-    uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor
+    uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor: first round of the chunk, slots used
     uint32_t round_it = 0;                                 // wave iterations since the last refill
     uint32_t slot = 0, r = 0;
     // ---- read ----
@@ -644,13 +666,14 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 round_it = 0;
 #ifdef GROOT_WORK_COUNTERS
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
+                if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
                 wc_round0 = wc_iter;
 #endif
-                const uint64_t base = (uint64_t)chunk_j * kWaveChunk;
+                const uint64_t base = (uint64_t)chunk_j * 64u;
                 if (base >= a.n_reads) {                       // this wave's share is used up
                     if (phase == PH_WAIT) phase = PH_DONE;
                 } else {
-                    const uint32_t room = kWaveChunk - chunk_pos;
+                    const uint32_t room = chunk_len - chunk_pos;
                     if (phase == PH_WAIT) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
                         const uint64_t sl = base + chunk_pos + rank;
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                         }
                     }
                     chunk_pos += min((uint32_t)cw, room);
-                    if (chunk_pos >= kWaveChunk) { chunk_pos = 0; chunk_j = take_chunk(); }
+                    if (chunk_pos >= chunk_len) { chunk_pos = 0; chunk_j = take_chunk(); }
                 }
                 continue;
             }
@@ -926,6 +949,9 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 }
             }
             }
+#ifdef GROOT_WORK_COUNTERS
+            wc_iter++;                                         // (events of the steps inside this loop are merged)
+#endif
             nd = __popcll(__ballot(phase == PH_DFS));
             nf = cf + __popcll(__ballot(phase == PH_FETCH));
             ns = cs + __popcll(__ballot(phase == PH_SCAN));
