@@ -427,22 +427,20 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
 //   graphMinion loop (graphminion.go:46-102) -> AlignRead hierarchy (alignment.go:13-159)
 //   -> performAlignment / dfsRecursive / processTraversal (alignment.go:162-317)
 // Each lane is in one of three phases and advances by ONE step when its phase is executed:
-//   FETCH  take the next read (grid stride) / pick the read's next seed window, count IncrementSubPath
-//   SCAN   test up to 12 candidate start offsets of one node against the read prefix (SWAR, 4-base
+//   FETCH  take the next read (its record, in processing order; bases staged in the lane's LDS slice) / pick the
+//          read's next seed window, count IncrementSubPath, apply the seed stage's verdicts on hierarchy levels
+//   SCAN   test up to 16 candidate start offsets of one node against the read prefix (SWAR, 4-base
 //          filter then exact 8-base check of the lowest survivor); walks the hierarchy levels 1..4
-//   DFS    match up to 16 bases of one graph node, choose the next neighbour, emit / backtrack
+//   DFS    match up to 32 bases of one graph node, choose the next neighbour, emit / backtrack
 // Per iteration the wave executes only the phase holding the most lanes (ballot + popcount in SALU), so
 // lanes in different reads / levels / depths never serialise each other's loops and every executed
-// instruction runs at the best available lane fill; a lane that finishes a read fetches the next one.
+// instruction runs at the best available lane fill.  A wavefront takes 64 consecutive reads of the processing order
+// at a time (they share a seed window, hence the graph nodes they walk) and asks for more when all lanes are done.
 enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
 #ifndef GROOT_REFILL
 #define GROOT_REFILL 64
 #endif
 constexpr int kRefill = GROOT_REFILL;          // waiting lanes that trigger a refill
-#ifndef GROOT_REFILL_A
-#define GROOT_REFILL_A 0x7FFFFFFF          // ... for the first A iterations after a refill, then B lanes are enough
-#define GROOT_REFILL_B 64
-#endif
 #ifndef GROOT_WAVE_CHUNK
 #define GROOT_WAVE_CHUNK 128
 #endif
@@ -539,7 +537,6 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
         return c & 0x0FFFFFFFu;
     };
     uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor: first round of the chunk, slots used
-    uint32_t round_it = 0;                                 // wave iterations since the last refill
     uint32_t slot = 0, r = 0;
     // ---- read ----
     bool have_read = false;
@@ -659,11 +656,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             // orientation class), so lanes that start together do near-identical work and share phases.
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
-            // a round that drags on is down to its stragglers: stop holding the finished lanes back for them
-            round_it++;
-            const int need = round_it <= GROOT_REFILL_A ? kRefill : GROOT_REFILL_B;
-            if (cw >= need || (cw && !(bf | bs | bd))) {
-                round_it = 0;
+            if (cw >= kRefill || (cw && !(bf | bs | bd))) {
 #ifdef GROOT_WORK_COUNTERS
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
                 if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
