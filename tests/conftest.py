@@ -85,6 +85,19 @@ def testgfa_index():
 
 
 @pytest.fixture(scope="session")
+def resfinder_index(tmp_path_factory):
+    """resfinder.90 (669 MSAs) with the `groot index` defaults: the database of BASELINE.json's mixed-length configuration
+    (card.90 itself is not in the reference tree)"""
+    from groot_amd import host
+
+    d = tmp_path_factory.mktemp("resfinder")
+    with tarfile.open(os.path.join(DATA, "resfinder.90.tar.gz")) as tf:
+        members = [m for m in tf.getmembers() if os.path.basename(m.name).startswith("cluster") and m.name.endswith(".msa")]
+        tf.extractall(d, members=members)
+    return host.Index.from_msa_dir(os.path.join(d, "resfinder.90"))
+
+
+@pytest.fixture(scope="session")
 def genes_index():
     """src/pipeline/test-data/test-genes.msa with the parameters of 1_pipeline_test.go:32-40"""
     from groot_amd import host

@@ -237,6 +237,28 @@ def test_mutated_reads_stress(small_index, threshold):
     al.close()
 
 
+@pytest.mark.parametrize("threshold", [0.99, 0.97, 0.95, 0.90])
+def test_mixed_length_threshold_sweep_on_resfinder(resfinder_index, threshold):
+    """BASELINE.json configs[4] in miniature: 75-150 bp mixed-length reads of both strands on the larger database,
+    containment-threshold sweep (general LSH-Forest path with per-length K/L/min-equal tables)"""
+    index = resfinder_index
+    cat, o, lens = synth.reference_sequences(index)
+    rng = np.random.default_rng(9000 + int(threshold * 100))
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    reads = []
+    for _ in range(15000):
+        s = int(rng.integers(0, len(lens)))
+        L = min(int(rng.integers(75, 151)), int(lens[s]))
+        st = int(rng.integers(0, lens[s] - L + 1))
+        r = cat[int(o[s]) + st:int(o[s]) + st + L].tobytes()
+        reads.append(r.translate(comp)[::-1] if rng.integers(0, 2) else r)
+    seq, off = O.pack_reads(reads)
+    al, counts, run = run_both(index, seq, off, threshold=threshold)
+    assert_same(al, counts, run, index)
+    assert counts["mapped"] > 1000                              # reads shorter than the window rarely reach t=0.99
+    al.close()
+
+
 def test_error_behaviour_matches_reference_panics(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)
