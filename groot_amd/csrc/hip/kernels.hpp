@@ -143,12 +143,17 @@ constexpr uint32_t kLdsReads = 4096 + 192;       // staged read bytes (16-byte a
 // ---------------------------------------------------------------------------------------------
 // K1+K2
 // ---------------------------------------------------------------------------------------------
+// (5 workgroups per CU: the register allocator then settles on 81 VGPRs instead of 105 without spilling more, and the
+// fifth wave per SIMD lifts VALU issue from 87 % to 90 %; a sixth does not fit the LDS)
+#ifndef GROOT_SEED_WAVES
+#define GROOT_SEED_WAVES 5
+#endif
 // M5 >= 0: compile-time value of (k * multiSeed) & 31.  The MultiHash multipliers c_i = i ^ (k*multiSeed) of
 // slots i < 32 then equal C0 + (i ^ M5) with C0 = (k*multiSeed) & ~31, so h*c_i for all slots comes from ONE
 // 64-bit multiply (h*C0) and a running sum (+h per step) instead of a quarter-rate 64-bit multiply per slot.
 // M5 < 0: generic path (any k, any S).
 template <int S, int MAXK, bool DUMP, int M5>
-__global__ __launch_bounds__(kBlock) void sketch_seed_kernel(SeedArgs a)
+__global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(SeedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *tabF = reinterpret_cast<uint64_t *>(smem + kLdsTabF);
