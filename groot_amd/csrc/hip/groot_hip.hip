@@ -61,7 +61,9 @@ struct groot_ctx {
     DeviceIndex dix{};
 
     // batch state
-    DevBuf<uint8_t> seq;
+    DevBuf<uint8_t> seq, exc_byte;
+    DevBuf<uint32_t> packed;
+    DevBuf<uint64_t> exc_pos;
     DevBuf<uint64_t> seq_off;
     const uint8_t *cur_seq = nullptr;
     const uint64_t *cur_off = nullptr;
@@ -794,6 +796,44 @@ int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    c->cur_seq = c->seq.p; c->cur_off = c->seq_off.p;
+    return run_batch_async(c);
+}
+
+int groot_hip_submit_packed(groot_ctx *c, const uint8_t *packed, const uint64_t *seq_off, uint32_t n_reads, uint32_t first_read_id,
+                            const uint64_t *exc_pos, const uint8_t *exc_byte, uint64_t n_exc)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (n_reads && (!packed || !seq_off)) return fail(c, GROOT_E_INVALID, "null read buffers");
+    if (n_exc && (!exc_pos || !exc_byte)) return fail(c, GROOT_E_INVALID, "null exception list");
+    if (int rc = begin_batch(c, n_reads, first_read_id)) return rc;
+    if (!n_reads) return GROOT_OK;
+    const uint64_t total = seq_off[n_reads];
+    if (seq_off[0] != 0) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0"); }
+    if (total > c->prm.max_batch_bases) { c->submitted = false; return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)total, (unsigned long long)c->prm.max_batch_bases); }
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        if (seq_off[i + 1] < seq_off[i]) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off not monotone at read %u", i); }
+        max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(seq_off[i + 1] - seq_off[i], 0xFFFFFFFFu));
+    }
+    for (uint64_t i = 0; i < n_exc; i++)
+        if (exc_pos[i] >= total) { c->submitted = false; return fail(c, GROOT_E_INVALID, "exception %llu lies outside the batch", (unsigned long long)i); }
+    c->batch_max_len = std::min(max_len, c->prm.max_read_len);
+    const uint64_t n_words = (total + 15) / 16;                  // 16 bases per packed word
+    if (c->packed.n < n_words) HIP_TRY(c, c->packed.alloc((c->prm.max_batch_bases + 15) / 16 + 1));
+    if (c->exc_pos.n < n_exc) { HIP_TRY(c, c->exc_pos.alloc(n_exc + n_exc / 4 + 1024)); HIP_TRY(c, c->exc_byte.alloc(n_exc + n_exc / 4 + 1024)); }
+    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->packed.p, packed, (size_t)((total + 3) / 4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(unpack_reads_kernel, dim3((unsigned)((n_words + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->packed.p, n_words,
+                       reinterpret_cast<uint4 *>(c->seq.p));
+    if (n_exc) {
+        HIP_TRY(c, hipMemcpyAsync(c->exc_pos.p, exc_pos, n_exc * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->exc_byte.p, exc_byte, n_exc, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(patch_reads_kernel, dim3((unsigned)((n_exc + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->exc_pos.p,
+                           c->exc_byte.p, n_exc, c->seq.p);
+    }
+    HIP_TRY(c, hipGetLastError());
     c->cur_seq = c->seq.p; c->cur_off = c->seq_off.p;
     return run_batch_async(c);
 }

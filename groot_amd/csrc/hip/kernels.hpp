@@ -388,6 +388,33 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
     }
 }
 
+// groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
+// thread (one 4-byte load, one 16-byte store); bytes other than ACGT are patched in from the exception list afterwards
+__global__ __launch_bounds__(kBlock) void unpack_reads_kernel(const uint32_t *__restrict__ packed, uint64_t n_words, uint4 *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_words) return;
+    const uint32_t w = packed[i];
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t code = (w >> (8 * q + 2 * b)) & 3u;
+            v |= ((0x47544341u >> (8 * code)) & 0xFFu) << (8 * b);   // "ACTG"[code]
+        }
+        o[q] = v;
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__global__ __launch_bounds__(kBlock) void patch_reads_kernel(const uint64_t *__restrict__ pos, const uint8_t *__restrict__ byte, uint64_t n,
+                                                             uint8_t *__restrict__ seq)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) seq[pos[i]] = byte[i];
+}
+
 // read records in processing order: the align stage then fetches slot-consecutive (coalesced) records instead of
 // chasing perm[slot] -> read_rec[read]
 __global__ __launch_bounds__(kBlock) void gather_recs_kernel(const uint32_t *__restrict__ perm, const ReadRec *__restrict__ in,

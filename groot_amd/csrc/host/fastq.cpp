@@ -5,7 +5,10 @@
 // Lines from consecutive files form ONE stream (the reference's four-line grouping carries across files).
 #include "host_common.hpp"
 
+#include <algorithm>
 #include <cstring>
+#include <thread>
+#include <utility>
 #include <zlib.h>
 
 using namespace groot;
@@ -141,3 +144,39 @@ void groot_fastq_close(groot_fastq *fq)
 }
 
 } // extern "C"
+
+// ---- 2-bit packing for groot_hip_submit_packed ------------------------------------------------------------
+extern "C" int groot_host_pack_reads(const uint8_t *seq, uint64_t n_bases, uint8_t *packed, uint64_t *exc_pos, uint8_t *exc_byte,
+                                     uint64_t exc_cap, uint64_t *n_exc, uint32_t n_threads)
+{
+    if ((n_bases && (!seq || !packed)) || !n_exc) return groot::set_error(GROOT_E_INVALID, "null argument");
+    unsigned nt = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t n_quads = (n_bases + 3) / 4;
+    nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, n_quads / 65536 + 1));
+    std::vector<std::vector<std::pair<uint64_t, uint8_t>>> exc(nt);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t]() {
+            const uint64_t q0 = n_quads * t / nt, q1 = n_quads * (t + 1) / nt;   // whole output bytes per thread
+            for (uint64_t q = q0; q < q1; q++) {
+                unsigned v = 0;
+                for (unsigned b = 0; b < 4; b++) {
+                    const uint64_t i = q * 4 + b;
+                    if (i >= n_bases) break;
+                    const uint8_t c = seq[i];
+                    v |= ((c >> 1) & 3u) << (2 * b);
+                    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') exc[t].emplace_back(i, c);
+                }
+                packed[q] = (uint8_t)v;
+            }
+        });
+    for (auto &x : th) x.join();
+    uint64_t total = 0;
+    for (auto &e : exc) total += e.size();
+    *n_exc = total;
+    if (total > exc_cap) return groot::set_error(GROOT_E_NOSPACE, "%llu bytes are not ACGT, room for %llu", (unsigned long long)total, (unsigned long long)exc_cap);
+    uint64_t o = 0;
+    for (auto &e : exc)
+        for (auto &pr : e) { exc_pos[o] = pr.first; exc_byte[o] = pr.second; o++; }
+    return GROOT_OK;
+}

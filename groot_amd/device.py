@@ -117,6 +117,17 @@ class Aligner:
         self._check(lib().groot_hip_submit(self._h, _ffi.as_ptr(seq, C.c_uint8), _ffi.as_ptr(off, C.c_uint64),
                                            C.c_uint32(len(off) - 1), C.c_uint32(first_read_id)))
 
+    def submit_packed(self, packed, seq_off, exc_pos, exc_byte, first_read_id=0):
+        """groot_hip_submit_packed: the arguments host.pack_reads() builds from seq_concat"""
+        pk = np.ascontiguousarray(packed, dtype=np.uint8)
+        off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        ep = np.ascontiguousarray(exc_pos, dtype=np.uint64)
+        eb = np.ascontiguousarray(exc_byte, dtype=np.uint8)
+        self._keep = (pk, off, ep, eb)
+        self._check(lib().groot_hip_submit_packed(self._h, _ffi.as_ptr(pk, C.c_uint8), _ffi.as_ptr(off, C.c_uint64), C.c_uint32(len(off) - 1),
+                                                  C.c_uint32(first_read_id), _ffi.as_ptr(ep, C.c_uint64), _ffi.as_ptr(eb, C.c_uint8),
+                                                  C.c_uint64(len(ep))))
+
     def submit_device(self, d_seq_ptr, d_off_ptr, n_reads, first_read_id=0, max_len=0):
         self._check(lib().groot_hip_submit_device(self._h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), C.c_uint32(n_reads),
                                                   C.c_uint32(first_read_id), C.c_uint32(max_len)))

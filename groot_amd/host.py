@@ -258,6 +258,24 @@ class BamWriter:
                 pass
 
 
+def pack_reads(seq_concat, threads=0):
+    """2 bits per base + the list of bytes that are not ACGT (groot_host_pack_reads) -> (packed, exc_pos, exc_byte)"""
+    seq = np.ascontiguousarray(seq_concat, dtype=np.uint8)
+    packed = np.empty((len(seq) + 3) // 4, dtype=np.uint8)
+    cap = 1024
+    while True:
+        pos, byte = np.empty(cap, dtype=np.uint64), np.empty(cap, dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = lib().groot_host_pack_reads(_ffi.as_ptr(seq, C.c_uint8), C.c_uint64(len(seq)), _ffi.as_ptr(packed, C.c_uint8),
+                                         _ffi.as_ptr(pos, C.c_uint64), _ffi.as_ptr(byte, C.c_uint8), C.c_uint64(cap), C.byref(n),
+                                         C.c_uint32(threads))
+        if rc == -6 and n.value > cap:      # GROOT_E_NOSPACE: retry with the size it asked for
+            cap = int(n.value)
+            continue
+        _check(rc)
+        return packed, pos[: n.value].copy(), byte[: n.value].copy()
+
+
 def report(bam_path, cov_cutoff=0.97, low_cov=False, out_path=None):
     """`groot report` (src/reporting/reporting.go): list of (name, read count, length, coverage cigar)"""
     import tempfile

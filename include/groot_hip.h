@@ -88,6 +88,12 @@ int groot_hip_set_profiling(groot_ctx *ctx, int enable);
  * seq_off[i]..seq_off[i+1] = read i (n_reads+1 entries).  Copies H2D and launches; asynchronous. */
 int groot_hip_submit(groot_ctx *ctx, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n_reads,
                      uint32_t first_read_id);
+/* Same batch, bases packed 2 bits each: base b of seq_concat sits in bits 2*(b%4).. of packed[b/4] as
+ * (byte >> 1) & 3 (A=0 C=1 T=2 G=3); every byte that is not one of ACGT is listed in exc_pos (its index in
+ * seq_concat) / exc_byte and may carry any code in `packed`.  A quarter of the PCIe traffic of groot_hip_submit for
+ * the same result (the device unpacks to the byte layout first); groot_host_pack_reads builds the arguments. */
+int groot_hip_submit_packed(groot_ctx *ctx, const uint8_t *packed, const uint64_t *seq_off, uint32_t n_reads,
+                            uint32_t first_read_id, const uint64_t *exc_pos, const uint8_t *exc_byte, uint64_t n_exc);
 /* Same, inputs already resident in HBM.  d_seq must be 16-byte aligned and readable for 16 bytes past
  * the last base (the kernels load 16-byte / 8-byte words); max_len = longest read of the batch
  * (0 = params.max_read_len). */

@@ -185,6 +185,12 @@ int groot_bam_write_travs(groot_bam *bam, const groot_index_view *idx, const gro
                           const uint64_t *masks, uint64_t n_trav, uint64_t *n_records);
 int groot_bam_close(groot_bam *bam);
 
+/* ---- packing reads for groot_hip_submit_packed (include/groot_hip.h) ------------------------------------ */
+/* packed[(n_bases+3)/4]; exceptions (bytes other than A C G T, e.g. N or lower case) in ascending position, at most
+ * exc_cap of them: GROOT_E_NOSPACE with *n_exc = the number needed otherwise.  n_threads 0 = all cores. */
+int groot_host_pack_reads(const uint8_t *seq_concat, uint64_t n_bases, uint8_t *packed, uint64_t *exc_pos, uint8_t *exc_byte,
+                          uint64_t exc_cap, uint64_t *n_exc, uint32_t n_threads);
+
 /* ---- after the hot path: the reference's own consumer of the BAM ---------------------------------- */
 /* `groot report` (src/reporting/reporting.go:33-173, cmd/report.go:104-129): breadth of coverage per reference from the
  * BAM of `groot align` (bam_path NULL = stdin).  One line "name\tread count\tlength\tcoverage cigar" per reference whose

@@ -259,6 +259,31 @@ def test_mixed_length_threshold_sweep_on_resfinder(resfinder_index, threshold):
     al.close()
 
 
+def test_packed_submit_equals_byte_submit(small_index):
+    """groot_hip_submit_packed (2 bits per base + exception list over PCIe) gives what groot_hip_submit gives"""
+    cat, o, lens = synth.reference_sequences(small_index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 5000, 100)
+    seq = seq.copy()
+    rng = np.random.default_rng(3)
+    odd = rng.choice(len(seq), 300, replace=False)
+    seq[odd] = np.frombuffer(b"NnacgtRY", dtype=np.uint8)[rng.integers(0, 8, 300)]      # bytes <= 'T' or lower case: no panic below
+    seq[odd[seq[odd] > ord("T")]] = ord("N")
+    al, counts, run = run_both(small_index, seq, off)
+    got = assert_same(al, counts, run, small_index)
+    sk, sd = al.sketches().copy(), al.seeds().copy()
+    al.attempts_reset()
+    packed, pos, byte = host.pack_reads(seq)
+    assert len(pos) == 300
+    al.submit_packed(packed, off, pos, byte)
+    c2 = al.wait()
+    assert c2 == counts
+    assert np.array_equal(al.sketches(), sk) and np.array_equal(al.seeds(), sd)
+    again = al.alns()
+    for f in got.dtype.names:
+        assert np.array_equal(again[f], got[f]), f
+    al.close()
+
+
 def test_error_behaviour_matches_reference_panics(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)

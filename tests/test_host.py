@@ -322,3 +322,22 @@ def test_bam_fast_path_equals_record_path(small_index, tmp_path):
     host._check(H.groot_bam_close(h))
     assert nrec.value == len(al)
     assert read_bam(slow) == read_bam(fast)
+
+
+def test_pack_reads():
+    """2-bit packing for groot_hip_submit_packed: code (byte >> 1) & 3, everything that is not ACGT listed as an exception"""
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 1_000_003)].copy()
+    odd = rng.choice(len(seq), 500, replace=False)
+    seq[odd] = np.frombuffer(b"NnacgtRY*\x00", dtype=np.uint8)[rng.integers(0, 10, 500)]
+    for threads in (1, 0):
+        packed, pos, byte = host.pack_reads(seq, threads)
+        assert len(packed) == (len(seq) + 3) // 4
+        assert np.array_equal(pos, np.sort(odd).astype(np.uint64)) and np.array_equal(byte, seq[np.sort(odd)])
+        codes = (packed[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3
+        back = np.frombuffer(b"ACTG", dtype=np.uint8)[codes.reshape(-1)[: len(seq)]]
+        keep = np.ones(len(seq), bool)
+        keep[odd] = False
+        assert np.array_equal(back[keep], seq[keep])
+    empty = host.pack_reads(np.zeros(0, np.uint8))
+    assert len(empty[0]) == 0 and len(empty[1]) == 0
