@@ -778,6 +778,24 @@ static int begin_batch(groot_ctx *c, uint32_t n_reads, uint32_t first_read_id)
     return GROOT_OK;
 }
 
+// offsets must not decrease; *max_len = the longest read (branch-free pass so that it vectorises: 10 M reads per batch)
+static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads, uint32_t *max_len)
+{
+    uint64_t longest = 0, bad = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        bad |= (uint64_t)(seq_off[i + 1] < seq_off[i]);
+        longest = std::max(longest, seq_off[i + 1] - seq_off[i]);
+    }
+    if (bad) {
+        uint32_t i = 0;
+        while (seq_off[i + 1] >= seq_off[i]) i++;
+        c->submitted = false;
+        return fail(c, GROOT_E_INVALID, "seq_off not monotone at read %u", i);
+    }
+    *max_len = (uint32_t)std::min<uint64_t>(longest, 0xFFFFFFFFu);
+    return GROOT_OK;
+}
+
 int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n_reads, uint32_t first_read_id)
 {
     if (!c) return GROOT_E_INVALID;
@@ -788,10 +806,7 @@ int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     if (seq_off[0] != 0) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0"); }
     if (total > c->prm.max_batch_bases) { c->submitted = false; return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)total, (unsigned long long)c->prm.max_batch_bases); }
     uint32_t max_len = 0;
-    for (uint32_t i = 0; i < n_reads; i++) {
-        if (seq_off[i + 1] < seq_off[i]) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off not monotone at read %u", i); }
-        max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(seq_off[i + 1] - seq_off[i], 0xFFFFFFFFu));
-    }
+    if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc;
     c->batch_max_len = std::min(max_len, c->prm.max_read_len);
     if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
@@ -812,10 +827,7 @@ int groot_hip_submit_packed(groot_ctx *c, const uint8_t *packed, const uint64_t 
     if (seq_off[0] != 0) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0"); }
     if (total > c->prm.max_batch_bases) { c->submitted = false; return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)total, (unsigned long long)c->prm.max_batch_bases); }
     uint32_t max_len = 0;
-    for (uint32_t i = 0; i < n_reads; i++) {
-        if (seq_off[i + 1] < seq_off[i]) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off not monotone at read %u", i); }
-        max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(seq_off[i + 1] - seq_off[i], 0xFFFFFFFFu));
-    }
+    if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc;
     for (uint64_t i = 0; i < n_exc; i++)
         if (exc_pos[i] >= total) { c->submitted = false; return fail(c, GROOT_E_INVALID, "exception %llu lies outside the batch", (unsigned long long)i); }
     c->batch_max_len = std::min(max_len, c->prm.max_read_len);
