@@ -516,7 +516,7 @@ template <int PW> struct RecRegs {
 // their 8-base chunks with three ds_read_b32 + two alignbit instead of going back to the Infinity Cache /
 // HBM for the read's line and re-doing the reverse complement at every step.
 #ifndef GROOT_ALIGN_WAVES
-#define GROOT_ALIGN_WAVES 1
+#define GROOT_ALIGN_WAVES 4   // 4 waves/SIMD = at most 128 VGPRs (5 or 6 spill and are slower; 3 hide too little latency)
 #endif
 template <int PW, bool LDSR>
 __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignArgs a)
@@ -718,6 +718,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
         if (phase != run) continue;
         GROOT_EV(run);                                          // events 0,1,2: a step of FETCH / SCAN / DFS
+        bool advance = false;                                   // leave the current scan range (one call site: the code is large)
 
         if (run == PH_FETCH) {
             if (!have_read) {
@@ -800,9 +801,10 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             cn_begin = wb.x; cn_end = wb.y;
             seed_s0 = wb.z; seed_len = wb.w;
             GROOT_EV(5);
-            if (start_orientation(0)) next_range();
+            advance = start_orientation(0);
         } else if (run == PH_SCAN) {
-            if (sc_pos >= sc_end) { GROOT_EV(6); next_range(); continue; }   // only after a DFS that used the range's last offset
+            if (sc_pos >= sc_end) { GROOT_EV(6); advance = true; }   // only after a DFS that used the range's last offset
+            else {
             // up to 16 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
             const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
             const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
@@ -825,24 +827,25 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             if (j >= npos) {
                 GROOT_EV(7);
                 sc_pos += npos;
-                if (sc_pos >= sc_end) next_range();           // set up the next range now: no empty step
-                continue;
-            }
-            // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
-            const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
-            const uint32_t off = sc_pos + j;
-            sc_pos = off + 1;
-            if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
-                GROOT_EV(8);
-                if (sc_pos >= sc_end) next_range();
-                continue;
-            }
-            node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
-            cur8 = pre8;
+                advance = sc_pos >= sc_end;                   // set up the next range in this step: no empty one
+            } else {
+                // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
+                const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
+                const uint32_t off = sc_pos + j;
+                sc_pos = off + 1;
+                if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
+                    GROOT_EV(8);
+                    advance = sc_pos >= sc_end;
+                } else {
+                    node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
+                    cur8 = pre8;
 #pragma unroll
-            for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
-            phase = PH_DFS;
-            GROOT_EV(10);
+                    for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
+                    phase = PH_DFS;
+                    GROOT_EV(10);
+                }
+            }
+            }
         } else {
             // ---- DFS: match up to 32 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
             // The lanes stay in here for as long as the scheduling rule above would pick the phase again (lanes only leave
@@ -982,6 +985,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             ns = cs + __popcll(__ballot(phase == PH_SCAN));
             } while (nd > 0 && nd >= ns && nd >= nf);
         }
+        if (advance) next_range();
     }
 
     alns = block_sum(alns, red);
