@@ -489,6 +489,14 @@ __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
 // 0x80 in the low n bytes (n may exceed 8 or be <= 0)
 __device__ __forceinline__ uint64_t low_bytes(int n) { return n <= 0 ? 0 : (n >= 8 ? kHi1 : (kHi1 >> (8 * (8 - n)))); }
 
+// both halves of a 32-byte record in flight together, and kept from being split into per-field loads sunk into branches
+__device__ __forceinline__ void load32(const void *p, uint4 &a, uint4 &b)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    a = q[0]; b = q[1];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
+
 // a NodeRec held in registers as dwords (16-byte loads; every access below uses a constant index)
 template <int PW> struct RecRegs {
     static constexpr int NQ = (int)(sizeof(NodeRec<PW>) / 16);
@@ -501,6 +509,11 @@ template <int PW> struct RecRegs {
             const uint4 v = q[i];
             d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
         }
+        // The whole record is wanted NOW, in one round trip.  Left to itself the compiler sinks field loads into the
+        // branches that use them (seq_off after the length test, first8 folded into a pointer select with the bases
+        // load), which turns one DFS step into three dependent trips to L2.
+#pragma unroll
+        for (int i = 0; i < NQ * 4; i++) asm volatile("" : "+v"(d[i]));
     }
     __device__ __forceinline__ uint32_t seq_off() const { return d[0]; }
     __device__ __forceinline__ uint32_t seq_len() const { return d[1]; }
@@ -724,8 +737,8 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             if (!have_read) {
                 GROOT_EV(3);
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
-                const uint4 *rq = reinterpret_cast<const uint4 *>(a.read_rec + slot);   // records are in slot order
-                const uint4 ra = rq[0], rb = rq[1];               // one 32-byte record per read
+                uint4 ra, rb;                                     // one 32-byte record per read, records in slot order
+                load32(a.read_rec + slot, ra, rb);
                 const uint32_t sc = ra.w;
                 cnt = min(sc & kRecCountMask, a.seed_slots);   // overflow already flagged; batch is re-run
                 cls = a.perm ? (sc >> 24) & 0x3Fu : 0x80u;     // bit 7: no verdicts without the seed stage's sort keys
@@ -789,8 +802,8 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             }
             cls = (cls & 0xBFu) | ((last < 0 && !(cls & 0x80u)) ? 0x40u : 0u);   // bit 6: w is the read's first seed window
             w = nw; last = nw;
-            const uint4 *wq = reinterpret_cast<const uint4 *>(ix.win_rec + w);
-            const uint4 wa = wq[0], wb = wq[1];               // the whole lshe.Key in one 32-byte load
+            uint4 wa, wb;                                     // the whole lshe.Key in one 32-byte load
+            load32(ix.win_rec + w, wa, wb);
             g = wa.x;
             if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
             if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
@@ -957,19 +970,24 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
 #pragma unroll
                     for (int i = 0; i < PW; i++) mask[i] = a.stk_mask[si * PW + i];
                     cur8 = dfs_chunk(dist);
-                    const Rec &pr = recs[pn];
-                    const uint32_t deg = pr.deg;
+                    RecRegs<PW> pr;
+                    pr.load(recs + pn);
+                    const uint32_t deg = pr.deg();
                     uint32_t more = kEmpty;
                     if (deg <= 4) {
                         const unsigned nextb = (unsigned)cur8 & 0xFF;
-                        for (uint32_t e2 = e + 1; e2 < deg; e2++) {
-                            const unsigned cf1 = pr.child_first[e2];
-                            if (cf1 == 'N' || cf1 == nextb) { more = e2; break; }
+#pragma unroll
+                        for (int e2 = 3; e2 >= 1; e2--) {
+                            const unsigned cf1 = pr.child_first(e2);
+                            if ((uint32_t)e2 > e && (uint32_t)e2 < deg && (cf1 == 'N' || cf1 == nextb)) more = e2;
                         }
-                        cur = pr.edges[e];
+                        cur = pr.edge(0);
+                        if (e == 1) cur = pr.edge(1);
+                        if (e == 2) cur = pr.edge(2);
+                        if (e == 3) cur = pr.edge(3);
                     } else {
                         if (e + 1 < deg) more = e + 1;
-                        cur = ix.edges[pr.edges[0] + e];
+                        cur = ix.edges[pr.edge(0) + e];
                     }
                     coff = 0;
                     if (more == kEmpty) sp--;
