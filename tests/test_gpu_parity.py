@@ -284,6 +284,30 @@ def test_packed_submit_equals_byte_submit(small_index):
     al.close()
 
 
+@pytest.mark.parametrize("threshold", [0.99, 0.9])
+def test_long_reads_take_the_unstaged_variant(msa_dir, threshold):
+    """index with 300-base windows, reads of 300-900 bp (max_read_len 1024): too long for the per-lane LDS slices, so the
+    align kernel variant that reads the bases from HBM runs; reads that hang off the graph end included"""
+    index = host.Index.from_msa_files(host.msa_files(msa_dir)[:24], host.index_params(w=300))
+    cat, o, lens = synth.reference_sequences(index)
+    rng = np.random.default_rng(77)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    reads = []
+    for i in range(3000):
+        s = int(rng.integers(0, len(lens)))
+        L = min(300 if i % 3 else int(rng.integers(300, 901)), int(lens[s]))   # window-sized reads seed at any threshold
+        st = int(rng.integers(0, lens[s] - L + 1))
+        r = cat[int(o[s]) + st:int(o[s]) + st + L].tobytes()
+        if i % 7 == 0:
+            r = cat[int(o[s]):int(o[s]) + int(lens[s])].tobytes()[-L:] + b"ACGTACGTAC"   # runs past the last node
+        reads.append(r.translate(comp)[::-1] if rng.integers(0, 2) else r)
+    seq, off = O.pack_reads(reads)
+    al, counts, run = run_both(index, seq, off, threshold=threshold, max_read_len=1024)
+    assert_same(al, counts, run, index)
+    assert counts["mapped"] > 100
+    al.close()
+
+
 def test_error_behaviour_matches_reference_panics(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)
