@@ -135,3 +135,26 @@ def test_travis_e2e_flow(cli, msa_dir, tmp_path):
     assert r.returncode == 0, r.stderr
     text2, refs2, recs2 = read_bam(bam2)
     assert refs2 == refs and recs2 == recs
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_path(argannot_index, tmp_path):
+    """bench.py as the driver launches it for N>1 (torch.distributed.run, one rank per GPU).  This box has one GPU, so both
+    ranks share it and talk over gloo (GROOT_BENCH_TEST_SAME_DEVICE): the sharding, barriers, the all-reduce of the call-count
+    table and the whole-job rate are the code the 8-GPU run executes."""
+    import json
+    import sys
+
+    env = dict(os.environ, GROOT_BENCH_TEST_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300000"]
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["per_step_counts"]["received"] == 300000 and "cpu_baseline" not in line
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "300000", "--no-cpu"],
+                         cwd=REPO, capture_output=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert single["n_gpus"] == 1 and single["config"]["per_step_counts"]["received"] == 300000
