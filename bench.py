@@ -191,13 +191,20 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(REPO, "profiles", "r01_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom.split("<")[0], {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(dom.split("<")[0], {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                # the ceiling that actually binds: VALU issue = wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
+                insts = rec.get("per_launch", {}).get("SQ_INSTS_VALU")
+                if insts:
+                    issue_ms = insts * 4 / (1024 * 2.4e9) * 1e3
+                    valu = {"wave_insts_per_launch": insts, "issue_ms": issue_ms, "frac_of_kernel": issue_ms / dom_ms,
+                            "source": "profiles/r01_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU of the same command)"}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         line = {
             "metric": "Mreads/s aligned", "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -208,7 +215,7 @@ def main():
                        "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
-                         "note": "integer hashing / graph walking: the binding ceiling is VALU issue, not HBM (DESIGN.md)",
+                         "note": "integer hashing / graph walking: the binding ceiling is VALU issue, not HBM (DESIGN.md)", "valu_issue": valu,
                          "other": {k: {"kernel_ms": v[0], "bytes_per_launch": v[1], "achieved": v[1] / (v[0] * 1e-3) / 1e9}
                                    for k, v in kernels.items() if k != dom}},
         }
