@@ -1,7 +1,7 @@
 // groot-hip -- flag-compatible `index` and `align` subcommands on top of libgroot_host.so / libgroot_hip.so.
 //
 //   groot-hip index -m <msaDir> -i <indexDir> [-k 31 -s 21 -w 100 -x 8 -y 4 --maxSketchSpan 30 -p N --log F]
-//        cmd/index.go:44-133: writes <indexDir>/groot.gidx (flat index; the Go gob files are not produced)
+//        cmd/index.go:44-133: writes <indexDir>/groot.gidx (flat index) and the reference's groot.gg + groot.lshe
 //   groot-hip align -i <indexDir> -f a.fq[,b.fq.gz] [-t 0.99 -c 1.0 -g <graphDir> --noAlign -p N --log F] > out.bam
 //        cmd/align.go:30-197 + src/pipeline/sketch.go (DataStreamer..GraphPruner): BAM on stdout, weighted GFAs in
 //        graphDir, the reference's log lines in --log (default groot.log)
@@ -232,6 +232,8 @@ int run_index(const Args &a)   // cmd/index.go:57-133
     const std::string out = a.index_dir + "/groot.gidx";
     logf("writing index files in \"%s\"...", a.index_dir.c_str());
     if (groot_index_save(idx, out.c_str())) die("%s", groot_host_last_error());
+    // and the reference's own files (cmd/index.go:130-131), so that `groot align|haplotype` can use this directory too
+    if (groot_index_save_gob(idx, a.index_dir.c_str(), a.max_span)) die("%s", groot_host_last_error());
     groot_index_free(idx);
     logf("finished in %.3fs", seconds_since(t0));
     return 0;

@@ -364,6 +364,128 @@ static void to_json(const Value &v, const Decoder &dec, std::string &o)
 } // namespace gob
 } // namespace groot
 
+// ---- writer: the same wire format, for index directories the reference can load ---------------------
+namespace groot {
+namespace gob {
+
+struct GType {
+    enum { BASIC, STRUCT, SLICE, MAP } kind = BASIC;
+    int basic = 0;                                                  // 1 bool 2 int 3 uint 4 float 5 bytes 6 string
+    std::string name;
+    std::vector<std::pair<std::string, const GType *>> fields;     // STRUCT
+    const GType *elem = nullptr, *key = nullptr;                   // SLICE / MAP
+};
+
+static void put_uint(std::string &o, uint64_t v)
+{
+    if (v < 128) { o.push_back((char)v); return; }
+    char b[8];
+    int n = 0;
+    for (uint64_t x = v; x; x >>= 8) n++;
+    for (int i = 0; i < n; i++) b[i] = (char)(v >> (8 * (n - 1 - i)));
+    o.push_back((char)(256 - n));
+    o.append(b, (size_t)n);
+}
+static void put_int(std::string &o, int64_t i) { put_uint(o, i < 0 ? ((~(uint64_t)i) << 1) | 1u : (uint64_t)i << 1); }
+static void put_float(std::string &o, double d)
+{
+    uint64_t u, r = 0;
+    memcpy(&u, &d, 8);
+    for (int i = 0; i < 8; i++) { r = (r << 8) | (u & 0xFF); u >>= 8; }
+    put_uint(o, r);
+}
+static void put_bytes(std::string &o, const void *p, size_t n) { put_uint(o, n); o.append((const char *)p, n); }
+
+// one gob stream: type definitions are sent the first time a type is used (definition first, then the types it refers to)
+class Encoder {
+  public:
+    std::string out;
+    int id_of(const GType *t)
+    {
+        if (t->kind == GType::BASIC) return t->basic;
+        auto it = ids_.find(t);
+        if (it != ids_.end()) return it->second;
+        const int id = next_id_++;
+        ids_[t] = id;
+        send_type(t);
+        return id;
+    }
+    // a top-level struct value: `body` holds its fields (as StructWriter leaves them, terminator included)
+    void message(const GType *t, const std::string &body)
+    {
+        std::string head;
+        put_int(head, id_of(t));
+        put_uint(out, head.size() + body.size());
+        out += head;
+        out += body;
+    }
+
+  private:
+    std::map<const GType *, int> ids_;
+    int next_id_ = 65;
+    int ref(const GType *t) const { return t->kind == GType::BASIC ? t->basic : ids_.at(t); }
+    void common(std::string &w, const std::string &name, int id)
+    {
+        if (!name.empty()) { w.push_back(1); put_bytes(w, name.data(), name.size()); w.push_back(1); }
+        else w.push_back(2);
+        put_int(w, id);
+        w.push_back(0);
+    }
+    void send_type(const GType *t)
+    {
+        const int id = ids_.at(t);
+        std::vector<const GType *> parts, inner;
+        if (t->kind == GType::STRUCT) for (auto &f : t->fields) parts.push_back(f.second);
+        else if (t->kind == GType::SLICE) parts = {t->elem};
+        else parts = {t->key, t->elem};
+        for (const GType *p : parts)
+            if (p->kind != GType::BASIC && !ids_.count(p)) { ids_[p] = next_id_++; inner.push_back(p); }
+        std::string w;
+        if (t->kind == GType::STRUCT) {
+            w.push_back(3); w.push_back(1);
+            common(w, t->name, id);
+            if (!t->fields.empty()) {
+                w.push_back(1);
+                put_uint(w, t->fields.size());
+                for (auto &f : t->fields) {
+                    w.push_back(1); put_bytes(w, f.first.data(), f.first.size());
+                    w.push_back(1); put_int(w, ref(f.second));
+                    w.push_back(0);
+                }
+            }
+            w.push_back(0);
+        } else {
+            w.push_back(t->kind == GType::SLICE ? 2 : 4); w.push_back(1);
+            common(w, t->name, id);
+            for (const GType *p : parts) { w.push_back(1); put_int(w, ref(p)); }
+            w.push_back(0);
+        }
+        w.push_back(0);
+        std::string msg;
+        put_int(msg, -id);
+        msg += w;
+        put_uint(out, msg.size());
+        out += msg;
+        for (const GType *p : inner) send_type(p);
+    }
+};
+
+// fields of one struct value: call field(i) before writing the value of a non-zero field i (ascending), end() last
+struct StructWriter {
+    std::string &b;
+    int last = -1;
+    explicit StructWriter(std::string &buf) : b(buf) {}
+    void field(int i) { put_uint(b, (uint64_t)(i - last)); last = i; }
+    void u(int i, uint64_t v) { if (v) { field(i); put_uint(b, v); } }
+    void i64(int i, int64_t v) { if (v) { field(i); put_int(b, v); } }
+    void f(int i, double v) { if (v != 0.0) { field(i); put_float(b, v); } }
+    void str(int i, const void *p, size_t n) { if (n) { field(i); put_bytes(b, p, n); } }
+    void end() { b.push_back(0); }
+};
+
+} // namespace gob
+} // namespace groot
+
 using namespace groot;
 using gob::Value;
 
@@ -581,6 +703,144 @@ int groot_index_load_gob(const char *gg_path, const char *lshe_path, groot_index
         return flatten_graphs(graphs, prm, out);
     } catch (const std::out_of_range &) {
         return set_error(GROOT_E_FORMAT, "gob index: a window or edge refers to a segment that is not in its graph");
+    } catch (const std::exception &e) {
+        return set_error(GROOT_E_FORMAT, "%s", e.what());
+    }
+}
+
+// index.Dump + SaveDB of the reference (cmd/index.go:96-106,130-131; src/pipeline/runtime.go:64-72; src/lshe/lshe.go:71-92):
+// <dir>/groot.gg and <dir>/groot.lshe with the fields `groot index` sets, so that the reference's own `groot align` /
+// `groot haplotype` can load an index built here.  Maps are written in ascending key / window order (Go writes them in
+// random order; a decoder does not care).
+int groot_index_save_gob(const groot_index *idx, const char *dir, uint32_t max_sketch_span)
+{
+    using gob::GType;
+    if (!idx || !dir) return set_error(GROOT_E_INVALID, "null argument");
+    const groot_index_view &v = idx->v;
+    auto basic = [](int id) { GType t; t.kind = GType::BASIC; t.basic = id; return t; };
+    const GType BOOL = basic(1), INT = basic(2), UINT = basic(3), FLOAT = basic(4), BYTES = basic(5), STRING = basic(6);
+    auto slice = [](const char *n, const GType *e) { GType t; t.kind = GType::SLICE; t.name = n; t.elem = e; return t; };
+    auto map = [](const char *n, const GType *k, const GType *e) { GType t; t.kind = GType::MAP; t.name = n; t.key = k; t.elem = e; return t; };
+    auto strct = [](const char *n, std::vector<std::pair<std::string, const GType *>> f) { GType t; t.kind = GType::STRUCT; t.name = n; t.fields = std::move(f); return t; };
+    try {
+        {   // ---- groot.gg: pipeline.Info ----
+            const GType nodes_t = slice("Nodes", &UINT), u32s_t = slice("[]uint32", &UINT), pos_t = map("map[int]int", &INT, &INT);
+            const GType node_t = strct("GrootGraphNode", {{"SegmentID", &UINT}, {"SegmentLength", &FLOAT}, {"Sequence", &BYTES}, {"OutEdges", &nodes_t},
+                                                          {"PathIDs", &u32s_t}, {"Position", &pos_t}, {"KmerFreq", &FLOAT}, {"Marked", &BOOL}});
+            const GType sorted_t = slice("[]*graph.GrootGraphNode", &node_t), paths_t = map("map[uint32][]uint8", &UINT, &BYTES),
+                        lengths_t = map("map[uint32]int", &UINT, &INT), lookup_t = map("map[uint64]int", &UINT, &INT);
+            const GType graph_t = strct("GrootGraph", {{"GrootVersion", &STRING}, {"GraphID", &UINT}, {"SortedNodes", &sorted_t}, {"Paths", &paths_t},
+                                                       {"Lengths", &lengths_t}, {"NodeLookup", &lookup_t}, {"Masked", &BOOL}, {"KmerTotal", &UINT},
+                                                       {"EMiterations", &INT}});
+            const GType align_t = strct("AlignCmd", {{"Fasta", &BOOL}, {"BloomFilter", &BOOL}, {"MinKmerCoverage", &FLOAT}, {"BAMout", &STRING},
+                                                     {"NoExactAlign", &BOOL}});
+            const GType haplo_t = strct("HaploCmd", {{"Cutoff", &FLOAT}, {"MinIterations", &INT}, {"MaxIterations", &INT}, {"TotalKmers", &INT},
+                                                     {"HaploDir", &STRING}});
+            const GType store_t = map("Store", &UINT, &graph_t);
+            const GType info_t = strct("Info", {{"Version", &STRING}, {"NumProc", &INT}, {"Profiling", &BOOL}, {"KmerSize", &INT}, {"SketchSize", &INT},
+                                                {"WindowSize", &INT}, {"NumPart", &INT}, {"MaxK", &INT}, {"MaxSketchSpan", &INT},
+                                                {"ContainmentThreshold", &FLOAT}, {"IndexDir", &STRING}, {"Store", &store_t}, {"Sketch", &align_t},
+                                                {"Haplotype", &haplo_t}});
+            std::string b;
+            gob::StructWriter info(b);
+            const char *ver = groot_host_version();
+            info.str(0, ver, strlen(ver));
+            info.i64(3, v.kmer_size); info.i64(4, v.sketch_size); info.i64(5, v.window_size); info.i64(6, v.num_part); info.i64(7, v.max_k);
+            info.i64(8, max_sketch_span);
+            info.str(10, dir, strlen(dir));
+            info.field(11);
+            gob::put_uint(b, v.n_graphs);
+            for (uint32_t g = 0; g < v.n_graphs; g++) {
+                gob::put_uint(b, g);
+                gob::StructWriter gw(b);
+                gw.u(1, g);
+                const uint32_t n0 = v.graph_node_off[g], n1 = v.graph_node_off[g + 1], p0 = v.graph_path_off[g], p1 = v.graph_path_off[g + 1];
+                if (n1 > n0) {
+                    gw.field(2);
+                    gob::put_uint(b, n1 - n0);
+                    for (uint32_t n = n0; n < n1; n++) {
+                        gob::StructWriter nw(b);
+                        const uint32_t s0 = v.node_seq_off[n], s1 = v.node_seq_off[n + 1];
+                        nw.u(0, v.node_seg_id[n]);
+                        nw.f(1, (double)(s1 - s0));
+                        nw.str(2, v.bases + s0, s1 - s0);
+                        const uint32_t e0 = v.node_edge_off[n], e1 = v.node_edge_off[n + 1];
+                        if (e1 > e0) { nw.field(3); gob::put_uint(b, e1 - e0); for (uint32_t e = e0; e < e1; e++) gob::put_uint(b, v.node_seg_id[v.edges[e]]); }
+                        const uint32_t q0 = v.node_np_off[n], q1 = v.node_np_off[n + 1];
+                        if (q1 > q0) { nw.field(4); gob::put_uint(b, q1 - q0); for (uint32_t q = q0; q < q1; q++) gob::put_uint(b, v.np_path[q]); }
+                        nw.field(5);
+                        gob::put_uint(b, q1 - q0);
+                        for (uint32_t q = q0; q < q1; q++) { gob::put_int(b, v.np_path[q]); gob::put_int(b, v.np_pos[q]); }
+                        nw.end();
+                    }
+                }
+                gw.field(3);
+                gob::put_uint(b, p1 - p0);
+                for (uint32_t p = p0; p < p1; p++) {
+                    gob::put_uint(b, p - p0);
+                    gob::put_bytes(b, v.path_names + v.path_name_off[p], v.path_name_off[p + 1] - v.path_name_off[p]);
+                }
+                gw.field(4);
+                gob::put_uint(b, p1 - p0);
+                for (uint32_t p = p0; p < p1; p++) { gob::put_uint(b, p - p0); gob::put_int(b, v.path_len[p]); }
+                gw.field(5);
+                gob::put_uint(b, n1 - n0);
+                for (uint32_t n = n0; n < n1; n++) { gob::put_uint(b, v.node_seg_id[n]); gob::put_int(b, n - n0); }
+                gw.u(6, v.graph_masked[g] ? 1 : 0);
+                gw.end();
+            }
+            info.field(12); b.push_back(0);      // Sketch AlignCmd{}: struct-typed fields are always sent
+            info.field(13); b.push_back(0);      // Haplotype HaploCmd{}
+            info.end();
+            gob::Encoder enc;
+            enc.message(&info_t, b);
+            std::ofstream f(std::string(dir) + "/groot.gg", std::ios::binary);
+            if (!f || !f.write(enc.out.data(), (std::streamsize)enc.out.size())) return set_error(GROOT_E_IO, "cannot write %s/groot.gg", dir);
+        }
+        {   // ---- groot.lshe: lshe.ContainmentIndex ----
+            const GType cn_t = map("map[uint64]float64", &UINT, &FLOAT), ref_t = slice("[]uint32", &UINT), sk_t = slice("[]uint64", &UINT);
+            const GType key_t = strct("Key", {{"GraphID", &UINT}, {"Node", &UINT}, {"OffSet", &UINT}, {"ContainedNodes", &cn_t}, {"Ref", &ref_t},
+                                              {"RC", &BOOL}, {"Sketch", &sk_t}, {"Freq", &FLOAT}, {"MergeSpan", &UINT}, {"WindowSize", &UINT}});
+            const GType look_t = map("map[string]lshe.Key", &STRING, &key_t);
+            const GType ci_t = strct("ContainmentIndex", {{"NumPart", &INT}, {"MaxK", &INT}, {"NumWindowKmers", &INT}, {"SketchSize", &INT},
+                                                          {"WindowLookup", &look_t}});
+            std::string b;
+            gob::StructWriter ci(b);
+            ci.i64(0, v.num_part); ci.i64(1, v.max_k); ci.i64(2, v.num_window_kmers); ci.i64(3, v.sketch_size);
+            ci.field(4);
+            gob::put_uint(b, v.n_windows);
+            uint32_t dup = 0;
+            for (uint32_t w = 0; w < v.n_windows; w++) {
+                const uint32_t g = v.win_graph[w], node = v.node_seg_id[v.win_node[w]], off = v.win_offset[w];
+                // "g%dn%do%d-%d" (src/pipeline/index.go:199): windows sharing a start position are numbered in window order
+                dup = (w && v.win_graph[w - 1] == g && v.win_node[w - 1] == v.win_node[w] && v.win_offset[w - 1] == off) ? dup + 1 : 0;
+                char name[96];
+                const int nl = snprintf(name, sizeof name, "g%un%uo%u-%u", g, node, off, dup);
+                gob::put_bytes(b, name, (size_t)nl);
+                gob::StructWriter kw(b);
+                kw.u(0, g); kw.u(1, node); kw.u(2, off);
+                kw.field(3);
+                gob::put_uint(b, v.win_cn_off[w + 1] - v.win_cn_off[w]);
+                for (uint32_t c = v.win_cn_off[w]; c < v.win_cn_off[w + 1]; c++) { gob::put_uint(b, v.node_seg_id[v.cn_node[c]]); gob::put_float(b, (double)v.cn_count[c]); }
+                if (v.win_ref_off[w + 1] > v.win_ref_off[w]) {
+                    kw.field(4);
+                    gob::put_uint(b, v.win_ref_off[w + 1] - v.win_ref_off[w]);
+                    for (uint32_t r = v.win_ref_off[w]; r < v.win_ref_off[w + 1]; r++) gob::put_uint(b, v.win_ref[r]);
+                }
+                kw.field(6);
+                gob::put_uint(b, v.sketch_size);
+                for (uint32_t i = 0; i < v.sketch_size; i++) gob::put_uint(b, v.win_sketch[(size_t)w * v.sketch_size + i]);
+                kw.u(8, v.win_merge_span[w]);
+                kw.u(9, v.window_size);
+                kw.end();
+            }
+            ci.end();
+            gob::Encoder enc;
+            enc.message(&ci_t, b);
+            std::ofstream f(std::string(dir) + "/groot.lshe", std::ios::binary);
+            if (!f || !f.write(enc.out.data(), (std::streamsize)enc.out.size())) return set_error(GROOT_E_IO, "cannot write %s/groot.lshe", dir);
+        }
+        return GROOT_OK;
     } catch (const std::exception &e) {
         return set_error(GROOT_E_FORMAT, "%s", e.what());
     }

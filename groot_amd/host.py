@@ -121,6 +121,11 @@ class Index:
     def save(self, path):
         _check(lib().groot_index_save(self._h, path.encode()))
 
+    def save_gob(self, index_dir, max_sketch_span=30):
+        """groot.gg + groot.lshe as the reference's `groot index` writes them (cmd/index.go:130-131)"""
+        os.makedirs(index_dir, exist_ok=True)
+        _check(lib().groot_index_save_gob(self._h, index_dir.encode(), C.c_uint32(max_sketch_span)))
+
     # ---- convenience accessors ------------------------------------------------------------
     def path_name(self, global_path):
         a = self.arrays

@@ -80,6 +80,10 @@ int groot_index_load(const char *path, groot_index **out);
  * Key.OffSet, the "-<i>" suffix of the WindowLookup key, src/pipeline/index.go:195-203).  GROOT_E_FORMAT for a stream
  * that does not decode or whose cross references do not resolve. */
 int groot_index_load_gob(const char *gg_path, const char *lshe_path, groot_index **out);
+/* the reverse: Info.Dump + ContainmentIndex.Dump (src/pipeline/runtime.go:64-72, src/lshe/lshe.go:71-92; cmd/index.go:96-106,
+ * 130-131) -- writes <dir>/groot.gg and <dir>/groot.lshe with the fields `groot index` sets, so that the reference's own
+ * subcommands can load an index built here.  The directory must exist. */
+int groot_index_save_gob(const groot_index *idx, const char *dir, uint32_t max_sketch_span);
 /* renders every top-level value of a gob stream as JSON text (structs as objects holding the fields present on the
  * wire, maps as [[key,value],...]): the decoder behind groot_index_load_gob, exposed for inspection and for the
  * known-answer tests on the byte vectors of the gob documentation.  *needed = bytes incl. the terminating NUL; the

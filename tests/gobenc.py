@@ -189,8 +189,10 @@ def lshe_type():
                                        ("WindowLookup", Map("map[string]lshe.Key", STRING, key))])
 
 
-def index_to_go_values(index, max_sketch_span=30):
-    """the values `groot index` would hold in memory for this flat index (field by field)"""
+def index_to_go_values(index, max_sketch_span=30, as_written_by_index=None):
+    """the values `groot index` would hold in memory for this flat index (field by field).  as_written_by_index = the index
+    directory name: only the fields cmd/index.go:96-106 sets (what groot_index_save_gob writes); otherwise a few more
+    fields are filled in to exercise the reader"""
     a, v = index.arrays, index.view
     store, lookup = {}, {}
     for g in range(v.n_graphs):
@@ -205,7 +207,7 @@ def index_to_go_values(index, max_sketch_span=30):
             nodes.append({"SegmentID": int(a["node_seg_id"][n]), "SegmentLength": float(len(seq)), "Sequence": seq,
                           "OutEdges": [int(a["node_seg_id"][int(e)]) for e in a["edges"][e0:e1]], "PathIDs": pids,
                           "Position": {p: int(x) for p, x in zip(pids, a["np_pos"][q0:q1])}})
-        store[g] = {"GrootVersion": "1.1.2", "GraphID": g, "SortedNodes": nodes,
+        store[g] = {"GrootVersion": None if as_written_by_index else "1.1.2", "GraphID": g, "SortedNodes": nodes,
                     "Paths": {p - p0: index.path_name(p).encode() for p in range(p0, p1)},
                     "Lengths": {p - p0: int(a["path_len"][p]) for p in range(p0, p1)},
                     "NodeLookup": {int(a["node_seg_id"][n]): n - n0 for n in range(n0, n1)},
@@ -227,6 +229,8 @@ def index_to_go_values(index, max_sketch_span=30):
     info = {"Version": "1.1.2", "NumProc": 8, "KmerSize": int(v.kmer_size), "SketchSize": int(s), "WindowSize": int(v.window_size),
             "NumPart": int(v.num_part), "MaxK": int(v.max_k), "MaxSketchSpan": max_sketch_span, "ContainmentThreshold": 0.99,
             "IndexDir": "index-dir", "Store": store, "Sketch": {}, "Haplotype": {}}
+    if as_written_by_index:
+        info.update({"NumProc": 0, "ContainmentThreshold": 0.0, "IndexDir": as_written_by_index})
     ci = {"NumPart": int(v.num_part), "MaxK": int(v.max_k), "NumWindowKmers": int(v.num_window_kmers), "SketchSize": int(s),
           "WindowLookup": lookup}
     return info, ci

@@ -35,6 +35,12 @@ def test_index_subcommand_and_align_without_gpu(cli, msa_dir, tmp_path):
         assert line in text, line
     again = host.Index.load(os.path.join(idx_dir, "groot.gidx"))
     assert (again.view.n_graphs, again.view.n_paths) == (583, 1749)
+    # the directory also holds the reference's own index files (cmd/index.go:130-131), equal to the flat index
+    os.rename(os.path.join(idx_dir, "groot.gidx"), str(tmp_path / "moved.gidx"))
+    from_gob = host.Index.load_gob(idx_dir)
+    for k, arr in again.arrays.items():
+        assert np.array_equal(arr, from_gob.arrays[k]), k
+    os.rename(str(tmp_path / "moved.gidx"), os.path.join(idx_dir, "groot.gidx"))
     # required flags / bad inputs (cmd/index.go:57-61,161-163; cmd/align.go:56-60)
     assert run([cli, "index", "-i", idx_dir]).returncode != 0
     assert run([cli, "index", "-m", msa_dir, "-i", idx_dir, "-k", "200", "-w", "100", "--log", log]).returncode != 0

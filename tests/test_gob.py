@@ -72,6 +72,19 @@ def test_reference_index_dir_loads_to_the_same_flat_index(which, small_index, te
     _same_index(index, host.Index.load_gob(d))
 
 
+@pytest.mark.parametrize("which", ["small", "testgfa"])
+def test_writer_matches_the_test_encoder_byte_for_byte(which, small_index, testgfa_index, tmp_path):
+    """groot_index_save_gob (C++) and tests/gobenc.py (Python) were written independently from the format description: for
+    the same values in the same map order they must emit the same bytes; and the reader takes the files back"""
+    index = small_index if which == "small" else testgfa_index
+    d = str(tmp_path / "out")
+    index.save_gob(d)
+    info, ci = gobenc.index_to_go_values(index, as_written_by_index=d)
+    assert open(os.path.join(d, "groot.gg"), "rb").read() == bytes(gobenc.Encoder().encode(gobenc.info_type(), info).out)
+    assert open(os.path.join(d, "groot.lshe"), "rb").read() == bytes(gobenc.Encoder().encode(gobenc.lshe_type(), ci).out)
+    _same_index(index, host.Index.load_gob(d))
+
+
 def test_gob_index_errors(testgfa_index, tmp_path):
     d = str(tmp_path / "idx")
     with pytest.raises(host.GrootError) as e:
