@@ -43,7 +43,7 @@ struct groot_ctx {
     int device = 0;
     std::string err;
     groot_params prm{};
-    uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0;
+    uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[6]{};
     bool profiling = false;
@@ -52,6 +52,9 @@ struct groot_ctx {
     // index in HBM
     DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
         band_keys, band_ids;
+    DevBuf<ExactEntry> band_hash;
+    DevBuf<uint8_t> band_sig;
+    DevBuf<uint32_t> band_run;
     DevBuf<uint8_t> bases, q_k, q_l;
     DevBuf<uint16_t> q_min_eq;
     DevBuf<uint64_t> win_sketch;
@@ -675,6 +678,46 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         }
         HIP_TRY(c, upload(c->band_keys, keys.data(), keys.size()));
         HIP_TRY(c, upload(c->band_ids, ids.data(), ids.size()));
+        // hash tables over the distinct K-prefixes of every band: the query finds the first matching row with one or two
+        // probes instead of a binary search of ~log2(n) dependent loads
+        uint32_t bits = 4;
+        while ((1ull << bits) < 2 * (uint64_t)n) bits++;
+        c->band_hash_bits = bits;
+        const uint32_t cap = 1u << bits;
+        std::vector<ExactEntry> tab((size_t)lmax * mk * cap, ExactEntry{0, kEmpty});
+        for (uint32_t b = 0; b < lmax; b++)
+            for (uint32_t K = 1; K <= mk; K++) {
+                ExactEntry *t = tab.data() + (((size_t)b * mk + (K - 1)) << bits);
+                for (uint32_t e = 0; e < n; e++) {
+                    const uint32_t *ke = &keys[((size_t)b * n + e) * mk];
+                    if (e && std::equal(ke, ke + K, ke - mk)) continue;      // same prefix as the previous row
+                    uint64_t h = GROOT_SKETCH_HASH_INIT;
+                    for (uint32_t j = 0; j < K; j++) h = sketch_hash_step(h, ke[j]);
+                    uint32_t slot = (uint32_t)h & (cap - 1);
+                    while (t[slot].id != kEmpty) slot = (slot + 1) & (cap - 1);
+                    t[slot] = ExactEntry{(uint32_t)(h >> 32), e};
+                }
+            }
+        HIP_TRY(c, upload(c->band_hash, tab.data(), tab.size()));
+        std::vector<uint8_t> sig((size_t)lmax * n * 32, 0);
+        const uint32_t sl = std::min<uint32_t>(s, 32);
+        for (uint32_t b = 0; b < lmax; b++)
+            for (uint32_t e = 0; e < n; e++) {
+                const uint64_t *ws = v->win_sketch + (size_t)ids[(size_t)b * n + e] * s;
+                uint8_t *row = &sig[((size_t)b * n + e) * 32];
+                for (uint32_t i = 0; i < sl; i++) row[i] = (uint8_t)sig8(ws[i]);
+            }
+        HIP_TRY(c, upload(c->band_sig, sig.data(), sig.size(), 32));
+        std::vector<uint32_t> run((size_t)lmax * mk * n, 0);
+        for (uint32_t b = 0; b < lmax; b++)
+            for (uint32_t K = 1; K <= mk; K++) {
+                uint32_t *rn = run.data() + ((size_t)b * mk + (K - 1)) * n;
+                for (uint32_t e = n; e-- > 0;) {             // backwards: length of the run of equal K-prefixes starting at e
+                    const uint32_t *ke = &keys[((size_t)b * n + e) * mk];
+                    rn[e] = (e + 1 < n && std::equal(ke, ke + K, ke + mk)) ? rn[e + 1] + 1 : 1;
+                }
+            }
+        HIP_TRY(c, upload(c->band_run, run.data(), run.size()));
     }
     {   // per kmerCount: (K, L) of the partitions (all have Upper = NumWindowKmers) and min #equal slots
         std::vector<uint8_t> qk(c->max_q + 1, 0), ql(c->max_q + 1, 0);
@@ -695,6 +738,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     x.edges = c->edges.p; x.bases = c->bases.p;
     x.win_prefix = c->win_prefix.p; x.win_graph = c->win_graph.p; x.win_rec = c->win_rec.p; x.cn_node = c->cn_node.p;
     x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
+    x.band_hash = c->band_hash.p; x.band_hash_bits = c->band_hash_bits; x.band_sig = c->band_sig.p; x.band_run = c->band_run.p;
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
 
     // ---- batch buffers ----

@@ -56,6 +56,8 @@ __host__ __device__ __forceinline__ uint64_t sketch_hash_step(uint64_t h, uint64
     return h ^ (h >> 29);
 }
 #define GROOT_SKETCH_HASH_INIT 0x9E3779B97F4A7C15ULL
+// one byte of a sketch slot for DeviceIndex::band_sig
+__host__ __device__ __forceinline__ uint32_t sig8(uint64_t v) { return (uint32_t)((v * 0xD6E8FEB86659FD93ULL) >> 56); }
 
 // 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 12-bit code of the first 6 bases of r8,
 // or -1 if one of them is not ACGT (such a base can still meet the graph's 'N' wildcard)
@@ -296,6 +298,10 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
         constexpr int LMAX = S / MAXK;
         const uint32_t K = ix.q_k[q], L = ix.q_l[q];
         const uint32_t n = ix.n_windows;
+        constexpr int SL = S < 32 ? S : 32;                 // slots covered by the row signatures
+        uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < SL; i++) rs[i >> 2] |= sig8(m[i]) << (8 * (i & 3));
 #pragma unroll
         for (int b = 0; b < LMAX; b++) {
             if ((uint32_t)b >= L) break;
@@ -311,12 +317,34 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
                 }
                 return 0;
             };
-            uint32_t lo = 0, hi = n;
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (cmp(mid) >= 0) hi = mid; else lo = mid + 1;
+            // first row of the (sorted) band table with this prefix: hash table over the distinct prefixes
+            uint32_t lo = n;
+            if (K >= 1) {
+                uint64_t hk = GROOT_SKETCH_HASH_INIT;
+#pragma unroll
+                for (int j = 0; j < MAXK; j++)
+                    if ((uint32_t)j < K) hk = sketch_hash_step(hk, (uint32_t)m[b * MAXK + j]);
+                const ExactEntry *tab = ix.band_hash + (((size_t)b * MAXK + (K - 1)) << ix.band_hash_bits);
+                const uint32_t hmask = (1u << ix.band_hash_bits) - 1u, tag = (uint32_t)(hk >> 32);
+                for (uint32_t slot = (uint32_t)hk & hmask;; slot = (slot + 1) & hmask) {
+                    const ExactEntry e = tab[slot];
+                    if (e.id == kEmpty) break;
+                    if (e.tag == tag && cmp(e.id) == 0) { lo = e.id; break; }
+                }
             }
-            for (uint32_t e = lo; e < n && cmp(e) == 0; e++) {
+            const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * 32);
+            const uint32_t e_end = lo < n ? lo + ix.band_run[((size_t)b * MAXK + (K - 1)) * n + lo] : n;   // rows with this prefix
+            for (uint32_t e = lo; e < e_end; e++) {
+                // slots whose signature bytes agree (pad bytes are zero on both sides): an upper bound of the equal slots
+                const uint4 sa = sigs[2 * (size_t)e], sb = sigs[2 * (size_t)e + 1];
+                const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+                uint32_t same = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t x = ws8[i] ^ rs[i];
+                    same += __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));
+                }
+                if (same - (32u - SL) + (uint32_t)(S - SL) < min_eq) continue;
                 const uint32_t id = ids[e];
                 const uint64_t *ws = ix.win_sketch + (size_t)id * S;
                 uint32_t eq = 0;
