@@ -82,6 +82,14 @@ def main():
 
     import torch
 
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        # the native libraries normally travel prebuilt; (re)build whatever is missing or stale (logs go to stderr)
+        import __graft_entry__ as entry
+
+        entry.build_host()
+        entry.build_hip()
+        if args.gpus == 1 and not args.no_cpu:
+            entry.build_oracle()
     from groot_amd import device, synth
 
     rank = int(os.environ.get("RANK", "0"))
