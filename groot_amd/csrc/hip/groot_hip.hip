@@ -766,10 +766,10 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
     if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 4))) return rc;
     if (int rc = alloc_ovf(c, std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
-    #ifndef GROOT_ALIGN_BLOCKS_PER_CU
-#define GROOT_ALIGN_BLOCKS_PER_CU 8
-#endif
-    c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, 256u * GROOT_ALIGN_BLOCKS_PER_CU * kBlock);
+    // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, (uint32_t)std::max(n_cu, 1) * GROOT_ALIGN_WAVES * kBlock);
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
     HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
