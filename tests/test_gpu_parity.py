@@ -308,6 +308,31 @@ def test_long_reads_take_the_unstaged_variant(msa_dir, threshold):
     al.close()
 
 
+@pytest.mark.parametrize("k,sketch,w", [(11, 8, 50), (15, 16, 60), (21, 24, 80), (31, 32, 100), (25, 42, 120), (31, 64, 100), (9, 10, 40)])
+def test_other_index_parameters(msa_dir, k, sketch, w):
+    """every compiled sketch size (and k-mer sizes that take the generic multiplier path / leave fewer than 12 bases to the
+    prefix tables' second 6-mer): window-sized and shorter reads, both strands, two thresholds"""
+    index = host.Index.from_msa_files(host.msa_files(msa_dir)[:8], host.index_params(k=k, s=sketch, w=w))
+    cat, o, lens = synth.reference_sequences(index)
+    rng = np.random.default_rng(k * 1000 + sketch)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    reads = []
+    for i in range(2500):
+        sq = int(rng.integers(0, len(lens)))
+        L = min(w if i % 2 else int(rng.integers(max(k, w // 2), w + 30)), int(lens[sq]))
+        st = int(rng.integers(0, lens[sq] - L + 1))
+        r = bytearray(cat[int(o[sq]) + st:int(o[sq]) + st + L].tobytes())
+        if i % 11 == 0:
+            r[0] = ord("A") if r[0] != ord("A") else ord("C")
+        r = bytes(r)
+        reads.append(r.translate(comp)[::-1] if rng.integers(0, 2) else r)
+    seq, off = O.pack_reads(reads)
+    for t in (0.99, 0.9):
+        al, counts, run = run_both(index, seq, off, threshold=t)
+        assert_same(al, counts, run, index)
+        al.close()
+
+
 def test_error_behaviour_matches_reference_panics(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)
