@@ -10,7 +10,7 @@ cd "$GRAFT_REPO_ROOT"
 P=/tmp/prof; rm -rf $P; mkdir -p $P profiles gpurun_out
 ARGS="--steps 3 --warmup 1 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o t -- python bench.py $ARGS > gpurun_out/prof_trace.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $P/sq -o c -- python bench.py $ARGS > gpurun_out/prof_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $P/sq -o c -- python bench.py $ARGS > gpurun_out/prof_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -o c -- python bench.py $ARGS > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -o c -- python bench.py $ARGS > gpurun_out/prof_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $P/tcc -o c -- python bench.py $ARGS > gpurun_out/prof_tcc.log 2>&1
