@@ -98,6 +98,38 @@ def resfinder_index(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def accuracy_index(msa_dir):
+    """arg-annot.90 with the parameters of testing/run_accuracy_tests.sh:13-20 (k=41 s=21 w=150 x=8 y=4)"""
+    from groot_amd import host
+
+    return host.Index.from_msa_dir(msa_dir, host.index_params(k=41, s=21, w=150))
+
+
+@pytest.fixture(scope="session")
+def accuracy_reads():
+    return read_fastq(os.path.join(DATA, "argannot-150bp-10000-reads.fq.gz"))
+
+
+def accuracy_stats(index, reads, alns):
+    """testing/groot-accuracy.go:56-140: aligned / multi-aligned reads, reads without a record on the reference named in the
+    read header (field 9 of the randomreads.sh name, up to '$'; randomreads writes '{' for '_'), records with the right start"""
+    names = [index.path_name(p).lstrip("*") for p in range(index.view.n_paths)]
+    hits = {}
+    for a in alns:
+        hits.setdefault(int(a["read_id"]), []).append(a)
+    multi = sum(1 for h in hits.values() if len(h) > 1)
+    wrong_as_the_tool_counts, wrong, right_start = 0, 0, 0
+    for rid, hs in hits.items():
+        parts = reads[rid][0].decode().split("_")
+        ref, pos = parts[9].split("$")[0].split(" ")[0], int(parts[2])
+        refs = [names[int(a["ref_id"])] for a in hs]
+        wrong_as_the_tool_counts += ref not in refs
+        wrong += ref.replace("{", "_") not in refs
+        right_start += sum(1 for a, n in zip(hs, refs) if n == ref.replace("{", "_") and int(a["pos"]) == pos)
+    return {"aligned": len(hits), "multi": multi, "misaligned_tool": wrong_as_the_tool_counts, "misaligned": wrong, "right_start": right_start}
+
+
+@pytest.fixture(scope="session")
 def genes_index():
     """src/pipeline/test-data/test-genes.msa with the parameters of 1_pipeline_test.go:32-40"""
     from groot_amd import host

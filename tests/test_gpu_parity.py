@@ -333,6 +333,19 @@ def test_other_index_parameters(msa_dir, k, sketch, w):
         al.close()
 
 
+def test_accuracy_fixture(accuracy_index, accuracy_reads):
+    """the input of testing/run_accuracy_tests.sh (k=41 s=21 w=150): device == oracle, and groot-accuracy.go's tallies"""
+    from conftest import accuracy_stats
+
+    seq, off = O.pack_reads([r[1] for r in accuracy_reads])
+    al, counts, run = run_both(accuracy_index, seq, off)
+    got = assert_same(al, counts, run, accuracy_index)
+    st = accuracy_stats(accuracy_index, accuracy_reads, got)
+    assert st == accuracy_stats(accuracy_index, accuracy_reads, run.alns())
+    assert st["aligned"] >= 9900 and st["misaligned"] <= 20
+    al.close()
+
+
 def test_error_behaviour_matches_reference_panics(small_index):
     cat, o, lens = synth.reference_sequences(small_index)
     seq, off, _ = synth.reads_np(cat, o, lens, 32, 100)

@@ -179,3 +179,20 @@ def test_golden_digests(argannot_index, perfect_reads, variable_reads, genes_ind
     with open(GOLDEN) as f:
         exp = json.load(f)
     assert got == exp
+
+
+def test_accuracy_flow_on_the_reference_fixture(accuracy_index, accuracy_reads):
+    """testing/run_accuracy_tests.sh: 10 000 error-free 150 bp reads simulated from the ARG-annot genes, index k=41 s=21 w=150,
+    align -t 0.99, then groot-accuracy.go's tallies.  The script prints percentages without asserting; what must hold for
+    error-free reads: nearly all align, and an aligned read has a record on the gene it was simulated from."""
+    from conftest import accuracy_stats
+
+    seq, off = O.pack_reads([r[1] for r in accuracy_reads])
+    run = O.Run(accuracy_index, 0.99)
+    run.batch(seq, off)
+    st = accuracy_stats(accuracy_index, accuracy_reads, run.alns())
+    assert st["aligned"] >= 9900                                  # 99.6 % here; the rest lost their windows to the dropped last run
+    assert st["misaligned"] <= 20                                 # reads of a 3' end that only a sister allele still indexes
+    assert st["misaligned_tool"] - st["misaligned"] > 100         # the tool itself is fooled by randomreads' '{' for '_'
+    assert st["right_start"] >= st["aligned"] - st["misaligned"] - 200
+    assert run.counts()["received"] == 10000 and run.counts()["revcomp_panics"] == 0
