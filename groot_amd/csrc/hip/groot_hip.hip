@@ -977,6 +977,9 @@ int groot_hip_wait(groot_ctx *c, groot_counts *counts)
     for (int e = 0; e < 32; e++)
         if (c->hctr.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, c->hctr.dbg[e], c->hctr.dbg[32 + e]);
     fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", c->hctr.dbg[63]);
+    for (int ph = 0; ph < 3; ph++)
+        fprintf(stderr, "[groot work] phase %d: %llu steps, %.2f us per step (wall clock, per wave)\n", ph, c->hctr.dbg[27 + ph],
+                c->hctr.dbg[27 + ph] ? (double)c->hctr.dbg[24 + ph] / 100.0 / (double)c->hctr.dbg[27 + ph] : 0.0);
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "[groot work] %s (buckets of 2 iterations):", h ? "round length" : "lane finish");
         for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", c->hctr.dbg[64 + 64 * h + b]);

@@ -575,6 +575,8 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
 #ifdef GROOT_WORK_COUNTERS
     uint32_t ev = 0;                                       // events of this lane in the current wave iteration
     uint32_t wc_iter = 0, wc_round0 = 0;                   // wave iterations so far / at the last refill
+    unsigned long long wc_t[3] = {0, 0, 0};                // wall-clock ticks (100 MHz) per phase, wave-uniform
+    uint32_t wc_n[3] = {0, 0, 0};                          // steps per phase
 #define GROOT_EV(i) (ev |= 1u << (i))
 #else
 #define GROOT_EV(i) ((void)0)
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     };
 
     for (;;) {
-#ifdef GROOT_WORK_COUNTERS
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2     // (2 = phase timing only: the tally itself costs time)
         for (int e = 0; e < 32; e++) {                         // convergent point: tally the previous iteration
             const unsigned long long b = __ballot((ev >> e) & 1u);
             if (b && (threadIdx.x & 63) == 0) {
@@ -719,6 +721,8 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             }
         }
         ev = 0;
+#endif
+#ifdef GROOT_WORK_COUNTERS
         wc_iter++;
 #endif
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
@@ -730,9 +734,11 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
             if (cw >= kRefill || (cw && !(bf | bs | bd))) {
-#ifdef GROOT_WORK_COUNTERS
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
                 if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
+                wc_round0 = wc_iter;
+#elif defined(GROOT_WORK_COUNTERS)
                 wc_round0 = wc_iter;
 #endif
                 const uint64_t base = (uint64_t)chunk_j * 64u;
@@ -759,6 +765,10 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
         if (phase != run) continue;
         GROOT_EV(run);                                          // events 0,1,2: a step of FETCH / SCAN / DFS
+#ifdef GROOT_WORK_COUNTERS
+        const unsigned long long wc_t0 = wall_clock64();
+        const uint32_t wc_steps0 = wc_iter;
+#endif
         bool advance = false;                                   // leave the current scan range (one call site: the code is large)
 
         if (run == PH_FETCH) {
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                 }
             if (nw == kEmpty) {                               // every seed of the read handled
                 GROOT_EV(4);
-#ifdef GROOT_WORK_COUNTERS
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
                 atomicAdd(&a.ctr->dbg[64 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // when in its round the lane finished
 #endif
                 a.trav_cnt[r] = ord;
@@ -1032,8 +1042,19 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             } while (nd > 0 && nd >= ns && nd >= nf);
         }
         if (advance) next_range();
+#ifdef GROOT_WORK_COUNTERS
+        {   // wall-clock ticks (100 MHz) and steps of this phase execution (wave-uniform values)
+            const unsigned long long dt = wall_clock64() - wc_t0;
+            const uint32_t st = run == PH_DFS ? wc_iter - wc_steps0 : 1u;
+            if (run == PH_FETCH) { wc_t[0] += dt; wc_n[0] += st; } else if (run == PH_SCAN) { wc_t[1] += dt; wc_n[1] += st; } else { wc_t[2] += dt; wc_n[2] += st; }
+        }
+#endif
     }
 
+#ifdef GROOT_WORK_COUNTERS
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 3; i++) { atomicAdd(&a.ctr->dbg[24 + i], wc_t[i]); atomicAdd(&a.ctr->dbg[27 + i], (unsigned long long)wc_n[i]); }
+#endif
     alns = block_sum(alns, red);
     mapped = block_sum(mapped, red);
     multimapped = block_sum(multimapped, red);
