@@ -340,7 +340,8 @@ static bool seed_supported(uint32_t s, uint32_t max_k)
 {
     if (max_k != 4) return false;
     switch (s) {
-    case 8: case 10: case 16: case 20: case 21: case 24: case 30: case 32: case 42: case 64: return true;
+    case 8: case 10: case 12: case 16: case 20: case 21: case 24: case 28: case 30: case 32: case 36: case 40: case 42: case 48: case 50:
+    case 56: case 64: return true;
     default: return false;
     }
 }
@@ -360,13 +361,20 @@ static void launch_seed(uint32_t s, const SeedArgs &a, bool dump, dim3 grid, siz
     switch (s) {
     case 8: launch_seed_sm<8, 4, -1>(a, dump, grid, lds, st); break;
     case 10: launch_seed_sm<10, 4, -1>(a, dump, grid, lds, st); break;
+    case 12: launch_seed_sm<12, 4, -1>(a, dump, grid, lds, st); break;
     case 16: launch_seed_sm<16, 4, -1>(a, dump, grid, lds, st); break;
     case 20: launch_seed_sm<20, 4, -1>(a, dump, grid, lds, st); break;
     case 21: launch_seed_sm<21, 4, -1>(a, dump, grid, lds, st); break;
     case 24: launch_seed_sm<24, 4, -1>(a, dump, grid, lds, st); break;
+    case 28: launch_seed_sm<28, 4, -1>(a, dump, grid, lds, st); break;
     case 30: launch_seed_sm<30, 4, -1>(a, dump, grid, lds, st); break;
     case 32: launch_seed_sm<32, 4, -1>(a, dump, grid, lds, st); break;
+    case 36: launch_seed_sm<36, 4, -1>(a, dump, grid, lds, st); break;
+    case 40: launch_seed_sm<40, 4, -1>(a, dump, grid, lds, st); break;
     case 42: launch_seed_sm<42, 4, -1>(a, dump, grid, lds, st); break;
+    case 48: launch_seed_sm<48, 4, -1>(a, dump, grid, lds, st); break;
+    case 50: launch_seed_sm<50, 4, -1>(a, dump, grid, lds, st); break;
+    case 56: launch_seed_sm<56, 4, -1>(a, dump, grid, lds, st); break;
     case 64: launch_seed_sm<64, 4, -1>(a, dump, grid, lds, st); break;
     default: break;
     }

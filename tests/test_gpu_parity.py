@@ -308,7 +308,8 @@ def test_long_reads_take_the_unstaged_variant(msa_dir, threshold):
     al.close()
 
 
-@pytest.mark.parametrize("k,sketch,w", [(11, 8, 50), (15, 16, 60), (21, 24, 80), (31, 32, 100), (25, 42, 120), (31, 64, 100), (9, 10, 40)])
+@pytest.mark.parametrize("k,sketch,w", [(11, 8, 50), (15, 16, 60), (21, 24, 80), (31, 32, 100), (25, 42, 120), (31, 64, 100), (9, 10, 40),
+                                          (13, 12, 50), (27, 28, 90), (31, 36, 100), (31, 40, 100), (21, 48, 100), (31, 50, 100), (31, 56, 110)])
 def test_other_index_parameters(msa_dir, k, sketch, w):
     """every compiled sketch size (and k-mer sizes that take the generic multiplier path / leave fewer than 12 bases to the
     prefix tables' second 6-mer): window-sized and shorter reads, both strands, two thresholds"""
