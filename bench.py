@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- Mreads/s aligned on MI355X for BASELINE.json's workload.
+"""bench.py -- Mreads/s aligned on MI355X for BASELINE.json's workload (configs[2]).
 
-A step = one pass of the whole `groot align` hot path (sketch -> LSH-Ensemble seed -> graph DFS
-alignment -> canonical ordering of the traversal records) over one batch of synthetic 100 bp
-reads that is already resident in HBM.  Reads shard across GPUs (one process per GPU, index
-replicated); the only exchange is one RCCL all-reduce of the IncrementSubPath call counts after the
-last step (inside the timed region).
+A step = one pass of the whole `groot align` hot path (sketch -> LSH-Ensemble seed -> graph DFS alignment -> canonical
+ordering of the traversal records) over one batch of synthetic 100 bp reads that is already resident in HBM; the records
+stay in HBM (`value`).  Reads shard across GPUs (one process per GPU, index replicated); the only exchange is one RCCL
+all-reduce of the IncrementSubPath call counts after the last step (inside the timed region).
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
+Beside `value` the same JSON line carries, at N=1:
+  host_fed      pinned host buffers -> groot_hip_submit_acquired (2-bit bases + u16 lengths over PCIe) -> kernels ->
+                traversal records back in pinned host memory (groot_hip_collect), several batches in flight in ONE ctx:
+                SURVEY 8d's "first submit -> last collect" rate, PCIe in both directions included
+  cli_e2e       build/groot-hip align: FASTQ file -> BAM file + GFAs, the whole process
+  cpu_baseline  the oracle (CPU restatement of the reference path) as one process per hardware thread
+
+  python bench.py --gpus 1 --steps 200 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tarfile
 import tempfile
@@ -26,16 +33,21 @@ sys.path.insert(0, REPO)
 
 READ_LEN = 100
 HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
+PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
 
 
 def load_index():
     """arg-annot.90, k=31 s=21 w=100 x=8 y=4 (cmd/index.go:45-49 defaults), cached under build/"""
     from groot_amd import host
 
-    cache = os.path.join(REPO, "build", "arg-annot.90.k31.s21.w100.gidx")
+    cache = host.index_cache_path("arg-annot.90.k31.s21.w100")
     if os.path.exists(cache):
         try:
-            return host.Index.load(cache)
+            return host.Index.load(cache), cache
         except Exception:
             pass
     with tempfile.TemporaryDirectory() as td:
@@ -49,54 +61,181 @@ def load_index():
         os.replace(tmp, cache)
     except Exception:
         pass
-    return index
+    return index, cache
 
 
-def cpu_baseline(index, n_sample):
-    """the oracle (single-thread C port of the reference path) timed on this box's host cores"""
-    from groot_amd import synth
-    from oracle import oracle_py as O
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(index_path, seconds):
+    """The oracle (C port of the reference path, single thread per instance) on this box's host cores: one PROCESS per
+    hardware thread, each on its own slice of the synthetic stream, all started together (oracle/cpu_worker.py).  The
+    reference's Go binary cannot be built here (no Go toolchain): kind = "port"."""
+    worker = os.path.join(REPO, "oracle", "cpu_worker.py")
 
-    cat, off, lens = synth.reference_sequences(index)
-    seq, seq_off, _ = synth.reads_np(cat, off, lens, n_sample, READ_LEN)
-    run = O.Run(index, 0.99)
+    def run(n_proc, per, first0):
+        procs = [subprocess.Popen([sys.executable, worker, index_path, str(first0 + i * per), str(per), str(READ_LEN), "25000"],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(n_proc)]
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu worker failed to start")
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+        for p in procs:
+            p.wait()
+        wall = max(r["t_end"] for r in res) - min(r["t_start"] for r in res)
+        return sum(r["reads"] for r in res) / wall / 1e6, wall
+
+    one_n = 150_000
+    one, one_wall = run(1, one_n, 0)
+    cores = os.cpu_count() or 1
+    per = int(max(50_000, min(600_000, one * 1e6 * seconds * 0.6)) // 25_000 * 25_000)   # SMT siblings run slower than a lone thread
+    allv, wall = run(cores, per, 1_000_000)
+    return {"value": allv, "unit": "Mreads/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} oracle processes x {per} reads of the same synthetic stream, started together, {wall:.1f} s wall "
+                      f"(records dropped per 25k-read chunk as the reference streams them to the BAM)",
+            "single_core": {"value": one, "sample": f"{one_n} reads, one process, {one_wall:.1f} s"},
+            "scaling_efficiency": allv / (one * cores),
+            "note": "oracle/groot_oracle.c = CPU restatement of the reference path; the Go binary itself cannot be built in this image"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def host_fed(index, d_seq, R, steps, depth=3):
+    """submit -> collect through pinned host memory, `depth` batches in flight in one ctx.  The packed batch is written
+    into each slot's pinned staging once (a FASTQ parser's job in the CLI); the timed loop is acquire -> submit_acquired ->
+    collect -> release, i.e. H2D of 27 B/read, the kernels, D2H of the traversal records."""
+    import torch
+
+    from groot_amd import device, host
+
+    seq_host = d_seq[: R * READ_LEN].cpu().numpy()
+    packed, exc_pos, exc_byte = host.pack_reads(seq_host)
+    lens = np.full(R, READ_LEN, dtype=np.uint16)
+    al = device.Aligner(index, device=torch.cuda.current_device(), max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
+                        pipeline_depth=depth)
+    bufs = [al.acquire() for _ in range(depth)]
+    for b in bufs:
+        b["packed"][: len(packed)] = packed
+        b["seq_len"][:R] = lens
+        b["exc_pos"][: len(exc_pos)] = exc_pos
+        b["exc_byte"][: len(exc_byte)] = exc_byte
+    for b in bufs:                                   # warm-up: also sizes the pinned result buffers
+        al.submit_acquired(b["ticket"], R, len(exc_pos))
+    first = None
+    for _ in range(depth):
+        r = al.collect(copy=False)
+        first = first or r["counts"]
+        al.release(r["ticket"])
+    al.attempts_reset()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run.batch(seq, seq_off)
+    done = 0
+    trav_bytes = 0
+    for i in range(steps):
+        b = al.acquire()                             # a free slot: its staging still holds the packed batch
+        al.submit_acquired(b["ticket"], R, len(exc_pos))
+        if al.in_flight()[0] == depth:
+            r = al.collect(copy=False)
+            trav_bytes += r["n_travs"] * (20 + 8 * index.view.path_words)
+            al.release(r["ticket"])
+            done += 1
+    while done < steps:
+        r = al.collect(copy=False)
+        trav_bytes += r["n_travs"] * (20 + 8 * index.view.path_words)
+        al.release(r["ticket"])
+        done += 1
     dt = time.perf_counter() - t0
-    one = {"value": n_sample / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
-           "sample": f"first {n_sample} reads of the same synthetic stream, oracle/groot_oracle.c single thread, {dt:.1f} s"}
-    del run
-    # the whole host, as the reference's goroutine path would use it (`groot align -p <cores>`): one oracle instance per
-    # hardware thread, each on its own slice of the stream (reads are independent; ctypes releases the GIL)
-    import threading
-
-    cores = min(os.cpu_count() or 1, 256)
-    per = max(20_000, min(100_000, n_sample // 4))
-    runs = [O.Run(index, 0.99) for _ in range(cores)]
-    slices = []
-    for i in range(cores):
-        lo = (i * per) % max(1, n_sample - per + 1)
-        slices.append((np.ascontiguousarray(seq[lo * READ_LEN:(lo + per) * READ_LEN]), np.ascontiguousarray(seq_off[lo:lo + per + 1] - seq_off[lo])))
-    th = [threading.Thread(target=lambda r=r, sl=sl: r.batch(sl[0], sl[1])) for r, sl in zip(runs, slices)]
+    out = {"value": steps * R / dt / 1e6, "unit": "Mreads/s", "steps": steps, "batches_in_flight": depth, "ms_per_batch": dt / steps * 1e3,
+           "h2d_bytes_per_read": (len(packed) + 2 * R + 9 * len(exc_pos)) / R, "d2h_bytes_per_read": trav_bytes / (steps * R),
+           "what": "one ctx, one index replica: pinned staging -> H2D (2-bit bases + u16 lengths) -> kernels -> D2H of the traversal "
+                   "records into pinned host memory; first submit -> last collect"}
+    # the plain-ASCII entry point with pageable caller memory (what a cgo caller handing over Go slices gets)
+    off = np.arange(R + 1, dtype=np.uint64) * READ_LEN
+    n_ascii = max(3, steps // 4)
     t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    done = 0
+    for i in range(n_ascii):
+        al.submit(seq_host, off)
+        if al.in_flight()[0] == depth:
+            r = al.collect(copy=False)
+            al.release(r["ticket"])
+            done += 1
+    while done < n_ascii:
+        r = al.collect(copy=False)
+        al.release(r["ticket"])
+        done += 1
     dta = time.perf_counter() - t0
-    allc = {"value": cores * per / dta / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} oracle instances x {per} reads of the same synthetic stream in parallel, {dta:.1f} s"}
-    return one, allc
+    out["ascii_pageable"] = {"value": n_ascii * R / dta / 1e6, "unit": "Mreads/s", "steps": n_ascii,
+                             "what": "groot_hip_submit: ASCII bases + u64 offsets copied from pageable memory into pinned staging, 108 B/read over PCIe"}
+    al.close()
+    return out, first
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+def write_fastq(path, seq_host, n):
+    """n fixed-length records '@r%09d\\nSEQ\\n+\\nIII..\\n' straight from the ASCII read matrix"""
+    L = READ_LEN
+    rec = np.empty((n, 1 + 10 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(9):
+        rec[:, 2 + d] = (idx // 10 ** (8 - d)) % 10 + ord("0")
+    rec[:, 11] = ord("\n")
+    rec[:, 12:12 + L] = seq_host[: n * L].reshape(n, L)
+    rec[:, 12 + L] = ord("\n")
+    rec[:, 13 + L] = ord("+")
+    rec[:, 14 + L] = ord("\n")
+    rec[:, 15 + L:15 + 2 * L] = ord("I")
+    rec[:, 15 + 2 * L] = ord("\n")
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())
+    return rec.shape[1] * n
+
+
+def cli_e2e(index, d_seq, n_reads, bam_level):
+    """FASTQ file -> build/groot-hip align -> BAM file + GFAs: the whole process, wall clock"""
+    import __graft_entry__ as entry
+
+    exe = entry.build_cli()
+    seq_host = d_seq[: n_reads * READ_LEN].cpu().numpy()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("GROOT_BENCH_TMP")) as td:
+        idx_dir = os.path.join(td, "index")
+        os.makedirs(idx_dir)
+        index.save(os.path.join(idx_dir, "groot.gidx"))
+        fq = os.path.join(td, "reads.fq")
+        fq_bytes = write_fastq(fq, seq_host, n_reads)
+        bam = os.path.join(td, "out.bam")
+        stats = os.path.join(td, "stats.json")
+        cmd = [exe, "align", "-i", idx_dir, "-f", fq, "-g", os.path.join(td, "graphs"), "--bam", bam, "--log", os.path.join(td, "groot.log"),
+               "-p", str(os.cpu_count() or 1), "--bamLevel", str(bam_level), "--stats", stats]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": (p.stderr or p.stdout)[-400:]}
+        st = json.load(open(stats))
+        out = {"value": n_reads / wall / 1e6, "unit": "Mreads/s", "reads": n_reads, "wall_s": wall, "fastq_bytes": fq_bytes,
+               "bam_bytes": os.path.getsize(bam), "bam_level": bam_level, "stream_value": n_reads / st["stream_s"] / 1e6,
+               "phases_s": st, "what": "build/groot-hip align: plain FASTQ file -> BAM file + GFAs; value = reads / whole-process wall "
+                                       "(index load + device open included), stream_value = reads / (first read parsed -> BAM closed)"}
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of the all-cores CPU baseline run")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--no-cli", action="store_true")
+    ap.add_argument("--host-fed-steps", type=int, default=40)
+    ap.add_argument("--cli-reads", type=int, default=2_000_000)
+    ap.add_argument("--cli-bam-level", type=int, default=1)
     ap.add_argument("--no-align", action="store_true", help="diagnostic: --noAlign mode (weights only, no BAM records)")
     ap.add_argument("--background", type=float, default=0.0,
                     help="diagnostic: fraction of reads replaced by uniform random ACGT (metagenome-like input, SURVEY 8d)")
@@ -110,8 +249,11 @@ def main():
 
         entry.build_host()
         entry.build_hip()
-        if args.gpus == 1 and not args.no_cpu:
-            entry.build_oracle()
+        if args.gpus == 1:
+            if not args.no_cli:
+                entry.build_cli()
+            if not args.no_cpu:
+                entry.build_oracle()
     from groot_amd import device, synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,11 +280,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if rank == 0:
-        index = load_index()
+        index, index_path = load_index()
     if dist is not None:
         dist.barrier()
     if rank != 0:
-        index = load_index()
+        index, index_path = load_index()
 
     # ---- synthetic reads of this rank's shard, generated straight into HBM ----
     cat, off, lens = synth.reference_sequences(index)
@@ -169,13 +311,16 @@ def main():
     torch.cuda.synchronize()
 
     al = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
-                        no_align=args.no_align)
+                        no_align=args.no_align, results_on_device=True, pipeline_depth=2)
     stream = torch.cuda.current_stream(dev)
     al.set_stream(stream.cuda_stream)
     al.set_profiling(True)
-    n_q, n_w = al.attempts_shape()
-    d_att = torch.zeros(n_q * n_w, dtype=torch.int32, device=dev)
-    al.attempts_bind(d_att.data_ptr(), d_att.numel())
+    # the call-count table of this workload has ONE row (kmerCount 70): it lives in a torch tensor so that RCCL can sum it
+    # across the ranks in place -- 1.3 MB, the whole multi-GPU exchange
+    _, n_w = al.attempts_shape()
+    q_row = READ_LEN - index.view.kmer_size + 1
+    d_att = torch.zeros(n_w, dtype=torch.int32, device=dev)
+    al.attempts_layout([q_row], d_att.data_ptr())
 
     def step():
         al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), R, first_read_id=0, max_len=READ_LEN)
@@ -217,22 +362,21 @@ def main():
         pw = index.view.path_words
         seed_bytes = R * (READ_LEN + 8 + 4) + 4 * counts["seeds"]
         align_bytes = R * (READ_LEN + 8 + 4 + 4) + 4 * counts["seeds"] + (20 + 8 * pw) * counts["travs"] + 4 * counts["seeds"]
-        kernels = {"sketch_seed_kernel<21,4,false,6>": (seed_ms, seed_bytes), "align_kernel<3,true>": (align_ms, align_bytes)}
+        kernels = {"sketch_seed_kernel": (seed_ms, seed_bytes), "align_kernel": (align_ms, align_bytes)}
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic / VALU issue need PMC passes (rocprofv3 --pmc), which cannot run inside this process: they are read
+        # from the committed profile of the same command and labelled as such; null when that file is absent
         traffic, valu = None, None
-        pmc = os.path.join(REPO, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(PMC_FILE):
             try:
-                rec = json.load(open(pmc)).get(dom.split("<")[0], {})
+                rec = json.load(open(PMC_FILE)).get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
-                # the ceiling that actually binds: VALU issue = wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
                 insts = rec.get("per_launch", {}).get("SQ_INSTS_VALU")
                 if insts:
-                    issue_ms = insts * 4 / (1024 * 2.4e9) * 1e3
-                    valu = {"wave_insts_per_launch": insts, "issue_ms": issue_ms, "frac_of_kernel": issue_ms / dom_ms,
-                            "source": "profiles/r01_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU of the same command)"}
+                    valu = {"wave_insts_per_launch": insts, "wave_insts_per_read": insts / R,
+                            "source": "profiles/r02_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU of this command, not measured in this run)"}
             except Exception:
                 traffic, valu = None, None
         line = {
@@ -241,18 +385,40 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: full pipeline incl. on-GPU graph-traversal alignment, 100 bp error-free reads sampled from arg-annot.90, index k=31 s=21 w=100 x=8 y=4, t=0.99",
                        "reads_per_gpu_per_step": R, "read_len": READ_LEN, **({"background_fraction": args.background} if args.background > 0 else {}), "parallelism": f"reads sharded x{world}, index replicated",
+                       "residency": "inputs and traversal records in HBM (host_fed / cli_e2e below carry the PCIe- and host-inclusive rates)",
                        "per_step_counts": counts,
                        "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r02_pmc.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
                          "note": "integer hashing / graph walking: the binding ceiling is VALU issue, not HBM (DESIGN.md)", "valu_issue": valu,
                          "other": {k: {"kernel_ms": v[0], "bytes_per_launch": v[1], "achieved": v[1] / (v[0] * 1e-3) / 1e9}
                                    for k, v in kernels.items() if k != dom}},
         }
-        if world == 1 and not args.no_cpu:
-            line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baseline(index, args.cpu_sample)
+        if world == 1:
+            al.close()
+            al = None
+            if not args.no_host_fed:
+                try:
+                    hf, _ = host_fed(index, d_seq, R, args.host_fed_steps)
+                    hf["frac_of_resident"] = hf["value"] / value
+                    line["host_fed"] = hf
+                except Exception as e:   # the headline must still print
+                    line["host_fed"] = {"error": repr(e)}
+            if not args.no_cli:
+                try:
+                    line["cli_e2e"] = cli_e2e(index, d_seq, min(args.cli_reads, R), args.cli_bam_level)
+                except Exception as e:
+                    line["cli_e2e"] = {"error": repr(e)}
+            if not args.no_cpu:
+                try:
+                    line["cpu_baseline"] = cpu_baseline(index_path, args.cpu_seconds)
+                except Exception as e:
+                    line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    al.close()
+    if al is not None:
+        al.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -18,6 +18,7 @@ enum : uint32_t {
     kFlagTravOverflow = 8u,   // more traversal records than the output buffer holds
     kFlagOrdOverflow = 16u,   // > 65535 traversals for one read
     kFlagOvfOverflow = 32u,   // a shard of the overflow traversal list is full
+    kFlagQOverflow = 64u,     // more distinct kmerCounts among the seeded reads than the call-count table has rows
 };
 
 constexpr uint32_t kOvfShards = 256;  // overflow traversal lists, picked by workgroup id: spreads the atomics
@@ -27,7 +28,7 @@ struct DeviceCounters {
     unsigned int n_trav;        // traversal records emitted (may exceed capacity: then kFlagTravOverflow)
     unsigned int max_seeds;     // largest per-read seed count seen
     unsigned int flags;
-    unsigned int pad;
+    unsigned int q_rows;        // rows of the call-count table in use after this batch (may exceed its capacity: then kFlagQOverflow)
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };
@@ -105,6 +106,9 @@ struct DeviceIndex {
     const uint8_t *q_k, *q_l;
     const uint16_t *q_min_eq;
     uint32_t max_q;
+    // IncrementSubPath call counts are kept per (kmerCount, window) only for the kmerCounts that occur: q_row[q] = row of
+    // the call-count table holding kmerCount q, kEmpty until a seeded read with that q shows up (assign_q_rows_kernel)
+    const uint32_t *q_row;          // [max_q + 1]
 };
 
 struct SeedArgs {
@@ -120,6 +124,7 @@ struct SeedArgs {
     uint32_t *sort_key;          // [n_reads] (node span class, first seed window, orientation class), kEmpty without seeds; or null
     uint32_t sort_span_bits;     // top bits of sort_key that hold min(contained nodes of the window, 2^bits-1); 0 = none
     ReadRec *read_rec;           // [n_reads]
+    uint32_t *q_seen;            // [max_q + 1] set for every kmerCount of a seeded read that has no row yet; or null
     DeviceCounters *ctr;
 };
 
@@ -135,7 +140,7 @@ struct AlignArgs {
     const ReadRec *read_rec;     // [n_reads]
     uint32_t no_align, update_weights;
     const void *node_rec;        // NodeRec<pw>[n_nodes]
-    uint32_t *attempts;          // [(max_q+1)*n_windows]
+    uint32_t *attempts;          // [rows][n_windows], row = ix.q_row[kmerCount]
     // traversal output: traversal 0 of read r goes to slot r; later ones (ord >= 1, ~4% of them)
     // to a sharded overflow list.  order_* kernels then compact both into (read, ord) order.
     groot_trav *trav_first;      // [n_reads]

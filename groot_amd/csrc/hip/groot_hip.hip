@@ -5,15 +5,20 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <deque>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "../common/view_check.hpp"
 #include "kernels.hpp"
 
 using namespace groot;
@@ -30,6 +35,7 @@ template <class T> struct DevBuf {
         n = count;
         return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
     }
+    hipError_t reserve(size_t count) { return count <= n && p ? hipSuccess : alloc(count); }
     void release()
     {
         if (p) (void)hipFree(p);
@@ -39,15 +45,74 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// page-locked host memory: the only kind hipMemcpyAsync really overlaps with kernels
+template <class T> struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        return hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+    }
+    hipError_t reserve(size_t count) { return count <= n && p ? hipSuccess : alloc(count); }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~PinBuf() { release(); }
+};
+
+// One batch in flight.  Inputs and outputs are per slot (copy-in of batch b+1 and copy-out of batch b-1 overlap the
+// kernels of batch b); everything the kernels only use between themselves is shared by all slots (one compute stream).
+struct Slot {
+    enum State { FREE, ACQUIRED, IN_FLIGHT, D2H_ISSUED, COLLECTED };
+    State state = FREE;
+    uint64_t ticket = 0;
+    uint32_t n_reads = 0, first_read_id = 0, max_len = 0;
+    uint64_t n_bases = 0, n_exc = 0;
+    enum Input { IN_ASCII, IN_PACKED, IN_PACKED16, IN_DEVICE } input = IN_ASCII;
+    const uint8_t *ext_seq = nullptr;      // IN_DEVICE
+    const uint64_t *ext_off = nullptr;
+    // pinned staging (inputs)
+    PinBuf<uint8_t> h_bases;               // ASCII or packed bases
+    PinBuf<uint16_t> h_len;
+    PinBuf<uint64_t> h_off, h_exc_pos;
+    PinBuf<uint8_t> h_exc_byte;
+    // HBM inputs
+    DevBuf<uint32_t> d_packed;
+    DevBuf<uint16_t> d_len;
+    DevBuf<uint8_t> d_seq, d_exc_byte;
+    DevBuf<uint64_t> d_off, d_exc_pos;
+    // outputs
+    uint32_t trav_cap = 0;
+    DevBuf<groot_trav> d_trav;
+    DevBuf<uint64_t> d_mask;
+    DevBuf<DeviceCounters> d_ctr;
+    PinBuf<DeviceCounters> h_ctr;
+    PinBuf<groot_trav> h_trav;
+    PinBuf<uint64_t> h_mask;
+    uint32_t n_trav = 0;
+    bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
+    hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
+    hipEvent_t ev[7]{};                    // stage boundaries on the compute stream (profiling)
+    groot_counts counts{};
+    int status = GROOT_OK;
+    std::string status_msg;
+    groot_stage_ms ms{};
+    const uint8_t *seq() const { return input == IN_DEVICE ? ext_seq : d_seq.p; }
+    const uint64_t *off() const { return input == IN_DEVICE ? ext_off : d_off.p; }
+};
+
 struct groot_ctx {
     int device = 0;
     std::string err;
     groot_params prm{};
     uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev[6]{};
+    hipStream_t own_stream = nullptr, stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
     bool profiling = false;
-    groot_stage_ms ms{};
 
     // index in HBM
     DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
@@ -63,35 +128,33 @@ struct groot_ctx {
     DevBuf<ExactEntry> exact;
     DeviceIndex dix{};
 
-    // batch state
-    DevBuf<uint8_t> seq, exc_byte;
-    DevBuf<uint32_t> packed;
-    DevBuf<uint64_t> exc_pos;
-    DevBuf<uint64_t> seq_off;
-    const uint8_t *cur_seq = nullptr;
-    const uint64_t *cur_off = nullptr;
-    uint32_t n_reads = 0, first_read_id = 0, batch_max_len = 0;
-    bool submitted = false, finished = false;
+    // pipeline
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::deque<Slot *> inflight;           // submission order: IN_FLIGHT / D2H_ISSUED
+    uint64_t next_ticket = 1;
+    Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
+    Slot *work_owner = nullptr;            // whose seeds / sketches the shared work buffers hold
+    uint64_t work_ticket = 0;
+
+    // shared work buffers (compute stream only)
     uint32_t seed_slots = 0;
     DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm;
     DevBuf<char> sort_tmp;
     DevBuf<ReadRec> read_rec, read_rec_sorted;
     DevBuf<uint64_t> sketches;
-    DevBuf<DeviceCounters> ctr;
-    DeviceCounters hctr{};
-    // traversal output
-    uint32_t trav_cap = 0, ovf_cap = 0;
-    DevBuf<groot_trav> trav_first, ovf_trav, trav_sorted;
-    DevBuf<uint64_t> mask_first, ovf_mask, trav_mask_sorted;
+    uint32_t ovf_cap = 0;
+    DevBuf<groot_trav> trav_first, ovf_trav;
+    DevBuf<uint64_t> mask_first, ovf_mask;
     DevBuf<uint32_t> trav_cnt, trav_off, ovf_cnt;
     DevBuf<char> scan_tmp;
-    uint32_t n_trav = 0;
     // DFS stacks
     uint32_t align_threads = 0, stk_depth = 0;
     DevBuf<uint64_t> stk_hdr, stk_mask;
-    // weights
-    DevBuf<uint32_t> attempts;
-    uint32_t *attempts_ptr = nullptr;   // own buffer or a caller-bound one
+    // IncrementSubPath call counts: [rows][n_windows], one row per kmerCount that occurred
+    DevBuf<uint32_t> attempts, q_row, q_seen, q_of_row, q_nrows;
+    uint32_t *attempts_ptr = nullptr;      // own buffer or the caller's (groot_hip_attempts_layout)
+    uint32_t att_cap = 0;                  // rows the table can hold
+    bool att_external = false;
 };
 
 static thread_local std::string g_open_err;
@@ -404,11 +467,11 @@ static int alloc_seed_slots(groot_ctx *c, uint32_t slots)
     return GROOT_OK;
 }
 
-static int alloc_trav(groot_ctx *c, uint32_t cap)
+static int alloc_trav(groot_ctx *c, Slot *s, uint32_t cap)
 {
-    c->trav_cap = cap;
-    HIP_TRY(c, c->trav_sorted.alloc(cap));
-    HIP_TRY(c, c->trav_mask_sorted.alloc((size_t)cap * c->pw_view));
+    s->trav_cap = cap;
+    HIP_TRY(c, s->d_trav.alloc(cap));
+    HIP_TRY(c, s->d_mask.alloc((size_t)cap * c->pw_view));
     return GROOT_OK;
 }
 
@@ -420,18 +483,34 @@ static int alloc_ovf(groot_ctx *c, uint32_t cap_per_shard)
     return GROOT_OK;
 }
 
+// call-count table with room for `rows` kmerCounts; existing rows are kept (device-to-device copy)
+static int grow_attempts(groot_ctx *c, uint32_t rows)
+{
+    if (c->att_external) return fail(c, GROOT_E_NOSPACE, "a kmerCount outside the fixed layout of groot_hip_attempts_layout occurred");
+    DevBuf<uint32_t> bigger;
+    HIP_TRY(c, bigger.alloc((size_t)rows * c->n_windows));
+    HIP_TRY(c, hipMemset(bigger.p, 0, (size_t)rows * c->n_windows * sizeof(uint32_t)));
+    if (c->attempts.p && c->att_cap)
+        HIP_TRY(c, hipMemcpy(bigger.p, c->attempts.p, (size_t)std::min(rows, c->att_cap) * c->n_windows * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    std::swap(c->attempts.p, bigger.p);
+    std::swap(c->attempts.n, bigger.n);
+    c->attempts_ptr = c->attempts.p;
+    c->att_cap = rows;
+    return GROOT_OK;
+}
+
 #ifndef GROOT_SPAN_BITS
 #define GROOT_SPAN_BITS 6
 #endif
-static int launch_seed_stage(groot_ctx *c)
+static int launch_seed_stage(groot_ctx *c, Slot *s)
 {
     SeedArgs a{};
     a.ix = c->dix;
-    a.seq = c->cur_seq;
-    a.seq_off = c->cur_off;
-    a.n_reads = c->n_reads;
+    a.seq = s->seq();
+    a.seq_off = s->off();
+    a.n_reads = s->n_reads;
     a.max_read_len = c->prm.max_read_len;
-    const uint64_t want = (uint64_t)kBlock * c->batch_max_len + 32;
+    const uint64_t want = (uint64_t)kBlock * s->max_len + 32;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>(want, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots;
     a.seed_count = c->seed_count.p;
@@ -439,7 +518,8 @@ static int launch_seed_stage(groot_ctx *c)
     a.sketch_out = c->prm.keep_sketches ? c->sketches.p : nullptr;
     a.sort_key = c->sort_key.p;
     a.read_rec = c->read_rec.p;
-    a.ctr = c->ctr.p;
+    a.q_seen = c->q_seen.p;
+    a.ctr = s->d_ctr.p;
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
     // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
     unsigned win_bits = 3;                                  // 2 class bits + one bit above the largest window id
@@ -447,32 +527,37 @@ static int launch_seed_stage(groot_ctx *c)
     win_bits = std::min(32u, win_bits);
     a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
-    const dim3 grid((c->n_reads + kBlock - 1) / kBlock);
+    const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
     launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
+    hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(1), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
+                       c->max_q, s->d_ctr.p);
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p, c->n_reads, 0,
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p, s->n_reads, 0,
                                          end_bit, c->stream));
-    if (tmp_bytes > c->sort_tmp.n) HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes));
+    if (tmp_bytes > c->sort_tmp.n) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes + tmp_bytes / 4));
+    }
     HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p,
-                                         c->n_reads, 0, end_bit, c->stream));
-    hipLaunchKernelGGL(gather_recs_kernel, grid, dim3(kBlock), 0, c->stream, c->perm.p, c->read_rec.p, c->read_rec_sorted.p, c->n_reads);
+                                         s->n_reads, 0, end_bit, c->stream));
+    hipLaunchKernelGGL(gather_recs_kernel, grid, dim3(kBlock), 0, c->stream, c->perm.p, c->read_rec.p, c->read_rec_sorted.p, s->n_reads);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
 
-static int launch_align_stage(groot_ctx *c, bool update_weights)
+static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     AlignArgs a{};
     a.ix = c->dix;
-    a.seq = c->cur_seq;
-    a.seq_off = c->cur_off;
-    a.n_reads = c->n_reads;
-    a.first_read_id = c->first_read_id;
+    a.seq = s->seq();
+    a.seq_off = s->off();
+    a.n_reads = s->n_reads;
+    a.first_read_id = s->first_read_id;
     a.seed_slots = c->seed_slots;
     a.seed_count = c->seed_count.p;
     a.seed_win = c->seed_win.p;
@@ -491,51 +576,343 @@ static int launch_align_stage(groot_ctx *c, bool update_weights)
     a.ovf_cap = c->ovf_cap;
     a.stk_hdr = c->stk_hdr.p;
     a.stk_mask = c->stk_mask.p;
-    const uint32_t blocks = std::min<uint32_t>((c->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
+    const uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
-    // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB (<= 2 workgroups... per CU budget)
+    // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB
     {
         // 8 zero bytes, then the read in whole 16-byte pieces up to 12 bytes past its end; odd dword stride = no bank conflicts
-        const uint32_t stride = (2 + 4 * ((c->batch_max_len + 27) / 16)) | 1u;
+        const uint32_t stride = (2 + 4 * ((s->max_len + 27) / 16)) | 1u;
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
-    a.ctr = c->ctr.p;
+    a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
     launch_align(c->pw, a, dim3(blocks), c->stream);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
 
-// traversal records -> (read, ord) order: exclusive scan of the per-read counts, then two scatters
-static int launch_order_stage(groot_ctx *c)
+// traversal records -> (read, ord) order: exclusive scan of the per-read counts, then two scatters into the slot's output
+static int launch_order_stage(groot_ctx *c, Slot *s)
 {
-    const uint32_t n = c->n_reads;
+    const uint32_t n = s->n_reads;
     size_t tmp_bytes = 0;
     HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
-    if (tmp_bytes > c->scan_tmp.n) HIP_TRY(c, c->scan_tmp.alloc(tmp_bytes));
+    if (tmp_bytes > c->scan_tmp.n) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, c->scan_tmp.alloc(tmp_bytes + tmp_bytes / 4));
+    }
     HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, c->ctr.p);
+    hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, s->d_ctr.p);
     hipLaunchKernelGGL(order_first_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav_first.p,
-                       c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, c->trav_sorted.p, c->trav_mask_sorted.p, c->trav_cap, c->pw,
-                       c->pw_view, c->ctr.p);
+                       c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw,
+                       c->pw_view, s->d_ctr.p);
     hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->stream,
-                       c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, c->first_read_id, c->trav_sorted.p,
-                       c->trav_mask_sorted.p, c->trav_cap, c->pw, c->pw_view, c->ctr.p);
+                       c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, s->first_read_id, s->d_trav.p,
+                       s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
 
-static int run_batch_async(groot_ctx *c)
+// sketch+seed -> schedule -> align -> order for the batch of slot s, on the compute stream
+static int run_batch_async(groot_ctx *c, Slot *s, bool update_weights)
 {
-    HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    if (int rc = launch_seed_stage(c)) return rc;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-    if (int rc = launch_align_stage(c, true)) return rc;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
-    if (int rc = launch_order_stage(c)) return rc;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(c, hipMemsetAsync(s->d_ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[1], c->stream));
+    if (int rc = launch_seed_stage(c, s)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[3], c->stream));
+    if (int rc = launch_align_stage(c, s, update_weights)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[4], c->stream));
+    if (int rc = launch_order_stage(c, s)) return rc;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[5], c->stream));
+    c->work_owner = s;
+    c->work_ticket = s->ticket;
+    return GROOT_OK;
+}
+
+// lengths on the wire -> u64 offsets in HBM
+struct LenToU64 {
+    __host__ __device__ uint64_t operator()(uint16_t v) const { return (uint64_t)v; }
+};
+
+static void par_copy(void *dst, const void *src, size_t bytes)
+{
+    const size_t kMin = 8u << 20;
+    unsigned nt = (unsigned)std::min<size_t>(8, bytes / kMin);
+    if (nt <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t lo = std::min(bytes, t * per), hi = std::min(bytes, lo + per);
+        if (lo < hi) th.emplace_back([=]() { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// input staging + output buffers of a slot, sized once for the ctx's batch capacity
+static int ensure_slot(groot_ctx *c, Slot *s, Slot::Input in, uint64_t n_exc)
+{
+    const uint32_t R = c->prm.max_batch_reads;
+    const uint64_t B = c->prm.max_batch_bases;
+    if (!s->d_ctr.p) {
+        HIP_TRY(c, s->d_ctr.alloc(1));
+        HIP_TRY(c, s->h_ctr.alloc(1));
+        if (int rc = alloc_trav(c, s, std::max<uint32_t>(1024, R + R / 4))) return rc;
+    }
+    if (in == Slot::IN_DEVICE) return GROOT_OK;
+    HIP_TRY(c, s->d_seq.reserve(B + 64));
+    HIP_TRY(c, s->d_off.reserve((size_t)R + 1));
+    if (in == Slot::IN_ASCII) {
+        HIP_TRY(c, s->h_bases.reserve(B + 64));
+        HIP_TRY(c, s->h_off.reserve((size_t)R + 1));
+        return GROOT_OK;
+    }
+    HIP_TRY(c, s->h_bases.reserve((B + 3) / 4 + 64));
+    HIP_TRY(c, s->d_packed.reserve((B + 15) / 16 + 1));
+    if (in == Slot::IN_PACKED) HIP_TRY(c, s->h_off.reserve((size_t)R + 1));
+    else {
+        HIP_TRY(c, s->h_len.reserve(R));
+        HIP_TRY(c, s->d_len.reserve(R));
+    }
+    const uint64_t exc_cap = std::max<uint64_t>(n_exc + n_exc / 4, std::max<uint64_t>(4096, B / 256));
+    if (s->h_exc_pos.n < std::max<uint64_t>(n_exc, 1)) {
+        HIP_TRY(c, s->h_exc_pos.alloc(exc_cap)); HIP_TRY(c, s->h_exc_byte.alloc(exc_cap));
+        HIP_TRY(c, s->d_exc_pos.alloc(exc_cap)); HIP_TRY(c, s->d_exc_byte.alloc(exc_cap));
+    }
+    return GROOT_OK;
+}
+
+static void release_slot(groot_ctx *c, Slot *s)
+{
+    s->state = Slot::FREE;
+    s->host_results = false;
+    if (c->waited == s) c->waited = nullptr;
+}
+
+static Slot *free_slot(groot_ctx *c)
+{
+    if (c->waited) release_slot(c, c->waited);      // one-batch-at-a-time callers never release explicitly
+    for (auto &s : c->slots)
+        if (s->state == Slot::FREE) return s.get();
+    return nullptr;
+}
+
+// copy-in, decode, kernels, counter copy-out of slot s: everything asynchronous
+static int enqueue(groot_ctx *c, Slot *s)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    s->status = GROOT_OK; s->status_msg.clear();
+    s->n_trav = 0; s->host_results = false;
+    memset(&s->counts, 0, sizeof s->counts);
+    memset(&s->ms, 0, sizeof s->ms);
+    s->ticket = c->next_ticket++;
+    if (s->n_reads == 0) {      // nothing to run: completes at once
+        memset(s->h_ctr.p, 0, sizeof(DeviceCounters));
+        HIP_TRY(c, hipEventRecord(s->ev_ctr, c->d2h_stream));
+        s->state = Slot::IN_FLIGHT;
+        c->inflight.push_back(s);
+        return GROOT_OK;
+    }
+    if (s->input != Slot::IN_DEVICE) {
+        hipStream_t h = c->h2d_stream;
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_h2d0, h));
+        if (s->input == Slot::IN_ASCII) {
+            HIP_TRY(c, hipMemcpyAsync(s->d_seq.p, s->h_bases.p, s->n_bases, hipMemcpyHostToDevice, h));
+            HIP_TRY(c, hipMemcpyAsync(s->d_off.p, s->h_off.p, ((size_t)s->n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h));
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(s->d_packed.p, s->h_bases.p, (size_t)((s->n_bases + 3) / 4), hipMemcpyHostToDevice, h));
+            if (s->input == Slot::IN_PACKED)
+                HIP_TRY(c, hipMemcpyAsync(s->d_off.p, s->h_off.p, ((size_t)s->n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h));
+            else
+                HIP_TRY(c, hipMemcpyAsync(s->d_len.p, s->h_len.p, (size_t)s->n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, h));
+            if (s->n_exc) {
+                HIP_TRY(c, hipMemcpyAsync(s->d_exc_pos.p, s->h_exc_pos.p, s->n_exc * sizeof(uint64_t), hipMemcpyHostToDevice, h));
+                HIP_TRY(c, hipMemcpyAsync(s->d_exc_byte.p, s->h_exc_byte.p, s->n_exc, hipMemcpyHostToDevice, h));
+            }
+        }
+        HIP_TRY(c, hipEventRecord(s->ev_h2d, h));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, s->ev_h2d, 0));
+    }
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[0], c->stream));
+    if (s->input == Slot::IN_PACKED || s->input == Slot::IN_PACKED16) {
+        const uint64_t n_words = (s->n_bases + 15) / 16;                  // 16 bases per packed word
+        if (n_words)
+            hipLaunchKernelGGL(unpack_reads_kernel, dim3((unsigned)((n_words + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, s->d_packed.p,
+                               n_words, reinterpret_cast<uint4 *>(s->d_seq.p));
+        if (s->n_exc)
+            hipLaunchKernelGGL(patch_reads_kernel, dim3((unsigned)((s->n_exc + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                               s->d_exc_pos.p, s->d_exc_byte.p, s->n_exc, s->d_seq.p);
+        HIP_TRY(c, hipGetLastError());
+        if (s->input == Slot::IN_PACKED16) {
+            HIP_TRY(c, hipMemsetAsync(s->d_off.p, 0, sizeof(uint64_t), c->stream));
+            auto in = rocprim::make_transform_iterator(s->d_len.p, LenToU64());
+            size_t tmp_bytes = 0;
+            HIP_TRY(c, rocprim::inclusive_scan(nullptr, tmp_bytes, in, s->d_off.p + 1, s->n_reads, rocprim::plus<uint64_t>(), c->stream));
+            if (tmp_bytes > c->scan_tmp.n) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, c->scan_tmp.alloc(tmp_bytes + tmp_bytes / 4));
+            }
+            HIP_TRY(c, rocprim::inclusive_scan(c->scan_tmp.p, tmp_bytes, in, s->d_off.p + 1, s->n_reads, rocprim::plus<uint64_t>(), c->stream));
+        }
+    }
+    if (int rc = run_batch_async(c, s, true)) return rc;
+    HIP_TRY(c, hipEventRecord(s->ev_compute, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->d2h_stream, s->ev_compute, 0));
+    HIP_TRY(c, hipMemcpyAsync(s->h_ctr.p, s->d_ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(c, hipEventRecord(s->ev_ctr, c->d2h_stream));
+    s->state = Slot::IN_FLIGHT;
+    c->inflight.push_back(s);
+    return GROOT_OK;
+}
+
+// The counters of slot s have arrived: grow-and-redo on overflow, then start the copy-out of its traversal records.
+static int finish_counters(groot_ctx *c, Slot *s)
+{
+    DeviceCounters &h = *s->h_ctr.p;
+    auto refetch = [&](DeviceCounters &dst) -> int {
+        HIP_TRY(c, hipMemcpyAsync(s->h_ctr.p, s->d_ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dst = *s->h_ctr.p;
+        return GROOT_OK;
+    };
+    DeviceCounters first = h;
+    bool have_first = false;              // weights + read counters already taken from an earlier pass
+    for (int attempt = 0; s->n_reads; attempt++) {
+        const uint32_t fl = h.flags;
+        if (!(fl & (kFlagSeedOverflow | kFlagQOverflow | kFlagOvfOverflow | kFlagTravOverflow))) break;
+        if (attempt > 8) return fail(c, GROOT_E_NOSPACE, "output buffers keep overflowing (flags=0x%x)", fl);
+        // Later batches may already have run through the shared work buffers: let them finish, grow, and redo this
+        // batch as a whole.  A pass whose align stage did nothing (seed slots / table rows ran out) is simply repeated;
+        // after any other overflow the weights and read counters of the first pass stand and only records are re-made.
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        bool redo_weights = !have_first;
+        if (fl & (kFlagSeedOverflow | kFlagQOverflow)) {
+            if (fl & kFlagSeedOverflow) { if (int rc = alloc_seed_slots(c, h.max_seeds + 4)) return rc; }
+            if (fl & kFlagQOverflow) {
+                if (c->att_external) {
+                    s->status = GROOT_E_NOSPACE;
+                    s->status_msg = "a kmerCount outside the fixed layout of groot_hip_attempts_layout occurred";
+                    h.n_trav = 0;
+                    break;
+                }
+                if (int rc = grow_attempts(c, std::max(h.q_rows, c->att_cap * 2))) return rc;
+            }
+        } else {
+            if (!have_first) { first = h; have_first = true; }
+            redo_weights = false;
+            if (fl & kFlagOvfOverflow) { if (int rc = alloc_ovf(c, c->ovf_cap * 4)) return rc; }
+            if (fl & kFlagTravOverflow) { if (int rc = alloc_trav(c, s, h.n_trav + h.n_trav / 8 + 1024)) return rc; }
+        }
+        if (int rc = run_batch_async(c, s, redo_weights)) return rc;
+        DeviceCounters again{};
+        if (int rc = refetch(again)) return rc;
+        if (have_first) {
+            const uint32_t keep = first.flags & ~(kFlagOvfOverflow | kFlagTravOverflow | kFlagSeedOverflow | kFlagQOverflow);
+            DeviceCounters merged = first;
+            merged.n_trav = again.n_trav; merged.alignments = again.alignments; merged.seeds = again.seeds; merged.max_seeds = again.max_seeds;
+            merged.flags = keep | again.flags;
+            merged.q_rows = again.q_rows;
+            h = merged;
+        } else h = again;
+    }
+    s->n_trav = s->n_reads ? h.n_trav : 0;
+    groot_counts &o = s->counts;
+    o.received = s->n_reads;              // boss.go:194 receivedReads++ for every read
+    o.mapped = h.mapped; o.multimapped = h.multimapped; o.alignments = h.alignments; o.seeds = h.seeds;
+    o.travs = s->n_trav; o.revcomp_panics = h.revcomp_panics; o.short_reads = h.short_reads;
+    if (s->status == GROOT_OK) {
+        char buf[256];
+        if (h.flags & kFlagLongRead) { s->status = GROOT_E_NOSPACE; snprintf(buf, sizeof buf, "a read is longer than max_read_len=%u", c->prm.max_read_len); s->status_msg = buf; }
+        else if (h.flags & kFlagOrdOverflow) { s->status = GROOT_E_NOSPACE; s->status_msg = "a read produced more than 65535 traversals"; }
+        else if (h.flags & kFlagShortRead) {
+            s->status = GROOT_E_SHORT_READ;
+            snprintf(buf, sizeof buf, "k size is greater than sequence length for %llu read(s) (the reference panics: boss.go:164-166)", h.short_reads);
+            s->status_msg = buf;
+        } else if (h.revcomp_panics) {
+            s->status = GROOT_E_REVCOMP;
+            snprintf(buf, sizeof buf, "%llu read(s) hold a byte > 'T' and reached RevComplement (the reference panics: seqio.go:126)", h.revcomp_panics);
+            s->status_msg = buf;
+        }
+    }
+#ifdef GROOT_WORK_COUNTERS
+    for (int e = 0; e < 32; e++)
+        if (h.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, h.dbg[e], h.dbg[32 + e]);
+    fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", h.dbg[63]);
+    for (int ph = 0; ph < 3; ph++)
+        fprintf(stderr, "[groot work] phase %d: %llu steps, %.2f us per step (wall clock, per wave)\n", ph, h.dbg[27 + ph],
+                h.dbg[27 + ph] ? (double)h.dbg[24 + ph] / 100.0 / (double)h.dbg[27 + ph] : 0.0);
+    for (int hh = 0; hh < 2; hh++) {
+        fprintf(stderr, "[groot work] %s (buckets of 2 iterations):", hh ? "round length" : "lane finish");
+        for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", h.dbg[64 + 64 * hh + b]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    // copy-out of the records (exact size now known), overlapping whatever the compute stream does next
+    if (!c->prm.results_on_device && s->n_trav) {
+        HIP_TRY(c, s->h_trav.reserve(s->trav_cap));
+        HIP_TRY(c, s->h_mask.reserve((size_t)s->trav_cap * c->pw_view));
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h0, c->d2h_stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->n_trav * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_mask.p, (size_t)s->n_trav * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
+        s->host_results = true;
+    }
+    HIP_TRY(c, hipEventRecord(s->ev_d2h, c->d2h_stream));
+    s->state = Slot::D2H_ISSUED;
+    return GROOT_OK;
+}
+
+// Move batches whose counters have arrived on to their copy-out, in submission order: blocking up to and including
+// `must`, opportunistically (event query) beyond it or when must is null.
+static int progress(groot_ctx *c, Slot *must = nullptr)
+{
+    bool blocking = must != nullptr;
+    for (Slot *s : c->inflight) {
+        if (s->state == Slot::IN_FLIGHT) {
+            if (blocking) HIP_TRY(c, hipEventSynchronize(s->ev_ctr));
+            else {
+                const hipError_t q = hipEventQuery(s->ev_ctr);
+                if (q == hipErrorNotReady) break;
+                if (q != hipSuccess) return fail(c, GROOT_E_DEVICE, "hipEventQuery: %s", hipGetErrorString(q));
+            }
+            if (int rc = finish_counters(c, s)) return rc;
+        }
+        if (s == must) blocking = false;
+    }
+    return GROOT_OK;
+}
+
+static int collect_impl(groot_ctx *c, Slot **out)
+{
+    if (c->inflight.empty()) return fail(c, GROOT_E_STATE, "no batch submitted");
+    HIP_TRY(c, hipSetDevice(c->device));
+    Slot *s = c->inflight.front();
+    if (s->state == Slot::IN_FLIGHT) {
+        if (int rc = progress(c, s)) return rc;
+    }
+    HIP_TRY(c, hipEventSynchronize(s->ev_d2h));
+    if (c->profiling && s->n_reads) {
+        if (s->input != Slot::IN_DEVICE) (void)hipEventElapsedTime(&s->ms.h2d, s->ev_h2d0, s->ev_h2d);
+        (void)hipEventElapsedTime(&s->ms.unpack, s->ev[0], s->ev[1]);
+        (void)hipEventElapsedTime(&s->ms.sketch_seed, s->ev[1], s->ev[2]);
+        (void)hipEventElapsedTime(&s->ms.schedule, s->ev[2], s->ev[3]);
+        (void)hipEventElapsedTime(&s->ms.align, s->ev[3], s->ev[4]);
+        (void)hipEventElapsedTime(&s->ms.sort, s->ev[4], s->ev[5]);
+        (void)hipEventElapsedTime(&s->ms.total, s->ev[0], s->ev[5]);
+        if (s->host_results) (void)hipEventElapsedTime(&s->ms.d2h, s->ev_d2h0, s->ev_d2h);
+    }
+    c->inflight.pop_front();
+    s->state = Slot::COLLECTED;
+    *out = s;
+    (void)progress(c);       // keep the copy-outs of the batches behind it going
+    return GROOT_OK;
+}
+
+static int drain(groot_ctx *c)     // everything submitted has finished on the device (results stay collectable)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->inflight.empty()) { if (int rc = progress(c, c->inflight.back())) return rc; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->d2h_stream));
     return GROOT_OK;
 }
 
@@ -552,6 +929,7 @@ void groot_params_default(groot_params *p)
     p->max_read_len = 256;
     p->max_batch_reads = 1u << 20;
     p->max_seeds_per_read = 8;
+    p->pipeline_depth = 3;
 }
 
 int groot_hip_device_count(int *n)
@@ -574,9 +952,18 @@ void groot_hip_close(groot_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto &e : ctx->ev)
-        if (e) (void)hipEventDestroy(e);
+    if (ctx->h2d_stream) (void)hipStreamSynchronize(ctx->h2d_stream);
+    if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
+    for (auto &s : ctx->slots) {
+        for (hipEvent_t e : {s->ev_h2d0, s->ev_h2d, s->ev_compute, s->ev_ctr, s->ev_d2h0, s->ev_d2h})
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : s->ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    ctx->slots.clear();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     delete ctx;
 }
 
@@ -596,9 +983,15 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     if (!c->prm.max_batch_reads) c->prm.max_batch_reads = d.max_batch_reads;
     if (!c->prm.max_seeds_per_read) c->prm.max_seeds_per_read = d.max_seeds_per_read;
     if (!c->prm.max_batch_bases) c->prm.max_batch_bases = (uint64_t)c->prm.max_batch_reads * c->prm.max_read_len;
+    if (!c->prm.pipeline_depth) c->prm.pipeline_depth = d.pipeline_depth;
+    if (c->prm.pipeline_depth > 16) return fail(c, GROOT_E_INVALID, "pipeline_depth must be <= 16");
     if (c->prm.max_read_len > 65535) return fail(c, GROOT_E_UNSUPPORTED, "max_read_len must be <= 65535");
     if (v->kmer_size == 0 || v->kmer_size > 64) return fail(c, GROOT_E_UNSUPPORTED, "k-mer size %u not in [1,64]", v->kmer_size);
     if (c->prm.max_read_len < v->kmer_size) return fail(c, GROOT_E_INVALID, "max_read_len smaller than the k-mer size");
+    {   // never upload a view whose indices do not resolve (truncated / corrupt index, wrong file)
+        const std::string why = check_index_view(v);
+        if (!why.empty()) return fail(c, GROOT_E_FORMAT, "inconsistent index view: %s", why.c_str());
+    }
     if (!seed_supported(v->sketch_size, v->max_k))
         return fail(c, GROOT_E_UNSUPPORTED, "sketch size %u with maxK %u has no compiled kernel (see launch_seed)", v->sketch_size, v->max_k);
     c->s = v->sketch_size; c->k = v->kmer_size; c->max_k = v->max_k; c->l_max = v->sketch_size / v->max_k;
@@ -608,8 +1001,15 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->max_q = c->prm.max_read_len - c->k + 1;
 
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+    for (uint32_t i = 0; i < c->prm.pipeline_depth; i++) {
+        std::unique_ptr<Slot> s(new Slot());
+        for (hipEvent_t *e : {&s->ev_h2d0, &s->ev_h2d, &s->ev_compute, &s->ev_ctr, &s->ev_d2h0, &s->ev_d2h}) HIP_TRY(c, hipEventCreate(e));
+        for (auto &e : s->ev) HIP_TRY(c, hipEventCreate(&e));
+        c->slots.push_back(std::move(s));
+    }
 
     // ---- graphs + windows -> HBM ----
     HIP_TRY(c, upload(c->edges, v->edges, v->n_edges));
@@ -740,6 +1140,16 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->q_l, ql.data(), ql.size()));
         HIP_TRY(c, upload(c->q_min_eq, qm.data(), qm.size()));
     }
+    {   // call-count table: rows appear as kmerCounts do
+        std::vector<uint32_t> none(c->max_q + 2, kEmpty);
+        HIP_TRY(c, upload(c->q_row, none.data(), none.size()));
+        HIP_TRY(c, c->q_seen.alloc(c->max_q + 2));
+        HIP_TRY(c, hipMemset(c->q_seen.p, 0, (size_t)(c->max_q + 2) * 4));
+        HIP_TRY(c, c->q_of_row.alloc(c->max_q + 2));
+        HIP_TRY(c, c->q_nrows.alloc(1));
+        HIP_TRY(c, hipMemset(c->q_nrows.p, 0, 4));
+        if (int rc = grow_attempts(c, std::min<uint32_t>(4, c->max_q + 1))) return rc;
+    }
     DeviceIndex &x = c->dix;
     x.k = v->kmer_size; x.s = s; x.w = v->window_size; x.num_window_kmers = v->num_window_kmers;
     x.n_windows = n; x.n_nodes = v->n_nodes; x.pw = c->pw;
@@ -748,11 +1158,10 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     x.win_sketch = c->win_sketch.p; x.exact = c->exact.p; x.band_keys = c->band_keys.p; x.band_ids = c->band_ids.p;
     x.band_hash = c->band_hash.p; x.band_hash_bits = c->band_hash_bits; x.band_sig = c->band_sig.p; x.band_run = c->band_run.p;
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
+    x.q_row = c->q_row.p;
 
-    // ---- batch buffers ----
+    // ---- shared work buffers (inputs / outputs are per pipeline slot, allocated at their first use) ----
     const uint32_t R = c->prm.max_batch_reads;
-    HIP_TRY(c, c->seq.alloc(c->prm.max_batch_bases + 64));
-    HIP_TRY(c, c->seq_off.alloc((size_t)R + 1));
     HIP_TRY(c, c->seed_count.alloc(R));
     HIP_TRY(c, c->sort_key.alloc(R));
     HIP_TRY(c, c->read_rec.alloc(R));
@@ -766,13 +1175,11 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     }
     if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
     if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
-    HIP_TRY(c, c->ctr.alloc(1));
     HIP_TRY(c, c->trav_first.alloc(R));
     HIP_TRY(c, c->mask_first.alloc((size_t)R * c->pw));
     HIP_TRY(c, c->trav_cnt.alloc(R));
     HIP_TRY(c, c->trav_off.alloc(R));
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
-    if (int rc = alloc_trav(c, std::max<uint32_t>(1024, R + R / 4))) return rc;
     if (int rc = alloc_ovf(c, std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)
     int n_cu = 256;
@@ -783,9 +1190,6 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
     HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
-    HIP_TRY(c, c->attempts.alloc((size_t)(c->max_q + 1) * n));
-    HIP_TRY(c, hipMemset(c->attempts.p, 0, (size_t)(c->max_q + 1) * n * sizeof(uint32_t)));
-    c->attempts_ptr = c->attempts.p;
     HIP_TRY(c, hipDeviceSynchronize());
     return GROOT_OK;
 }
@@ -805,10 +1209,15 @@ int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, 
     return GROOT_OK;
 }
 
+static bool idle(const groot_ctx *c)
+{
+    return c->inflight.empty();
+}
+
 int groot_hip_set_stream(groot_ctx *c, void *hip_stream)
 {
     if (!c) return GROOT_E_INVALID;
-    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "cannot change stream while a batch is in flight");
+    if (!idle(c)) return fail(c, GROOT_E_STATE, "cannot change stream while a batch is in flight");
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return GROOT_OK;
 }
@@ -820,21 +1229,22 @@ int groot_hip_set_profiling(groot_ctx *c, int enable)
     return GROOT_OK;
 }
 
-static int begin_batch(groot_ctx *c, uint32_t n_reads, uint32_t first_read_id)
+// ---- submit ---------------------------------------------------------------------------------------------------------
+static int take_slot(groot_ctx *c, uint32_t n_reads, Slot **out)
 {
-    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "previous batch not collected: call groot_hip_wait first");
     if (n_reads > c->prm.max_batch_reads) return fail(c, GROOT_E_NOSPACE, "batch of %u reads exceeds max_batch_reads=%u", n_reads, c->prm.max_batch_reads);
     HIP_TRY(c, hipSetDevice(c->device));
-    c->n_reads = n_reads; c->first_read_id = first_read_id;
-    c->submitted = true; c->finished = false; c->n_trav = 0;
-    memset(&c->hctr, 0, sizeof c->hctr);
-    memset(&c->ms, 0, sizeof c->ms);
+    if (int rc = progress(c)) return rc;
+    Slot *s = free_slot(c);
+    if (!s) return fail(c, GROOT_E_STATE, "pipeline full: %u batches submitted and not released (groot_hip_collect + groot_hip_release first)", c->prm.pipeline_depth);
+    *out = s;
     return GROOT_OK;
 }
 
-// offsets must not decrease; *max_len = the longest read (branch-free pass so that it vectorises: 10 M reads per batch)
+// offsets must start at 0 and not decrease; *max_len = the longest read (branch-free pass so that it vectorises: 10 M reads per batch)
 static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads, uint32_t *max_len)
 {
+    if (seq_off[0] != 0) return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0");
     uint64_t longest = 0, bad = 0;
     for (uint32_t i = 0; i < n_reads; i++) {
         bad |= (uint64_t)(seq_off[i + 1] < seq_off[i]);
@@ -843,10 +1253,30 @@ static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads
     if (bad) {
         uint32_t i = 0;
         while (seq_off[i + 1] >= seq_off[i]) i++;
-        c->submitted = false;
         return fail(c, GROOT_E_INVALID, "seq_off not monotone at read %u", i);
     }
+    if (seq_off[n_reads] > c->prm.max_batch_bases)
+        return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)seq_off[n_reads], (unsigned long long)c->prm.max_batch_bases);
     *max_len = (uint32_t)std::min<uint64_t>(longest, 0xFFFFFFFFu);
+    return GROOT_OK;
+}
+
+static int check_lengths(groot_ctx *c, const uint16_t *len, uint32_t n_reads, uint64_t *total, uint32_t *max_len)
+{
+    uint64_t sum = 0;
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < n_reads; i++) { sum += len[i]; longest = std::max<uint32_t>(longest, len[i]); }
+    if (sum > c->prm.max_batch_bases)
+        return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)sum, (unsigned long long)c->prm.max_batch_bases);
+    *total = sum; *max_len = longest;
+    return GROOT_OK;
+}
+
+static int check_exceptions(groot_ctx *c, const uint64_t *exc_pos, uint64_t n_exc, uint64_t total)
+{
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n_exc; i++) bad |= (uint64_t)(exc_pos[i] >= total);
+    if (bad) return fail(c, GROOT_E_INVALID, "an exception position lies outside the batch");
     return GROOT_OK;
 }
 
@@ -854,19 +1284,19 @@ int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
 {
     if (!c) return GROOT_E_INVALID;
     if (n_reads && (!seq_concat || !seq_off)) return fail(c, GROOT_E_INVALID, "null read buffers");
-    if (int rc = begin_batch(c, n_reads, first_read_id)) { return rc; }
-    if (!n_reads) return GROOT_OK;
-    const uint64_t total = seq_off[n_reads] - seq_off[0];
-    if (seq_off[0] != 0) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0"); }
-    if (total > c->prm.max_batch_bases) { c->submitted = false; return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)total, (unsigned long long)c->prm.max_batch_bases); }
     uint32_t max_len = 0;
-    if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc;
-    c->batch_max_len = std::min(max_len, c->prm.max_read_len);
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    c->cur_seq = c->seq.p; c->cur_off = c->seq_off.p;
-    return run_batch_async(c);
+    if (n_reads) { if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc; }
+    Slot *s = nullptr;
+    if (int rc = take_slot(c, n_reads, &s)) return rc;
+    if (int rc = ensure_slot(c, s, Slot::IN_ASCII, 0)) return rc;
+    s->input = Slot::IN_ASCII; s->n_reads = n_reads; s->first_read_id = first_read_id;
+    s->n_bases = n_reads ? seq_off[n_reads] : 0; s->n_exc = 0;
+    s->max_len = std::min(max_len, c->prm.max_read_len);
+    if (n_reads) {   // the caller's memory is not referenced after this call returns
+        par_copy(s->h_bases.p, seq_concat, s->n_bases);
+        par_copy(s->h_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t));
+    }
+    return enqueue(c, s);
 }
 
 int groot_hip_submit_packed(groot_ctx *c, const uint8_t *packed, const uint64_t *seq_off, uint32_t n_reads, uint32_t first_read_id,
@@ -875,33 +1305,91 @@ int groot_hip_submit_packed(groot_ctx *c, const uint8_t *packed, const uint64_t 
     if (!c) return GROOT_E_INVALID;
     if (n_reads && (!packed || !seq_off)) return fail(c, GROOT_E_INVALID, "null read buffers");
     if (n_exc && (!exc_pos || !exc_byte)) return fail(c, GROOT_E_INVALID, "null exception list");
-    if (int rc = begin_batch(c, n_reads, first_read_id)) return rc;
-    if (!n_reads) return GROOT_OK;
-    const uint64_t total = seq_off[n_reads];
-    if (seq_off[0] != 0) { c->submitted = false; return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0"); }
-    if (total > c->prm.max_batch_bases) { c->submitted = false; return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)total, (unsigned long long)c->prm.max_batch_bases); }
     uint32_t max_len = 0;
-    if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc;
-    for (uint64_t i = 0; i < n_exc; i++)
-        if (exc_pos[i] >= total) { c->submitted = false; return fail(c, GROOT_E_INVALID, "exception %llu lies outside the batch", (unsigned long long)i); }
-    c->batch_max_len = std::min(max_len, c->prm.max_read_len);
-    const uint64_t n_words = (total + 15) / 16;                  // 16 bases per packed word
-    if (c->packed.n < n_words) HIP_TRY(c, c->packed.alloc((c->prm.max_batch_bases + 15) / 16 + 1));
-    if (c->exc_pos.n < n_exc) { HIP_TRY(c, c->exc_pos.alloc(n_exc + n_exc / 4 + 1024)); HIP_TRY(c, c->exc_byte.alloc(n_exc + n_exc / 4 + 1024)); }
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->packed.p, packed, (size_t)((total + 3) / 4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(unpack_reads_kernel, dim3((unsigned)((n_words + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->packed.p, n_words,
-                       reinterpret_cast<uint4 *>(c->seq.p));
-    if (n_exc) {
-        HIP_TRY(c, hipMemcpyAsync(c->exc_pos.p, exc_pos, n_exc * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->exc_byte.p, exc_byte, n_exc, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(patch_reads_kernel, dim3((unsigned)((n_exc + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->exc_pos.p,
-                           c->exc_byte.p, n_exc, c->seq.p);
+    if (n_reads) {
+        if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc;
+        if (int rc = check_exceptions(c, exc_pos, n_exc, seq_off[n_reads])) return rc;
     }
-    HIP_TRY(c, hipGetLastError());
-    c->cur_seq = c->seq.p; c->cur_off = c->seq_off.p;
-    return run_batch_async(c);
+    Slot *s = nullptr;
+    if (int rc = take_slot(c, n_reads, &s)) return rc;
+    if (int rc = ensure_slot(c, s, Slot::IN_PACKED, n_exc)) return rc;
+    s->input = Slot::IN_PACKED; s->n_reads = n_reads; s->first_read_id = first_read_id;
+    s->n_bases = n_reads ? seq_off[n_reads] : 0; s->n_exc = n_reads ? n_exc : 0;
+    s->max_len = std::min(max_len, c->prm.max_read_len);
+    if (n_reads) {
+        par_copy(s->h_bases.p, packed, (size_t)((s->n_bases + 3) / 4));
+        par_copy(s->h_off.p, seq_off, ((size_t)n_reads + 1) * sizeof(uint64_t));
+        if (n_exc) { memcpy(s->h_exc_pos.p, exc_pos, n_exc * sizeof(uint64_t)); memcpy(s->h_exc_byte.p, exc_byte, n_exc); }
+    }
+    return enqueue(c, s);
+}
+
+int groot_hip_submit_packed16(groot_ctx *c, const uint8_t *packed, const uint16_t *seq_len, uint32_t n_reads, uint32_t first_read_id,
+                              const uint64_t *exc_pos, const uint8_t *exc_byte, uint64_t n_exc)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (n_reads && (!packed || !seq_len)) return fail(c, GROOT_E_INVALID, "null read buffers");
+    if (n_exc && (!exc_pos || !exc_byte)) return fail(c, GROOT_E_INVALID, "null exception list");
+    uint64_t total = 0;
+    uint32_t max_len = 0;
+    if (n_reads) {
+        if (int rc = check_lengths(c, seq_len, n_reads, &total, &max_len)) return rc;
+        if (int rc = check_exceptions(c, exc_pos, n_exc, total)) return rc;
+    }
+    Slot *s = nullptr;
+    if (int rc = take_slot(c, n_reads, &s)) return rc;
+    if (int rc = ensure_slot(c, s, Slot::IN_PACKED16, n_exc)) return rc;
+    s->input = Slot::IN_PACKED16; s->n_reads = n_reads; s->first_read_id = first_read_id;
+    s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
+    s->max_len = std::min(max_len, c->prm.max_read_len);
+    if (n_reads) {
+        par_copy(s->h_bases.p, packed, (size_t)((total + 3) / 4));
+        par_copy(s->h_len.p, seq_len, (size_t)n_reads * sizeof(uint16_t));
+        if (n_exc) { memcpy(s->h_exc_pos.p, exc_pos, n_exc * sizeof(uint64_t)); memcpy(s->h_exc_byte.p, exc_byte, n_exc); }
+    }
+    return enqueue(c, s);
+}
+
+int groot_hip_acquire(groot_ctx *c, groot_batch_buffers *out)
+{
+    if (!c || !out) return GROOT_E_INVALID;
+    Slot *s = nullptr;
+    if (int rc = take_slot(c, 0, &s)) return rc;
+    if (int rc = ensure_slot(c, s, Slot::IN_PACKED16, 0)) return rc;
+    s->state = Slot::ACQUIRED;
+    s->ticket = c->next_ticket++;
+    memset(out, 0, sizeof *out);
+    out->ticket = s->ticket;
+    out->packed = s->h_bases.p; out->seq_len = s->h_len.p; out->exc_pos = s->h_exc_pos.p; out->exc_byte = s->h_exc_byte.p;
+    out->packed_cap = (c->prm.max_batch_bases + 3) / 4; out->exc_cap = s->h_exc_pos.n; out->reads_cap = c->prm.max_batch_reads;
+    return GROOT_OK;
+}
+
+static Slot *slot_by_ticket(groot_ctx *c, uint64_t ticket, Slot::State st)
+{
+    for (auto &s : c->slots)
+        if (s->ticket == ticket && s->state == st) return s.get();
+    return nullptr;
+}
+
+int groot_hip_submit_acquired(groot_ctx *c, uint64_t ticket, uint32_t n_reads, uint64_t n_exc, uint32_t first_read_id)
+{
+    if (!c) return GROOT_E_INVALID;
+    Slot *s = slot_by_ticket(c, ticket, Slot::ACQUIRED);
+    if (!s) return fail(c, GROOT_E_STATE, "ticket %llu is not an acquired batch", (unsigned long long)ticket);
+    if (n_reads > c->prm.max_batch_reads) return fail(c, GROOT_E_NOSPACE, "batch of %u reads exceeds max_batch_reads=%u", n_reads, c->prm.max_batch_reads);
+    if (n_exc > s->h_exc_pos.n) return fail(c, GROOT_E_NOSPACE, "more exceptions than the acquired buffers hold");
+    uint64_t total = 0;
+    uint32_t max_len = 0;
+    if (n_reads) {
+        if (int rc = check_lengths(c, s->h_len.p, n_reads, &total, &max_len)) return rc;
+        if (int rc = check_exceptions(c, s->h_exc_pos.p, n_exc, total)) return rc;
+    }
+    s->input = Slot::IN_PACKED16; s->n_reads = n_reads; s->first_read_id = first_read_id;
+    s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
+    s->max_len = std::min(max_len, c->prm.max_read_len);
+    s->state = Slot::FREE;           // enqueue re-labels it
+    return enqueue(c, s);
 }
 
 int groot_hip_submit_device(groot_ctx *c, const void *d_seq, const void *d_seq_off, uint32_t n_reads, uint32_t first_read_id,
@@ -910,120 +1398,112 @@ int groot_hip_submit_device(groot_ctx *c, const void *d_seq, const void *d_seq_o
     if (!c) return GROOT_E_INVALID;
     if (n_reads && (!d_seq || !d_seq_off)) return fail(c, GROOT_E_INVALID, "null device buffers");
     if (((uintptr_t)d_seq & 15) != 0) return fail(c, GROOT_E_INVALID, "d_seq must be 16-byte aligned");
-    if (int rc = begin_batch(c, n_reads, first_read_id)) return rc;
-    if (!n_reads) return GROOT_OK;
-    c->batch_max_len = max_len ? std::min(max_len, c->prm.max_read_len) : c->prm.max_read_len;
-    c->cur_seq = (const uint8_t *)d_seq; c->cur_off = (const uint64_t *)d_seq_off;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    return run_batch_async(c);
+    Slot *s = nullptr;
+    if (int rc = take_slot(c, n_reads, &s)) return rc;
+    if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;
+    s->input = Slot::IN_DEVICE; s->n_reads = n_reads; s->first_read_id = first_read_id; s->n_bases = 0; s->n_exc = 0;
+    s->ext_seq = (const uint8_t *)d_seq; s->ext_off = (const uint64_t *)d_seq_off;
+    s->max_len = max_len ? std::min(max_len, c->prm.max_read_len) : c->prm.max_read_len;
+    return enqueue(c, s);
 }
 
-static void fill_counts(groot_ctx *c, groot_counts *out)
+// ---- collect --------------------------------------------------------------------------------------------------------
+int groot_hip_collect(groot_ctx *c, groot_batch_result *out)
 {
-    if (!out) return;
-    out->received = c->n_reads;           // boss.go:194 receivedReads++ for every read
-    out->mapped = c->hctr.mapped;
-    out->multimapped = c->hctr.multimapped;
-    out->alignments = c->hctr.alignments;
-    out->seeds = c->hctr.seeds;
-    out->travs = c->n_trav;
-    out->revcomp_panics = c->hctr.revcomp_panics;
-    out->short_reads = c->hctr.short_reads;
+    if (!c || !out) return GROOT_E_INVALID;
+    Slot *s = nullptr;
+    if (int rc = collect_impl(c, &s)) return rc;
+    memset(out, 0, sizeof *out);
+    out->ticket = s->ticket; out->first_read_id = s->first_read_id; out->n_reads = s->n_reads;
+    out->counts = s->counts;
+    out->n_travs = s->n_trav;
+    out->travs = s->host_results ? s->h_trav.p : nullptr;
+    out->masks = s->host_results ? s->h_mask.p : nullptr;
+    out->d_travs = s->d_trav.p; out->d_masks = s->d_mask.p;
+    out->path_words = c->pw_view;
+    out->status = s->status;
+    out->ms = s->ms;
+    if (s->status) return fail(c, s->status, "%s", s->status_msg.c_str());
+    return GROOT_OK;
+}
+
+int groot_hip_release(groot_ctx *c, uint64_t ticket)
+{
+    if (!c) return GROOT_E_INVALID;
+    Slot *s = slot_by_ticket(c, ticket, Slot::COLLECTED);
+    if (!s) s = slot_by_ticket(c, ticket, Slot::ACQUIRED);     // an acquired batch may be abandoned
+    if (!s) return fail(c, GROOT_E_STATE, "ticket %llu is not a collected batch", (unsigned long long)ticket);
+    release_slot(c, s);
+    return GROOT_OK;
+}
+
+int groot_hip_in_flight(groot_ctx *c, uint32_t *submitted_not_collected, uint32_t *free_slots)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (submitted_not_collected) *submitted_not_collected = (uint32_t)c->inflight.size();
+    if (free_slots) {
+        uint32_t n = 0;
+        for (auto &s : c->slots) n += s->state == Slot::FREE || s.get() == c->waited;
+        *free_slots = n;
+    }
+    return GROOT_OK;
 }
 
 int groot_hip_wait(groot_ctx *c, groot_counts *counts)
 {
     if (!c) return GROOT_E_INVALID;
-    if (!c->submitted) return fail(c, GROOT_E_STATE, "no batch submitted");
-    if (c->finished) { fill_counts(c, counts); return GROOT_OK; }
+    if (c->inflight.empty()) {
+        if (!c->waited) return fail(c, GROOT_E_STATE, "no batch submitted");
+    } else {
+        if (c->waited) release_slot(c, c->waited);
+        Slot *s = nullptr;
+        if (int rc = collect_impl(c, &s)) return rc;
+        c->waited = s;
+    }
+    if (counts) *counts = c->waited->counts;
+    if (c->waited->status) return fail(c, c->waited->status, "%s", c->waited->status_msg.c_str());
+    return GROOT_OK;
+}
+
+int groot_hip_read_travs(groot_ctx *c, groot_trav *out, uint64_t *masks, uint64_t cap, uint64_t *n)
+{
+    if (!c || !n) return GROOT_E_INVALID;
+    Slot *s = c->waited;
+    if (!s) return fail(c, GROOT_E_STATE, "no finished batch");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->n_reads == 0) { c->finished = true; fill_counts(c, counts); return GROOT_OK; }
-    auto fetch = [&](DeviceCounters &dst) -> int {
-        HIP_TRY(c, hipMemcpyAsync(&dst, c->ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        return GROOT_OK;
-    };
-    if (int rc = fetch(c->hctr)) return rc;
-    for (int attempt = 0;; attempt++) {
-        if (attempt > 8) return fail(c, GROOT_E_NOSPACE, "output buffers keep overflowing (flags=0x%x)", c->hctr.flags);
-        if (c->hctr.flags & kFlagSeedOverflow) {
-            // a read had more seeds than slots; the align stage saw the flag and did nothing.  Grow and redo.
-            if (int rc = alloc_seed_slots(c, c->hctr.max_seeds + 4)) return rc;
-            if (int rc = run_batch_async(c)) return rc;
-            if (int rc = fetch(c->hctr)) return rc;
-            continue;
-        }
-        if (c->hctr.flags & kFlagOvfOverflow) {
-            // a shard of the overflow traversal list filled up: enlarge and re-emit traversals only
-            // (weights and read counters of the first pass stand)
-            const DeviceCounters first = c->hctr;
-            if (int rc = alloc_ovf(c, c->ovf_cap * 4)) return rc;
-            HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
-            if (int rc = launch_align_stage(c, false)) return rc;
-            if (int rc = launch_order_stage(c)) return rc;
-            DeviceCounters second{};
-            if (int rc = fetch(second)) return rc;
-            c->hctr = first;
-            c->hctr.n_trav = second.n_trav; c->hctr.alignments = second.alignments;
-            c->hctr.flags = (first.flags & ~(kFlagOvfOverflow | kFlagTravOverflow)) | second.flags;
-            continue;
-        }
-        if (c->hctr.flags & kFlagTravOverflow) {
-            // the ordered output buffer is too small: the raw records are intact, only the ordering is redone
-            if (int rc = alloc_trav(c, c->hctr.n_trav + c->hctr.n_trav / 8 + 1024)) return rc;
-            HIP_TRY(c, hipMemsetAsync(&c->ctr.p->flags, 0, sizeof(unsigned int), c->stream));
-            if (int rc = launch_order_stage(c)) return rc;
-            DeviceCounters again{};
-            if (int rc = fetch(again)) return rc;
-            c->hctr.flags = (c->hctr.flags & ~kFlagTravOverflow) | again.flags;
-            continue;
-        }
-        break;
+    *n = s->n_trav;
+    const uint64_t m = std::min<uint64_t>(cap, s->n_trav);
+    if (s->host_results) {
+        if (m && out) memcpy(out, s->h_trav.p, m * sizeof(groot_trav));
+        if (m && masks) memcpy(masks, s->h_mask.p, m * c->pw_view * sizeof(uint64_t));
+    } else {
+        if (m && out) HIP_TRY(c, hipMemcpy(out, s->d_trav.p, m * sizeof(groot_trav), hipMemcpyDeviceToHost));
+        if (m && masks) HIP_TRY(c, hipMemcpy(masks, s->d_mask.p, m * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
-    c->n_trav = c->hctr.n_trav;
-#ifdef GROOT_WORK_COUNTERS
-    for (int e = 0; e < 32; e++)
-        if (c->hctr.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, c->hctr.dbg[e], c->hctr.dbg[32 + e]);
-    fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", c->hctr.dbg[63]);
-    for (int ph = 0; ph < 3; ph++)
-        fprintf(stderr, "[groot work] phase %d: %llu steps, %.2f us per step (wall clock, per wave)\n", ph, c->hctr.dbg[27 + ph],
-                c->hctr.dbg[27 + ph] ? (double)c->hctr.dbg[24 + ph] / 100.0 / (double)c->hctr.dbg[27 + ph] : 0.0);
-    for (int h = 0; h < 2; h++) {
-        fprintf(stderr, "[groot work] %s (buckets of 2 iterations):", h ? "round length" : "lane finish");
-        for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", c->hctr.dbg[64 + 64 * h + b]);
-        fprintf(stderr, "\n");
-    }
-#endif
-    if (c->profiling) {
-        (void)hipEventElapsedTime(&c->ms.h2d, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&c->ms.sketch_seed, c->ev[1], c->ev[5]);
-        (void)hipEventElapsedTime(&c->ms.schedule, c->ev[5], c->ev[2]);
-        (void)hipEventElapsedTime(&c->ms.align, c->ev[2], c->ev[3]);
-        (void)hipEventElapsedTime(&c->ms.sort, c->ev[3], c->ev[4]);
-        (void)hipEventElapsedTime(&c->ms.total, c->ev[0], c->ev[4]);
-    }
-    c->finished = true;
-    fill_counts(c, counts);
-    if (c->hctr.flags & kFlagLongRead) return fail(c, GROOT_E_NOSPACE, "a read is longer than max_read_len=%u", c->prm.max_read_len);
-    if (c->hctr.flags & kFlagOrdOverflow) return fail(c, GROOT_E_NOSPACE, "a read produced more than 65535 traversals");
-    if (c->hctr.flags & kFlagShortRead)
-        return fail(c, GROOT_E_SHORT_READ, "k size is greater than sequence length for %llu read(s) (the reference panics: boss.go:164-166)", c->hctr.short_reads);
-    if (c->hctr.revcomp_panics)
-        return fail(c, GROOT_E_REVCOMP, "%llu read(s) hold a byte > 'T' and reached RevComplement (the reference panics: seqio.go:126)", c->hctr.revcomp_panics);
+    return GROOT_OK;
+}
+
+// seeds and sketches stay in the shared work buffers: they are the waited batch's only while no newer batch has run
+static int work_buffers_of_waited(groot_ctx *c)
+{
+    Slot *s = c->waited;
+    if (!s) return fail(c, GROOT_E_STATE, "no finished batch");
+    if (s->n_reads && (c->work_owner != s || c->work_ticket != s->ticket))
+        return fail(c, GROOT_E_STATE, "a newer batch has been submitted: the seeds / sketches of the waited batch are gone");
     return GROOT_OK;
 }
 
 int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *n)
 {
     if (!c || !n) return GROOT_E_INVALID;
-    if (!c->finished) return fail(c, GROOT_E_STATE, "no finished batch");
+    if (int rc = work_buffers_of_waited(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t R = c->n_reads;
+    const Slot *s = c->waited;
+    const uint32_t R = s->n_reads;
     std::vector<uint32_t> cnt(R), win((size_t)c->seed_slots * R);
     if (R) {
         HIP_TRY(c, hipMemcpy(cnt.data(), c->seed_count.p, (size_t)R * 4, hipMemcpyDeviceToHost));
-        for (uint32_t j = 0; j < c->seed_slots; j++)
-            HIP_TRY(c, hipMemcpy(win.data() + (size_t)j * R, c->seed_win.p + (size_t)j * R, (size_t)R * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(win.data(), c->seed_win.p, (size_t)c->seed_slots * R * 4, hipMemcpyDeviceToHost));   // [slot][R], R = this batch
     }
     uint64_t total = 0;
     std::vector<uint32_t> tmp;
@@ -1033,7 +1513,7 @@ int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *
         for (uint32_t j = 0; j < m; j++) tmp.push_back(win[(size_t)j * R + r]);
         std::sort(tmp.begin(), tmp.end());
         for (uint32_t w : tmp) {
-            if (out && total < cap) out[total] = groot_seed{c->first_read_id + r, w};
+            if (out && total < cap) out[total] = groot_seed{s->first_read_id + r, w};
             total++;
         }
     }
@@ -1041,26 +1521,14 @@ int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *
     return GROOT_OK;
 }
 
-int groot_hip_read_travs(groot_ctx *c, groot_trav *out, uint64_t *masks, uint64_t cap, uint64_t *n)
-{
-    if (!c || !n) return GROOT_E_INVALID;
-    if (!c->finished) return fail(c, GROOT_E_STATE, "no finished batch");
-    HIP_TRY(c, hipSetDevice(c->device));
-    *n = c->n_trav;
-    const uint64_t m = std::min<uint64_t>(cap, c->n_trav);
-    if (m && out) HIP_TRY(c, hipMemcpy(out, c->trav_sorted.p, m * sizeof(groot_trav), hipMemcpyDeviceToHost));
-    if (m && masks) HIP_TRY(c, hipMemcpy(masks, c->trav_mask_sorted.p, m * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    return GROOT_OK;
-}
-
 int groot_hip_read_sketches(groot_ctx *c, uint64_t *out, uint64_t cap_reads, uint64_t *n_reads)
 {
     if (!c || !n_reads) return GROOT_E_INVALID;
-    if (!c->finished) return fail(c, GROOT_E_STATE, "no finished batch");
+    if (int rc = work_buffers_of_waited(c)) return rc;
     if (!c->prm.keep_sketches) return fail(c, GROOT_E_STATE, "ctx was opened without keep_sketches");
     HIP_TRY(c, hipSetDevice(c->device));
-    *n_reads = c->n_reads;
-    const uint64_t m = std::min<uint64_t>(cap_reads, c->n_reads);
+    *n_reads = c->waited->n_reads;
+    const uint64_t m = std::min<uint64_t>(cap_reads, c->waited->n_reads);
     if (m && out) HIP_TRY(c, hipMemcpy(out, c->sketches.p, m * c->s * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return GROOT_OK;
 }
@@ -1068,7 +1536,95 @@ int groot_hip_read_sketches(groot_ctx *c, uint64_t *out, uint64_t cap_reads, uin
 int groot_hip_stage_ms(groot_ctx *c, groot_stage_ms *out)
 {
     if (!c || !out) return GROOT_E_INVALID;
-    *out = c->ms;
+    if (c->waited) *out = c->waited->ms;
+    else memset(out, 0, sizeof *out);
+    return GROOT_OK;
+}
+
+// ---- call counts ----------------------------------------------------------------------------------------------------
+static int table_rows(groot_ctx *c, std::vector<uint32_t> &q_of_row)     // device sync + the current row -> kmerCount map
+{
+    if (int rc = drain(c)) return rc;
+    uint32_t n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->q_nrows.p, 4, hipMemcpyDeviceToHost));
+    q_of_row.resize(n);
+    if (n) HIP_TRY(c, hipMemcpy(q_of_row.data(), c->q_of_row.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_export(groot_ctx *c, uint32_t *q_values, uint32_t *counts, uint32_t cap_rows, uint32_t *n_rows, uint32_t *n_windows)
+{
+    if (!c || !n_rows) return GROOT_E_INVALID;
+    std::vector<uint32_t> qs;
+    if (int rc = table_rows(c, qs)) return rc;
+    *n_rows = (uint32_t)qs.size();
+    if (n_windows) *n_windows = c->n_windows;
+    std::vector<uint32_t> order(qs.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return qs[a] < qs[b]; });
+    for (uint32_t i = 0; i < order.size() && i < cap_rows; i++) {
+        if (q_values) q_values[i] = qs[order[i]];
+        if (counts && c->n_windows)
+            HIP_TRY(c, hipMemcpy(counts + (size_t)i * c->n_windows, c->attempts_ptr + (size_t)order[i] * c->n_windows, (size_t)c->n_windows * 4,
+                                 hipMemcpyDeviceToHost));
+    }
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_layout(groot_ctx *c, const uint32_t *q_values, uint32_t n_q, void *d_table)
+{
+    if (!c || (n_q && !q_values)) return GROOT_E_INVALID;
+    if (!idle(c)) return fail(c, GROOT_E_STATE, "a batch is in flight");
+    for (uint32_t i = 0; i < n_q; i++) {
+        if (q_values[i] > c->max_q) return fail(c, GROOT_E_INVALID, "kmerCount %u exceeds max_read_len-k+1=%u", q_values[i], c->max_q);
+        if (i && q_values[i] <= q_values[i - 1]) return fail(c, GROOT_E_INVALID, "kmerCounts must be strictly ascending");
+    }
+    std::vector<uint32_t> qs;
+    if (int rc = table_rows(c, qs)) return rc;
+    std::vector<uint32_t> new_row(qs.size());
+    for (size_t r = 0; r < qs.size(); r++) {
+        const uint32_t *p = std::lower_bound(q_values, q_values + n_q, qs[r]);
+        if (p == q_values + n_q || *p != qs[r]) return fail(c, GROOT_E_INVALID, "the layout lacks kmerCount %u, which has counts", qs[r]);
+        new_row[r] = (uint32_t)(p - q_values);
+    }
+    const uint32_t cap = std::max<uint32_t>(n_q, 1);
+    DevBuf<uint32_t> own;
+    uint32_t *dst = (uint32_t *)d_table;
+    if (!dst) { HIP_TRY(c, own.alloc((size_t)cap * c->n_windows)); dst = own.p; }
+    if (n_q) HIP_TRY(c, hipMemset(dst, 0, (size_t)n_q * c->n_windows * 4));
+    for (size_t r = 0; r < qs.size(); r++)
+        HIP_TRY(c, hipMemcpy(dst + (size_t)new_row[r] * c->n_windows, c->attempts_ptr + r * c->n_windows, (size_t)c->n_windows * 4, hipMemcpyDeviceToDevice));
+    std::vector<uint32_t> rowmap(c->max_q + 2, kEmpty);
+    for (uint32_t i = 0; i < n_q; i++) rowmap[q_values[i]] = i;
+    HIP_TRY(c, hipMemcpy(c->q_row.p, rowmap.data(), rowmap.size() * 4, hipMemcpyHostToDevice));
+    if (n_q) HIP_TRY(c, hipMemcpy(c->q_of_row.p, q_values, (size_t)n_q * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->q_nrows.p, &n_q, 4, hipMemcpyHostToDevice));
+    if (d_table) {
+        c->attempts.release();
+        c->attempts_ptr = dst; c->att_external = true; c->att_cap = n_q;
+    } else {
+        std::swap(c->attempts.p, own.p); std::swap(c->attempts.n, own.n);
+        c->attempts_ptr = c->attempts.p; c->att_external = false; c->att_cap = cap;
+    }
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_device(groot_ctx *c, void **d_table, uint32_t *n_rows, uint32_t *n_windows)
+{
+    if (!c || !d_table) return GROOT_E_INVALID;
+    std::vector<uint32_t> qs;
+    if (int rc = table_rows(c, qs)) return rc;
+    *d_table = c->attempts_ptr;
+    if (n_rows) *n_rows = (uint32_t)qs.size();
+    if (n_windows) *n_windows = c->n_windows;
+    return GROOT_OK;
+}
+
+int groot_hip_attempts_reset(groot_ctx *c)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (int rc = drain(c)) return rc;
+    if (c->att_cap) HIP_TRY(c, hipMemset(c->attempts_ptr, 0, (size_t)c->att_cap * c->n_windows * sizeof(uint32_t)));
     return GROOT_OK;
 }
 
@@ -1080,74 +1636,157 @@ int groot_hip_attempts_shape(groot_ctx *c, uint32_t *n_q, uint32_t *n_windows)
     return GROOT_OK;
 }
 
-int groot_hip_attempts_device(groot_ctx *c, void **d_counts, uint64_t *n_elems)
-{
-    if (!c || !d_counts) return GROOT_E_INVALID;
-    *d_counts = c->attempts_ptr;
-    if (n_elems) *n_elems = (uint64_t)(c->max_q + 1) * c->n_windows;
-    return GROOT_OK;
-}
-
 int groot_hip_attempts_read(groot_ctx *c, uint32_t *out, uint64_t n_elems)
 {
     if (!c || !out) return GROOT_E_INVALID;
     const uint64_t have = (uint64_t)(c->max_q + 1) * c->n_windows;
     if (n_elems < have) return fail(c, GROOT_E_NOSPACE, "need room for %llu counts", (unsigned long long)have);
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (have) HIP_TRY(c, hipMemcpy(out, c->attempts_ptr, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> qs;
+    if (int rc = table_rows(c, qs)) return rc;
+    memset(out, 0, have * sizeof(uint32_t));
+    for (size_t r = 0; r < qs.size(); r++)
+        if (c->n_windows)
+            HIP_TRY(c, hipMemcpy(out + (size_t)qs[r] * c->n_windows, c->attempts_ptr + r * c->n_windows, (size_t)c->n_windows * 4, hipMemcpyDeviceToHost));
     return GROOT_OK;
 }
 
-int groot_hip_attempts_reset(groot_ctx *c)
-{
-    if (!c) return GROOT_E_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->attempts_ptr, 0, (size_t)(c->max_q + 1) * c->n_windows * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return GROOT_OK;
-}
+// ---- the one exchange of a multi-GPU run ----------------------------------------------------------------------------
+namespace {
+// RCCL is loaded on first use: a single-GPU run never touches it
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclUint32 = 3, kNcclSum = 0;    // ncclDataType_t / ncclRedOp_t values of rccl.h
+} // namespace
 
-int groot_hip_attempts_bind(groot_ctx *c, void *d_counts, uint64_t n_elems)
+int groot_hip_attempts_allreduce(groot_ctx *const *ctxs, int n_ctx)
 {
-    if (!c) return GROOT_E_INVALID;
-    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "a batch is in flight");
-    if (!d_counts) { c->attempts_ptr = c->attempts.p; return GROOT_OK; }
-    const uint64_t need = (uint64_t)(c->max_q + 1) * c->n_windows;
-    if (n_elems < need) return fail(c, GROOT_E_NOSPACE, "bound buffer holds %llu counts, need %llu", (unsigned long long)n_elems, (unsigned long long)need);
-    c->attempts_ptr = (uint32_t *)d_counts;
+    if (!ctxs || n_ctx <= 0) return GROOT_E_INVALID;
+    groot_ctx *c0 = ctxs[0];
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctxs[i]) return GROOT_E_INVALID;
+        if (ctxs[i]->n_windows != c0->n_windows || ctxs[i]->max_q != c0->max_q) return fail(c0, GROOT_E_INVALID, "ctxs were opened on different indexes / read length limits");
+        if (ctxs[i]->att_external) return fail(c0, GROOT_E_STATE, "ctx %d keeps its table in a caller-owned buffer", i);
+    }
+    if (n_ctx == 1) return drain(c0);
+    // union row layout (ascending kmerCount) on every ctx
+    std::vector<uint32_t> all;
+    for (int i = 0; i < n_ctx; i++) {
+        std::vector<uint32_t> qs;
+        if (int rc = table_rows(ctxs[i], qs)) return fail(c0, rc, "%s", ctxs[i]->err.c_str());
+        all.insert(all.end(), qs.begin(), qs.end());
+    }
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (int i = 0; i < n_ctx; i++) {
+        HIP_TRY(c0, hipSetDevice(ctxs[i]->device));
+        if (int rc = groot_hip_attempts_layout(ctxs[i], all.data(), (uint32_t)all.size(), nullptr)) return fail(c0, rc, "%s", ctxs[i]->err.c_str());
+    }
+    const size_t count = all.size() * (size_t)c0->n_windows;
+    if (!count) return GROOT_OK;
+    // ctxs sharing a device (tests; several ctxs per GPU): fold them into the first ctx of that device with a kernel
+    std::vector<int> lead;                       // one ctx index per distinct device
+    for (int i = 0; i < n_ctx; i++) {
+        int l = -1;
+        for (int j : lead) if (ctxs[j]->device == ctxs[i]->device) l = j;
+        if (l < 0) { lead.push_back(i); continue; }
+        HIP_TRY(c0, hipSetDevice(ctxs[i]->device));
+        hipLaunchKernelGGL(add_u32_kernel, dim3((unsigned)std::min<size_t>((count + kBlock - 1) / kBlock, 65535)), dim3(kBlock), 0, ctxs[l]->stream,
+                           ctxs[l]->attempts_ptr, ctxs[i]->attempts_ptr, count);
+        HIP_TRY(c0, hipGetLastError());
+        HIP_TRY(c0, hipStreamSynchronize(ctxs[l]->stream));
+    }
+    if (lead.size() > 1) {
+        // one RCCL communicator over the distinct devices, one in-place ncclAllReduce(sum, uint32) per device: ring over xGMI
+        if (!g_rccl.load()) return fail(c0, GROOT_E_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+        std::vector<int> devs;
+        for (int j : lead) devs.push_back(ctxs[j]->device);
+        std::vector<void *> comms(lead.size(), nullptr);
+        int nrc = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+        if (nrc) return fail(c0, GROOT_E_DEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error");
+        nrc = g_rccl.GroupStart();
+        for (size_t j = 0; j < lead.size() && !nrc; j++) {
+            groot_ctx *c = ctxs[lead[j]];
+            (void)hipSetDevice(c->device);
+            nrc = g_rccl.AllReduce(c->attempts_ptr, c->attempts_ptr, count, kNcclUint32, kNcclSum, comms[j], c->stream);
+        }
+        const int erc = g_rccl.GroupEnd();
+        if (!nrc) nrc = erc;
+        for (size_t j = 0; j < lead.size(); j++) {
+            (void)hipSetDevice(ctxs[lead[j]]->device);
+            (void)hipStreamSynchronize(ctxs[lead[j]]->stream);
+        }
+        for (void *cm : comms) if (cm) (void)g_rccl.CommDestroy(cm);
+        if (nrc) return fail(c0, GROOT_E_DEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error");
+    }
+    // every ctx ends up with the totals
+    for (int i = 0; i < n_ctx; i++) {
+        int l = -1;
+        for (int j : lead) if (ctxs[j]->device == ctxs[i]->device) l = j;
+        if (l == i) continue;
+        HIP_TRY(c0, hipSetDevice(ctxs[i]->device));
+        HIP_TRY(c0, hipMemcpy(ctxs[i]->attempts_ptr, ctxs[l]->attempts_ptr, count * 4, hipMemcpyDeviceToDevice));
+    }
     return GROOT_OK;
 }
 
 int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n, uint64_t *out)
 {
     if (!c || !out || (n && (!seq_concat || !seq_off))) return GROOT_E_INVALID;
-    if (c->submitted && !c->finished) return fail(c, GROOT_E_STATE, "a batch is in flight");
+    if (!idle(c)) return fail(c, GROOT_E_STATE, "a batch is in flight");
     if (!n) return GROOT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if (n > c->prm.max_batch_reads) return fail(c, GROOT_E_NOSPACE, "more sequences than max_batch_reads");
     const uint64_t total = seq_off[n];
-    if (total > c->prm.max_batch_bases) return fail(c, GROOT_E_NOSPACE, "more bases than max_batch_bases");
     uint32_t max_len = 0;
     for (uint32_t i = 0; i < n; i++) max_len = std::max<uint32_t>(max_len, (uint32_t)(seq_off[i + 1] - seq_off[i]));
-    DevBuf<uint64_t> sk;
+    DevBuf<uint64_t> sk, off;
+    DevBuf<uint8_t> seq;
+    DevBuf<DeviceCounters> ctr;
     HIP_TRY(c, sk.alloc((size_t)n * c->s));
-    HIP_TRY(c, hipMemcpyAsync(c->seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->seq_off.p, seq_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    HIP_TRY(c, off.alloc((size_t)n + 1));
+    HIP_TRY(c, seq.alloc(total + 64));
+    HIP_TRY(c, ctr.alloc(1));
+    HIP_TRY(c, hipMemcpyAsync(seq.p, seq_concat, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(off.p, seq_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->stream));
     SeedArgs a{};
     a.ix = c->dix;
     a.ix.max_q = 0;   // no lookup: every read gets min_eq = S+1
-    a.seq = c->seq.p; a.seq_off = c->seq_off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
+    a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
-    a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.ctr = c->ctr.p;
+    a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.q_seen = nullptr; a.ctr = ctr.p;
     launch_seed(c->s, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
     HIP_TRY(c, hipGetLastError());
     DeviceCounters h{};
-    HIP_TRY(c, hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, sk.p, (size_t)n * c->s * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->work_owner = nullptr;       // the seed slots were used as scratch
     if (h.flags & kFlagShortRead) return fail(c, GROOT_E_SHORT_READ, "k size is greater than sequence length");
     if (h.flags & kFlagLongRead) return fail(c, GROOT_E_NOSPACE, "a sequence is longer than max_read_len=%u", c->prm.max_read_len);
     return GROOT_OK;

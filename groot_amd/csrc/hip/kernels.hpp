@@ -410,6 +410,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
     if (n_hits) {
+        if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;   // this kmerCount needs a row of the call-count table
         atomicAdd(&a.ctr->seeds, (unsigned long long)n_hits);
         atomicMax(&a.ctr->max_seeds, n_hits);
         if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
@@ -441,6 +442,27 @@ __global__ __launch_bounds__(kBlock) void patch_reads_kernel(const uint64_t *__r
 {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) seq[pos[i]] = byte[i];
+}
+
+// One row of the call-count table per kmerCount that occurs among seeded reads (IncrementSubPath's numKmers,
+// graphminion.go:60-67): rows are handed out in ascending kmerCount order within a batch, after the seed stage and before
+// the align stage.  More kmerCounts than rows: kFlagQOverflow, the align stage does nothing, the host grows the table
+// and re-runs the batch.
+__global__ void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t *q_of_row, uint32_t *n_rows, uint32_t cap, uint32_t max_q,
+                                     DeviceCounters *ctr)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t need = *n_rows;
+    for (uint32_t q = 0; q <= max_q; q++) {
+        if (!q_seen[q]) continue;
+        q_seen[q] = 0;
+        if (q_row[q] != kEmpty) continue;
+        if (need < cap) { q_row[q] = need; q_of_row[need] = q; }
+        need++;
+    }
+    if (need > cap) atomicOr(&ctr->flags, kFlagQOverflow);
+    *n_rows = min(need, cap);
+    ctr->q_rows = need;
 }
 
 // read records in processing order: the align stage then fetches slot-consecutive (coalesced) records instead of
@@ -569,8 +591,8 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     const DeviceIndex &ix = a.ix;
     const Rec *recs = reinterpret_cast<const Rec *>(a.node_rec);
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    // the seed stage ran out of per-read slots: the host grows them and re-runs the whole batch
-    if (a.ctr->flags & kFlagSeedOverflow) return;
+    // the seed stage ran out of per-read slots (or the call-count table out of rows): the host grows them and re-runs the whole batch
+    if (a.ctr->flags & (kFlagSeedOverflow | kFlagQOverflow)) return;
     unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
 #ifdef GROOT_WORK_COUNTERS
     uint32_t ev = 0;                                       // events of this lane in the current wave iteration
@@ -616,7 +638,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
     // ---- read ----
     bool have_read = false;
     const uint8_t *p = nullptr;
-    uint32_t len = 0, cnt = 0, q = 0, n_graphs = 0, ord = 0, read_id = 0;
+    uint32_t len = 0, cnt = 0, qrow = 0, n_graphs = 0, ord = 0, read_id = 0;
     uint32_t sd0 = kEmpty, sd1 = kEmpty, sd2 = kEmpty, sd3 = kEmpty;   // the read's first four seed windows
     uint32_t high_byte = 0;                                // RevComplement would panic on this read
     uint32_t cls = 0;                                      // kRec* verdicts of the read record >> 24; bit 6: they apply to w
@@ -791,7 +813,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
                     phase = PH_WAIT;
                     continue;
                 }
-                q = len - ix.k + 1;                           // graphminion.go:60 kmerCount
+                qrow = ix.q_row[len - ix.k + 1];              // graphminion.go:60 kmerCount -> its row of the call-count table
                 read_id = a.first_read_id + r;
                 n_graphs = 0; ord = 0; last = -1;
                 done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
@@ -845,7 +867,7 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             g = wa.x;
             if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
             if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
-            if (a.update_weights) atomicAdd(&a.attempts[(size_t)q * ix.n_windows + w], 1u);   // :67 IncrementSubPath
+            if (a.update_weights) atomicAdd(&a.attempts[(size_t)qrow * ix.n_windows + w], 1u);   // :67 IncrementSubPath
             if (a.no_align) continue;                         // :70-72
             seed = wa.y; off0 = wa.z;
             l1_hi = wa.w;                                     // alignment.go:36 and :199-201, folded at open
@@ -1067,6 +1089,12 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             if (panics) atomicAdd(&a.ctr->revcomp_panics, panics);
         }
     }
+}
+
+// dst += src over n uint32 (call-count tables of ctxs that share a device, groot_hip_attempts_allreduce)
+__global__ __launch_bounds__(kBlock) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] += src[i];
 }
 
 // ---- ordering: (read, ord) order without a sort -------------------------------------------------

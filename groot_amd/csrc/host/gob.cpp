@@ -700,7 +700,13 @@ int groot_index_load_gob(const char *gg_path, const char *lshe_path, groot_index
         if (int rc = check_index_params(&prm)) return rc;
         if (num_window_kmers != (uint64_t)prm.window_size - prm.kmer_size + 1)
             throw gob::Error("groot.lshe: NumWindowKmers is not WindowSize-KmerSize+1");
-        return flatten_graphs(graphs, prm, out);
+        if (int rc = flatten_graphs(graphs, prm, out)) return rc;
+        if (int rc = groot_index_view_check(&(*out)->v)) {      // same pass as after groot_index_load
+            groot_index_free(*out);
+            *out = nullptr;
+            return rc;
+        }
+        return GROOT_OK;
     } catch (const std::out_of_range &) {
         return set_error(GROOT_E_FORMAT, "gob index: a window or edge refers to a segment that is not in its graph");
     } catch (const std::exception &e) {

@@ -95,6 +95,21 @@ int groot_host_weights(const groot_index_view *ix, const uint32_t *attempts, uin
     return GROOT_OK;
 }
 
+int groot_host_weights_rows(const groot_index_view *ix, const uint32_t *q_values, uint32_t n_rows, const uint32_t *counts, double *kf, uint64_t *kt)
+{
+    if (!ix || !kf || !kt || (n_rows && (!q_values || !counts))) return set_error(GROOT_E_INVALID, "null argument");
+    for (uint32_t r = 1; r < n_rows; r++)
+        if (q_values[r] <= q_values[r - 1]) return set_error(GROOT_E_INVALID, "kmerCounts must be strictly ascending");
+    memset(kf, 0, sizeof(double) * ix->n_nodes);
+    memset(kt, 0, sizeof(uint64_t) * ix->n_graphs);
+    for (uint32_t w = 0; w < ix->n_windows; w++)
+        for (uint32_t r = 0; r < n_rows; r++) {
+            const uint32_t c = counts[(size_t)r * ix->n_windows + w];
+            for (uint32_t i = 0; i < c; i++) increment_sub_path(ix, w, double(q_values[r]), kf, kt);
+        }
+    return GROOT_OK;
+}
+
 int groot_host_prune(const groot_index_view *ix, const double *kf, double min_cov, uint8_t *graph_kept, uint8_t *path_kept,
                      uint8_t *node_removed)
 {

@@ -11,6 +11,7 @@
 // Go-map-order dependent, so segment ids produced here are deterministic
 // but not those of a Go-built index -- parity is defined on id-free coordinates.
 #include "host_common.hpp"
+#include "../common/view_check.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -728,7 +729,20 @@ int groot_index_load(const char *path, groot_index **out)
         return set_error(GROOT_E_FORMAT, "%s is truncated or corrupt", path);
     }
     idx->bind();
+    // array lengths agree; now the contents: every index in range, offsets monotone and ending at their payload
+    const std::string why = groot::check_index_view(&idx->v);
+    if (!why.empty()) {
+        delete idx;
+        return set_error(GROOT_E_FORMAT, "%s is corrupt: %s", path, why.c_str());
+    }
     *out = idx;
+    return GROOT_OK;
+}
+
+int groot_index_view_check(const groot_index_view *view)
+{
+    const std::string why = groot::check_index_view(view);
+    if (!why.empty()) return set_error(GROOT_E_FORMAT, "inconsistent index view: %s", why.c_str());
     return GROOT_OK;
 }
 

@@ -21,7 +21,8 @@ TRAV_RC, TRAV_START_CLIP, TRAV_END_CLIP, TRAV_FIRST = 1, 2, 4, 8
 class Params(C.Structure):
     _fields_ = [("containment_threshold", C.c_double), ("no_exact_align", C.c_uint32), ("max_read_len", C.c_uint32),
                 ("max_batch_reads", C.c_uint32), ("max_seeds_per_read", C.c_uint32), ("max_batch_bases", C.c_uint64),
-                ("keep_sketches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("keep_sketches", C.c_uint32), ("pipeline_depth", C.c_uint32), ("results_on_device", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class Counts(C.Structure):
@@ -33,7 +34,21 @@ class Counts(C.Structure):
 
 
 class StageMs(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule")]
+    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack")]
+
+
+class BatchBuffers(C.Structure):
+    """groot_batch_buffers: the pinned staging of one pipeline slot (groot_hip_acquire)"""
+    _fields_ = [("ticket", C.c_uint64), ("packed", C.POINTER(C.c_uint8)), ("seq_len", C.POINTER(C.c_uint16)),
+                ("exc_pos", C.POINTER(C.c_uint64)), ("exc_byte", C.POINTER(C.c_uint8)), ("packed_cap", C.c_uint64),
+                ("exc_cap", C.c_uint64), ("reads_cap", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BatchResult(C.Structure):
+    """groot_batch_result"""
+    _fields_ = [("ticket", C.c_uint64), ("first_read_id", C.c_uint32), ("n_reads", C.c_uint32), ("counts", Counts),
+                ("travs", C.c_void_p), ("masks", C.c_void_p), ("n_travs", C.c_uint64), ("d_travs", C.c_void_p),
+                ("d_masks", C.c_void_p), ("path_words", C.c_uint32), ("status", C.c_int32), ("ms", StageMs)]
 
 
 _lib = None
@@ -80,10 +95,10 @@ class Aligner:
     """One groot_ctx: the replacement for theBoss.mapReads (src/pipeline/boss.go:108-242) on one GPU."""
 
     def __init__(self, index, device=0, threshold=0.99, no_align=False, max_read_len=256, max_batch_reads=1 << 20,
-                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0):
+                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0, pipeline_depth=0, results_on_device=False):
         self.index = index
         self.params = Params(threshold, 1 if no_align else 0, max_read_len, max_batch_reads, max_seeds_per_read,
-                             max_batch_bases, 1 if keep_sketches else 0, 0)
+                             max_batch_bases, 1 if keep_sketches else 0, pipeline_depth, 1 if results_on_device else 0, 0)
         self._h = C.c_void_p()
         rc = lib().groot_hip_open(C.byref(self._h), C.c_int(device), C.byref(index.view), C.byref(self.params))
         if rc:
@@ -127,6 +142,55 @@ class Aligner:
         self._check(lib().groot_hip_submit_packed(self._h, _ffi.as_ptr(pk, C.c_uint8), _ffi.as_ptr(off, C.c_uint64), C.c_uint32(len(off) - 1),
                                                   C.c_uint32(first_read_id), _ffi.as_ptr(ep, C.c_uint64), _ffi.as_ptr(eb, C.c_uint8),
                                                   C.c_uint64(len(ep))))
+
+    def submit_packed16(self, packed, seq_len, exc_pos, exc_byte, first_read_id=0):
+        """groot_hip_submit_packed16: 2-bit bases + one u16 length per read + exception list (the wire format)"""
+        pk = np.ascontiguousarray(packed, dtype=np.uint8)
+        ln = np.ascontiguousarray(seq_len, dtype=np.uint16)
+        ep = np.ascontiguousarray(exc_pos, dtype=np.uint64)
+        eb = np.ascontiguousarray(exc_byte, dtype=np.uint8)
+        self._check(lib().groot_hip_submit_packed16(self._h, _ffi.as_ptr(pk, C.c_uint8), _ffi.as_ptr(ln, C.c_uint16), C.c_uint32(len(ln)),
+                                                    C.c_uint32(first_read_id), _ffi.as_ptr(ep, C.c_uint64), _ffi.as_ptr(eb, C.c_uint8),
+                                                    C.c_uint64(len(ep))))
+
+    def acquire(self):
+        """groot_hip_acquire: numpy views of a free slot's pinned staging (packed, seq_len, exc_pos, exc_byte) + ticket"""
+        b = BatchBuffers()
+        self._check(lib().groot_hip_acquire(self._h, C.byref(b)))
+        views = {"ticket": int(b.ticket),
+                 "packed": _ffi._np_view(b.packed, b.packed_cap, np.uint8), "seq_len": _ffi._np_view(b.seq_len, b.reads_cap, np.uint16),
+                 "exc_pos": _ffi._np_view(b.exc_pos, b.exc_cap, np.uint64), "exc_byte": _ffi._np_view(b.exc_byte, b.exc_cap, np.uint8)}
+        return views
+
+    def submit_acquired(self, ticket, n_reads, n_exc=0, first_read_id=0):
+        self._check(lib().groot_hip_submit_acquired(self._h, C.c_uint64(ticket), C.c_uint32(n_reads), C.c_uint64(n_exc), C.c_uint32(first_read_id)))
+
+    def collect(self, check=True, copy=True):
+        """groot_hip_collect: blocks for the oldest batch.  Returns a dict with counts, ticket, status and the traversal
+        records (copies by default; copy=False gives views of the ctx's pinned memory, valid until release(ticket))."""
+        r = BatchResult()
+        rc = lib().groot_hip_collect(self._h, C.byref(r))
+        if rc < 0 and (check or not r.ticket):
+            self._check(rc)
+        n = int(r.n_travs)
+        if r.travs and n:
+            t = _ffi._np_view(C.cast(r.travs, C.POINTER(C.c_uint8)), n * TRAV_DTYPE.itemsize, np.uint8).view(TRAV_DTYPE)
+            m = _ffi._np_view(C.cast(r.masks, C.POINTER(C.c_uint64)), n * r.path_words, np.uint64).reshape(n, r.path_words)
+            if copy:
+                t, m = t.copy(), m.copy()
+        else:
+            t, m = np.zeros(0, dtype=TRAV_DTYPE), np.zeros((0, self.path_words), dtype=np.uint64)
+        return {"ticket": int(r.ticket), "first_read_id": int(r.first_read_id), "n_reads": int(r.n_reads), "counts": r.counts.as_dict(),
+                "status": int(r.status), "n_travs": n, "travs": t, "masks": m, "d_travs": r.d_travs, "d_masks": r.d_masks,
+                "ms": {k: float(getattr(r.ms, k)) for k, _ in StageMs._fields_}}
+
+    def release(self, ticket):
+        self._check(lib().groot_hip_release(self._h, C.c_uint64(ticket)))
+
+    def in_flight(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(lib().groot_hip_in_flight(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def submit_device(self, d_seq_ptr, d_off_ptr, n_reads, first_read_id=0, max_len=0):
         self._check(lib().groot_hip_submit_device(self._h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), C.c_uint32(n_reads),
@@ -179,18 +243,32 @@ class Aligner:
         return nq.value, nw.value
 
     def attempts_device(self):
-        p, n = C.c_void_p(), C.c_uint64()
-        self._check(lib().groot_hip_attempts_device(self._h, C.byref(p), C.byref(n)))
-        return p.value, n.value
+        """(device pointer of the [rows][n_windows] uint32 call-count table, rows, n_windows)"""
+        p, nr, nw = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        self._check(lib().groot_hip_attempts_device(self._h, C.byref(p), C.byref(nr), C.byref(nw)))
+        return p.value, nr.value, nw.value
 
     def attempts(self):
+        """dense compatibility view [max_read_len-k+2][n_windows] (rows of kmerCounts that never occurred are zero)"""
         nq, nw = self.attempts_shape()
         out = np.zeros((nq, nw), dtype=np.uint32)
         self._check(lib().groot_hip_attempts_read(self._h, _ffi.as_ptr(out, C.c_uint32), C.c_uint64(out.size)))
         return out
 
-    def attempts_bind(self, d_ptr, n_elems):
-        self._check(lib().groot_hip_attempts_bind(self._h, C.c_void_p(d_ptr), C.c_uint64(n_elems)))
+    def attempts_rows(self):
+        """groot_hip_attempts_export: (kmerCounts ascending, counts[rows][n_windows])"""
+        nr, nw = C.c_uint32(), C.c_uint32()
+        self._check(lib().groot_hip_attempts_export(self._h, None, None, C.c_uint32(0), C.byref(nr), C.byref(nw)))
+        q = np.zeros(nr.value, dtype=np.uint32)
+        cnt = np.zeros((nr.value, nw.value), dtype=np.uint32)
+        self._check(lib().groot_hip_attempts_export(self._h, _ffi.as_ptr(q, C.c_uint32), _ffi.as_ptr(cnt, C.c_uint32), C.c_uint32(nr.value),
+                                                    C.byref(nr), C.byref(nw)))
+        return q, cnt
+
+    def attempts_layout(self, q_values, d_table=None):
+        """groot_hip_attempts_layout: fix the rows (ascending kmerCounts); d_table = caller-owned device buffer or None"""
+        q = np.ascontiguousarray(q_values, dtype=np.uint32)
+        self._check(lib().groot_hip_attempts_layout(self._h, _ffi.as_ptr(q, C.c_uint32), C.c_uint32(len(q)), C.c_void_p(d_table or 0)))
 
     def attempts_reset(self):
         self._check(lib().groot_hip_attempts_reset(self._h))
@@ -203,6 +281,25 @@ class Aligner:
         self._check(lib().groot_hip_sketch(self._h, _ffi.as_ptr(seq, C.c_uint8), _ffi.as_ptr(off, C.c_uint64),
                                            C.c_uint32(len(off) - 1), _ffi.as_ptr(out, C.c_uint64)))
         return out
+
+
+def attempts_allreduce(aligners):
+    """groot_hip_attempts_allreduce over the ctxs of one process: RCCL across devices, a kernel within a device"""
+    arr = (C.c_void_p * len(aligners))(*[a._h for a in aligners])
+    rc = lib().groot_hip_attempts_allreduce(arr, C.c_int(len(aligners)))
+    aligners[0]._check(rc)
+
+
+def weights_rows(index, q_values, counts):
+    """groot_host_weights_rows: canonical replay of IncrementSubPath from the per-kmerCount rows of the call-count table"""
+    q = np.ascontiguousarray(q_values, dtype=np.uint32)
+    cnt = np.ascontiguousarray(counts, dtype=np.uint32)
+    v = index.view
+    kf = np.zeros(v.n_nodes, dtype=np.float64)
+    kt = np.zeros(v.n_graphs, dtype=np.uint64)
+    host._check(host.lib().groot_host_weights_rows(C.byref(v), _ffi.as_ptr(q, C.c_uint32), C.c_uint32(len(q)), _ffi.as_ptr(cnt, C.c_uint32),
+                                                   _ffi.as_ptr(kf, C.c_double), _ffi.as_ptr(kt, C.c_uint64)))
+    return kf, kt
 
 
 def weights(index, attempts):

@@ -43,6 +43,18 @@ def _check(rc):
     return rc
 
 
+def index_cache_path(stem):
+    """build/<stem>.<key>.gidx, key = hash of the index-builder sources and the view layout: a cached index never
+    outlives the code that built it (windowing / merge quirks / file format)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for rel in ("groot_amd/csrc/host/index.cpp", "groot_amd/csrc/host/host_common.hpp", "include/groot_index.h"):
+        with open(os.path.join(_ffi.REPO, rel), "rb") as f:
+            h.update(f.read())
+    return os.path.join(_ffi.BUILD_DIR, f"{stem}.{h.hexdigest()[:12]}.gidx")
+
+
 def index_params(k=31, s=21, w=100, x=8, y=4, max_sketch_span=30, threads=0):
     """defaults of `groot index` (cmd/index.go:45-50)"""
     return IndexParams(k, s, w, x, y, max_sketch_span, threads, 0)

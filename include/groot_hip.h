@@ -9,13 +9,17 @@
  *     graphMinion loop             src/pipeline/graphminion.go:46-102
  *     GrootGraph.IncrementSubPath  src/graph/graph.go:401-451   (as exact integer call counts)
  *     GrootGraph.AlignRead         src/graph/alignment.go:13-317
- * A Go host drains its read channel into batches, calls submit/wait/read_*, turns the returned
- * traversal records into sam.Records (it keeps ID/Seq/Qual) and, after the last batch, pulls the
- * call counts and replays IncrementSubPath (groot_host_weights).  INTEGRATION.md has the cgo stub.
+ * The reference streams reads continuously through that loop (boss.go:145-203).  Here a host drains its read channel
+ * into batches and keeps SEVERAL of them in flight in one ctx: groot_hip_submit* enqueues a batch (copy to pinned
+ * staging -> H2D -> kernels -> D2H, each on its own HIP stream), groot_hip_collect blocks for the OLDEST batch and
+ * hands back its traversal records, which the host turns into sam.Records (it keeps ID/Seq/Qual).  After the last batch
+ * the host pulls the IncrementSubPath call counts (summed over GPUs by groot_hip_attempts_allreduce when there are
+ * several) and replays the float formula (groot_host_weights_rows).  cgo/ has the Go binding, INTEGRATION.md the patch.
  *
- * Plain C: pointers and sizes only.  One ctx per GPU; a ctx is used from one host thread at a
- * time, different ctxs may be used concurrently.  Every call returns 0 or a negative GROOT_E_*
- * (include/groot_host.h); groot_hip_last_error(ctx) has the text.  There is no CPU fallback: without
+ * Plain C: pointers and sizes only.  One ctx per GPU; a ctx is used from one host thread at a time, different ctxs
+ * may be used concurrently.  No call retains a caller pointer after it returns (cgo rule), except buffers the ctx itself
+ * handed out (groot_hip_acquire) and the caller-owned table of groot_hip_attempts_layout.  Every call returns 0 or a
+ * negative GROOT_E_* (include/groot_host.h); groot_hip_last_error(ctx) has the text.  There is no CPU fallback: without
  * a usable HIP device groot_hip_open fails with GROOT_E_DEVICE.
  */
 #ifndef GROOT_HIP_H
@@ -41,6 +45,10 @@ typedef struct groot_params {
     uint32_t max_seeds_per_read;    /* initial per-read seed slots (grown automatically); 0 = 8      */
     uint64_t max_batch_bases;       /* 0 = max_batch_reads * max_read_len                            */
     uint32_t keep_sketches;         /* 1: keep every read's KHF sketch on the device (tests)         */
+    uint32_t pipeline_depth;        /* batches that may be in flight (submitted, not yet released); 0 = 3 */
+    uint32_t results_on_device;     /* 1: traversal records stay in HBM (groot_batch_result.d_*), no D2H unless
+                                       groot_hip_read_travs asks; 0 (default): D2H into pinned host memory, overlapped
+                                       with the next batch's kernels                                 */
     uint32_t reserved;
 } groot_params;
 
@@ -65,27 +73,36 @@ typedef struct groot_counts {
     uint64_t short_reads;    /* reads shorter than k (reference panics, boss.go:164-166)             */
 } groot_counts;
 
-/* per-stage device time of the last batch, HIP events on the ctx stream (ms); 0 if profiling off.
- * sketch_seed = the sketch+seed kernel alone; schedule = radix sort of the processing order + record gather;
- * align = the align kernel; sort = ordering of the traversal records into (read, ord) order */
+/* per-stage device time of a batch, HIP events (ms); 0 if profiling off.
+ * h2d = input copy on the copy-in stream; sketch_seed = the sketch+seed kernel alone; schedule = radix sort of the
+ * processing order + record gather; align = the align kernel; sort = ordering of the traversal records into
+ * (read, ord) order; total = first kernel .. last kernel; d2h = result copy on the copy-out stream */
 typedef struct groot_stage_ms {
-    float h2d, sketch_seed, align, sort, total, schedule;
+    float h2d, sketch_seed, align, sort, total, schedule, d2h, unpack;
 } groot_stage_ms;
 
 int groot_hip_device_count(int *n);
 const char *groot_hip_last_error(const groot_ctx *ctx); /* ctx may be NULL: error of a failed open */
 
 /* Uploads (replicates) the index into this GPU's HBM and builds the device lookup structures
- * (what ContainmentIndex.Load / BootstrapLshEnsembleEquiDepth do, lshe.go:95-147). */
+ * (what ContainmentIndex.Load / BootstrapLshEnsembleEquiDepth do, lshe.go:95-147).  The view is checked first
+ * (groot_index_view_check's pass): GROOT_E_FORMAT for one whose indices or offsets do not resolve. */
 int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p);
 void groot_hip_close(groot_ctx *ctx);
 
-/* Run work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own. */
+/* Run the kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own.
+ * Only while nothing is in flight. */
 int groot_hip_set_stream(groot_ctx *ctx, void *hip_stream);
 int groot_hip_set_profiling(groot_ctx *ctx, int enable);
 
-/* Submit one batch of reads held in host memory: seq_concat = read.Seq bytes back to back,
- * seq_off[i]..seq_off[i+1] = read i (n_reads+1 entries).  Copies H2D and launches; asynchronous. */
+/* ---- submitting batches ------------------------------------------------------------------------------------------
+ * Every submit takes a free pipeline slot (GROOT_E_STATE "pipeline full" when pipeline_depth batches are submitted and
+ * not yet released: collect + release first), copies the caller's buffers into the slot's pinned staging, enqueues
+ * H2D -> kernels -> D2H on the ctx's three streams and returns at once.  Batches complete in submission order.
+ * first_read_id only labels the records (groot_trav.read_id = first_read_id + position in the batch); a host that
+ * streams more than 2^32 reads passes 0 and keeps its own 64-bit base.                                              */
+
+/* read.Seq bytes back to back, seq_off[i]..seq_off[i+1] = read i (n_reads+1 entries). */
 int groot_hip_submit(groot_ctx *ctx, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n_reads,
                      uint32_t first_read_id);
 /* Same batch, bases packed 2 bits each: base b of seq_concat sits in bits 2*(b%4).. of packed[b/4] as
@@ -94,35 +111,92 @@ int groot_hip_submit(groot_ctx *ctx, const uint8_t *seq_concat, const uint64_t *
  * the same result (the device unpacks to the byte layout first); groot_host_pack_reads builds the arguments. */
 int groot_hip_submit_packed(groot_ctx *ctx, const uint8_t *packed, const uint64_t *seq_off, uint32_t n_reads,
                             uint32_t first_read_id, const uint64_t *exc_pos, const uint8_t *exc_byte, uint64_t n_exc);
-/* Same, inputs already resident in HBM.  d_seq must be 16-byte aligned and readable for 16 bytes past
+/* The wire format proper: packed bases + one u16 LENGTH per read (the device scans them into offsets) + exceptions:
+ * 27 bytes per 100 bp read over PCIe instead of 108. */
+int groot_hip_submit_packed16(groot_ctx *ctx, const uint8_t *packed, const uint16_t *seq_len, uint32_t n_reads,
+                              uint32_t first_read_id, const uint64_t *exc_pos, const uint8_t *exc_byte, uint64_t n_exc);
+/* Zero-copy producer side of the same format: acquire hands out the pinned staging of a free slot, the caller (a FASTQ
+ * parser) packs straight into it, submit_acquired enqueues it.  Capacities: packed (max_batch_bases+3)/4 bytes,
+ * seq_len max_batch_reads entries, exceptions exc_cap entries (a batch with more goes through
+ * groot_hip_submit_packed16, which grows the staging). */
+typedef struct groot_batch_buffers {
+    uint64_t ticket;       /* pass back to groot_hip_submit_acquired / groot_hip_release */
+    uint8_t *packed;
+    uint16_t *seq_len;
+    uint64_t *exc_pos;
+    uint8_t *exc_byte;
+    uint64_t packed_cap, exc_cap;
+    uint32_t reads_cap, reserved;
+} groot_batch_buffers;
+int groot_hip_acquire(groot_ctx *ctx, groot_batch_buffers *out);
+int groot_hip_submit_acquired(groot_ctx *ctx, uint64_t ticket, uint32_t n_reads, uint64_t n_exc, uint32_t first_read_id);
+/* Inputs already resident in HBM (no staging, no H2D).  d_seq must be 16-byte aligned and readable for 16 bytes past
  * the last base (the kernels load 16-byte / 8-byte words); max_len = longest read of the batch
- * (0 = params.max_read_len). */
+ * (0 = params.max_read_len).  The buffers must stay valid until the batch is collected. */
 int groot_hip_submit_device(groot_ctx *ctx, const void *d_seq, const void *d_seq_off, uint32_t n_reads,
                             uint32_t first_read_id, uint32_t max_len);
-/* Blocks until the submitted batch is finished; counts are for that batch. */
-int groot_hip_wait(groot_ctx *ctx, groot_counts *counts);
 
-/* Results of the finished batch.  *n = number available; at most cap are written. */
-int groot_hip_read_seeds(groot_ctx *ctx, groot_seed *out, uint64_t cap, uint64_t *n);
+/* ---- collecting results -------------------------------------------------------------------------------------------
+ * groot_hip_collect blocks until the OLDEST submitted batch is finished (its D2H included) and describes it; the
+ * pointers stay valid until groot_hip_release(ticket), which frees the slot for another submit.  Several collected
+ * batches may be held at once (e.g. while BAM writer threads work on them).  status = what the reference does with
+ * the batch: GROOT_E_SHORT_READ / GROOT_E_REVCOMP where it panics (results remain readable), GROOT_E_NOSPACE for a
+ * read longer than max_read_len; collect itself returns that status. */
+typedef struct groot_batch_result {
+    uint64_t ticket;
+    uint32_t first_read_id, n_reads;
+    groot_counts counts;
+    const groot_trav *travs;   /* [n_travs] in (read, ord) order; pinned host memory (NULL with results_on_device) */
+    const uint64_t *masks;     /* [n_travs * path_words] */
+    uint64_t n_travs;
+    const void *d_travs;       /* the same two arrays in HBM */
+    const void *d_masks;
+    uint32_t path_words;
+    int32_t status;
+    groot_stage_ms ms;
+} groot_batch_result;
+int groot_hip_collect(groot_ctx *ctx, groot_batch_result *out);
+int groot_hip_release(groot_ctx *ctx, uint64_t ticket);
+int groot_hip_in_flight(groot_ctx *ctx, uint32_t *submitted_not_collected, uint32_t *free_slots);
+
+/* One-batch-at-a-time convenience over the same machinery (tests, simple hosts): wait = collect, the batch is released
+ * by the next submit / wait; read_* copy out of it. */
+int groot_hip_wait(groot_ctx *ctx, groot_counts *counts);
 int groot_hip_read_travs(groot_ctx *ctx, groot_trav *out, uint64_t *masks /* [cap*path_words] */, uint64_t cap,
                          uint64_t *n);
+/* seeds / sketches live in the ctx's shared work buffers: readable only while the waited batch is the newest one
+ * submitted (GROOT_E_STATE otherwise) */
+int groot_hip_read_seeds(groot_ctx *ctx, groot_seed *out, uint64_t cap, uint64_t *n);
 int groot_hip_read_sketches(groot_ctx *ctx, uint64_t *out /* [cap_reads*sketch_size] */, uint64_t cap_reads,
                             uint64_t *n_reads);
 int groot_hip_stage_ms(groot_ctx *ctx, groot_stage_ms *out);
 
-/* IncrementSubPath call counts accumulated over every batch since open/reset:
- * counts[q * n_windows + w], q = kmerCount of the read in [0, n_q).  The device pointer variant lets
- * a host reduce them across GPUs (RCCL all-reduce) without a round trip. */
-int groot_hip_attempts_shape(groot_ctx *ctx, uint32_t *n_q, uint32_t *n_windows);
-int groot_hip_attempts_device(groot_ctx *ctx, void **d_counts_u32, uint64_t *n_elems);
-int groot_hip_attempts_read(groot_ctx *ctx, uint32_t *out, uint64_t n_elems);
+/* ---- IncrementSubPath call counts ---------------------------------------------------------------------------------
+ * Accumulated over every batch since open/reset in a table [rows][n_windows] of uint32, one row per kmerCount
+ * (len-k+1, graphminion.go:60) that occurred among seeded reads -- 1.3 MB per distinct read length on arg-annot.90,
+ * not (max_read_len-k+2) rows.  Rows are created on the device as kmerCounts show up.                               */
+/* rows in ascending kmerCount order: q_values[i] and counts[i*n_windows ..]; *n_rows = rows available, at most
+ * cap_rows are written.  Waits for everything in flight. */
+int groot_hip_attempts_export(groot_ctx *ctx, uint32_t *q_values, uint32_t *counts, uint32_t cap_rows, uint32_t *n_rows,
+                              uint32_t *n_windows);
+/* Fixes the row layout: row i holds kmerCount q_values[i] (strictly ascending; must include every kmerCount that has
+ * counts).  d_table NULL: ctx-owned storage (still grows if a new kmerCount appears).  d_table != NULL: the table
+ * lives in that caller-owned device buffer of n_q*n_windows uint32 (e.g. a torch tensor that is all-reduced over RCCL
+ * afterwards); existing counts are copied into it; a kmerCount outside the layout then fails the batch with
+ * GROOT_E_NOSPACE.  Only while nothing is in flight. */
+int groot_hip_attempts_layout(groot_ctx *ctx, const uint32_t *q_values, uint32_t n_q, void *d_table);
+int groot_hip_attempts_device(groot_ctx *ctx, void **d_table, uint32_t *n_rows, uint32_t *n_windows);
 int groot_hip_attempts_reset(groot_ctx *ctx);
-/* Accumulate into a caller-owned device buffer of n_q*n_windows uint32 (e.g. a torch tensor that is
- * all-reduced over RCCL afterwards) instead of the ctx's own; NULL = back to the ctx's buffer. */
-int groot_hip_attempts_bind(groot_ctx *ctx, void *d_counts_u32, uint64_t n_elems);
+/* SURVEY 8e / north_star: the one exchange of a multi-GPU run.  Brings every ctx to the union row layout and sums the
+ * tables in place over RCCL (ncclAllReduce, one communicator over the ctxs' devices, xGMI on an MI355X node); ctxs that
+ * share a device are summed by a kernel instead.  Afterwards every ctx holds the totals.  All ctxs must be idle. */
+int groot_hip_attempts_allreduce(groot_ctx *const *ctxs, int n_ctx);
+/* dense compatibility view: counts[q * n_windows + w], q in [0, max_read_len-k+2) */
+int groot_hip_attempts_shape(groot_ctx *ctx, uint32_t *n_q, uint32_t *n_windows);
+int groot_hip_attempts_read(groot_ctx *ctx, uint32_t *out, uint64_t n_elems);
 
 /* Fine-grained mirror of Sequence.RunMinHash(k, s, false, nil) (seqio.go:40-68) for a batch of
- * sequences in host memory: out[i*s .. (i+1)*s) = KHF sketch of sequence i. */
+ * sequences in host memory: out[i*s .. (i+1)*s) = KHF sketch of sequence i.  Only while nothing is in flight. */
 int groot_hip_sketch(groot_ctx *ctx, const uint8_t *seq_concat, const uint64_t *seq_off, uint32_t n, uint64_t *out);
 
 #ifdef __cplusplus

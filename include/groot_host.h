@@ -90,6 +90,11 @@ int groot_index_save_gob(const groot_index *idx, const char *dir, uint32_t max_s
  * text is written only when cap >= *needed. */
 int groot_gob_to_json(const uint8_t *data, uint64_t n, char *out, uint64_t cap, uint64_t *needed);
 void groot_index_get_view(const groot_index *idx, groot_index_view *view);
+/* One O(n) consistency pass over a view (every node / edge / path / window index in range, offset arrays monotone and
+ * ending at their payload, path_words wide enough): GROOT_E_FORMAT with the first inconsistency in
+ * groot_host_last_error().  groot_index_load / groot_index_load_gob run it on what they read, groot_hip_open runs the
+ * same pass on the view it is given before anything is uploaded. */
+int groot_index_view_check(const groot_index_view *view);
 void groot_index_free(groot_index *idx);
 
 /* fine-grained mirror of Sequence.RunMinHash(k, s, false, nil) (src/seqio/seqio.go:40-68) used by
@@ -138,6 +143,10 @@ int groot_host_expand_alns(const groot_index_view *idx, const groot_trav *travs,
  * window ascending, kmerCount ascending, one floating-point add per call. */
 int groot_host_weights(const groot_index_view *idx, const uint32_t *attempts, uint32_t n_q,
                        double *node_kmer_freq /*[n_nodes]*/, uint64_t *graph_kmer_total /*[n_graphs]*/);
+/* The same replay from the compact table of groot_hip_attempts_export: row r holds the call counts of kmerCount
+ * q_values[r] (strictly ascending), counts[r * n_windows + w]. */
+int groot_host_weights_rows(const groot_index_view *idx, const uint32_t *q_values, uint32_t n_rows, const uint32_t *counts,
+                            double *node_kmer_freq /*[n_nodes]*/, uint64_t *graph_kmer_total /*[n_graphs]*/);
 /* GrootGraph.Prune (graph.go:455-525) over every graph */
 int groot_host_prune(const groot_index_view *idx, const double *node_kmer_freq, double min_kmer_cov,
                      uint8_t *graph_kept /*[n_graphs]*/, uint8_t *path_kept /*[n_paths]*/,

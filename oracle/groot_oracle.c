@@ -714,6 +714,9 @@ int oracle_run_batch(oracle_run *r, const uint8_t *seq, const uint64_t *seq_off,
 }
 
 void oracle_run_counts(const oracle_run *r, oracle_counts *c) { *c = r->counts; }
+/* streaming use (the timed CPU baseline): forget the per-read outputs collected so far, keep the counters, the
+ * call counts and the buffers' capacity -- the reference writes its records to the BAM and drops them too */
+void oracle_run_drop_records(oracle_run *r) { r->seeds.n = 0; r->alns.n = 0; r->sketches.n = 0; }
 uint64_t oracle_run_seeds(const oracle_run *r, const oracle_seed **out) { *out = r->seeds.p; return r->seeds.n; }
 uint64_t oracle_run_alns(const oracle_run *r, const oracle_aln **out) { *out = r->alns.p; return r->alns.n; }
 uint64_t oracle_run_sketches(const oracle_run *r, const uint64_t **out) { *out = r->sketches.p; return r->sketches.n; }

@@ -118,6 +118,8 @@ void oracle_run_free(oracle_run *);
 int oracle_run_batch(oracle_run *, const uint8_t *seq, const uint64_t *seq_off, uint32_t n_reads,
                      uint32_t first_read_id);
 void oracle_run_counts(const oracle_run *, oracle_counts *);
+/* streaming use (bench.py's cpu_baseline): drop the seeds / records / sketches collected so far; counters, call counts stay */
+void oracle_run_drop_records(oracle_run *);
 uint64_t oracle_run_seeds(const oracle_run *, const oracle_seed **out);
 uint64_t oracle_run_alns(const oracle_run *, const oracle_aln **out);
 uint64_t oracle_run_sketches(const oracle_run *, const uint64_t **out); /* n_reads*s */

@@ -51,6 +51,8 @@ def lib():
         L.oracle_run_new.restype = C.c_void_p
         L.oracle_run_new.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.oracle_run_free.argtypes = [C.c_void_p]
+        L.oracle_run_drop_records.argtypes = [C.c_void_p]
+        L.oracle_run_drop_records.restype = None
         L.oracle_run_seeds.restype = C.c_uint64
         L.oracle_run_alns.restype = C.c_uint64
         L.oracle_run_sketches.restype = C.c_uint64
@@ -158,6 +160,10 @@ class Run:
                                     C.c_uint32(first_read_id))
         if rc:
             raise ValueError("read shorter than k (reference panics, boss.go:164-166)")
+
+    def drop_records(self):
+        """streaming use: forget the per-read outputs collected so far (counters and call counts stay)"""
+        lib().oracle_run_drop_records(self.h)
 
     def counts(self):
         c = OracleCounts()

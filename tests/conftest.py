@@ -54,7 +54,7 @@ def argannot_index(msa_dir):
     """arg-annot.90 with the `groot index` defaults k=31 s=21 w=100 x=8 y=4 (cmd/index.go:45-49)"""
     from groot_amd import host
 
-    cache = os.path.join(REPO, "build", "arg-annot.90.k31.s21.w100.gidx")
+    cache = host.index_cache_path("arg-annot.90.k31.s21.w100")
     if os.path.exists(cache):
         try:
             return host.Index.load(cache)

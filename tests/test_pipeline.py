@@ -1,0 +1,221 @@
+"""The pipelined boundary (submit / collect-the-oldest, several batches in flight in ONE ctx) and the compact
+call-count table, against the one-batch-at-a-time path and the CPU oracle.  The reference seam is the continuous
+stream of boss.go:145-203; what must hold is that batching, pipelining and the wire format change nothing."""
+import numpy as np
+import pytest
+
+from groot_amd import device, host, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(hip_lib):
+    assert device.device_count() > 0, "no MI355X visible: the HIP path has no CPU fallback"
+
+
+def make_batches(index, n_batches, n, min_len=None, read_len=100):
+    cat, o, lens = synth.reference_sequences(index)
+    out = []
+    for b in range(n_batches):
+        seq, off, _ = synth.reads_np(cat, o, lens, n + 37 * b, read_len, first=b * 100_000, min_len=min_len)
+        out.append((seq, off))
+    return out
+
+
+def oracle_of(index, batches, threshold=0.99):
+    run = O.Run(index, threshold)
+    first = 0
+    per = []
+    for seq, off in batches:
+        before = len(run.alns())
+        run.batch(seq, off, first_read_id=first)
+        per.append(run.alns()[before:])
+        first += len(off) - 1
+    return run, per
+
+
+def wire(seq, off):
+    packed, exc_pos, exc_byte = host.pack_reads(seq)
+    return packed, np.diff(off.astype(np.int64)).astype(np.uint16), exc_pos, exc_byte
+
+
+def test_three_in_flight_equal_oracle_and_serial(small_index):
+    batches = make_batches(small_index, 7, 1500)
+    run, per = oracle_of(small_index, batches)
+    al = device.Aligner(small_index, max_batch_reads=4096, pipeline_depth=3)
+    got, counts = [], []
+    first = 0
+    firsts = []
+    for i, (seq, off) in enumerate(batches):
+        pk, ln, ep, eb = wire(seq, off)
+        if i % 3 == 0:
+            al.submit_packed16(pk, ln, ep, eb, first_read_id=first)          # the wire format, copied into staging
+        elif i % 3 == 1:
+            b = al.acquire()                                                  # zero-copy producer side of the same format
+            b["packed"][: len(pk)] = pk
+            b["seq_len"][: len(ln)] = ln
+            b["exc_pos"][: len(ep)] = ep
+            b["exc_byte"][: len(eb)] = eb
+            al.submit_acquired(b["ticket"], len(ln), len(ep), first_read_id=first)
+        else:
+            al.submit(seq, off, first_read_id=first)                          # ASCII + u64 offsets
+        firsts.append(first)
+        first += len(off) - 1
+        if al.in_flight()[0] == 3:
+            r = al.collect()
+            got.append(r); al.release(r["ticket"])
+    while al.in_flight()[0]:
+        r = al.collect()
+        got.append(r); al.release(r["ticket"])
+    assert [r["first_read_id"] for r in got] == firsts                        # oldest first
+    for r, exp, (seq, off) in zip(got, per, batches):
+        assert r["status"] == 0 and r["n_reads"] == len(off) - 1
+        recs = device.expand_alns(small_index, r["travs"], r["masks"])
+        assert len(recs) == len(exp)
+        for f in exp.dtype.names:
+            assert np.array_equal(recs[f], exp[f]), f
+    tot = {k: sum(r["counts"][k] for r in got) for k in ("received", "mapped", "multimapped", "alignments", "seeds")}
+    oc = run.counts()
+    assert all(tot[k] == oc[k] for k in tot)
+    att, oatt = al.attempts(), run.attempts()
+    assert np.array_equal(att[: oatt.shape[0]], oatt) and not att[oatt.shape[0]:].any()
+    # a fourth submit without collecting is refused, nothing is lost
+    for seq, off in batches[:3]:
+        al.submit(seq, off)
+    with pytest.raises(host.GrootError) as e:
+        al.submit(*batches[3])
+    assert e.value.code == -9
+    for _ in range(3):
+        al.release(al.collect()["ticket"])
+    al.close()
+
+
+def test_held_results_survive_later_batches(small_index):
+    """collected batches stay valid until released, whatever runs meanwhile (BAM writer threads work on them)"""
+    batches = make_batches(small_index, 4, 2000)
+    _, per = oracle_of(small_index, batches[:1])
+    al = device.Aligner(small_index, max_batch_reads=4096, pipeline_depth=3)
+    al.submit(*batches[0])
+    held = al.collect(copy=False)
+    for seq, off in batches[1:3]:
+        al.submit(seq, off)
+    for _ in range(2):
+        al.release(al.collect()["ticket"])
+    al.submit(*batches[3])
+    al.release(al.collect()["ticket"])
+    recs = device.expand_alns(small_index, held["travs"], held["masks"])
+    assert len(recs) == len(per[0]) and all(np.array_equal(recs[f], per[0][f]) for f in per[0].dtype.names)
+    al.release(held["ticket"])
+    with pytest.raises(host.GrootError):
+        al.release(held["ticket"])
+    al.close()
+
+
+def test_call_count_table_has_one_row_per_kmer_count(small_index):
+    """mixed read lengths: rows appear on the device as kmerCounts do (more than the initial capacity: the table grows and
+    the batch is redone), the export is ascending, and the replay equals the dense one and the oracle's"""
+    cat, o, lens = synth.reference_sequences(small_index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 6000, 150, min_len=60)
+    run = O.Run(small_index, 0.97)
+    run.batch(seq, off)
+    al = device.Aligner(small_index, threshold=0.97, max_batch_reads=8192, max_read_len=160)
+    al.submit(seq, off)
+    c = al.wait()
+    assert c["seeds"] == run.counts()["seeds"]
+    q, rows = al.attempts_rows()
+    assert len(q) > 4 and np.all(np.diff(q.astype(np.int64)) > 0)
+    oatt = run.attempts()
+    dense = al.attempts()
+    assert np.array_equal(dense[: oatt.shape[0]], oatt)
+    assert np.array_equal(rows, dense[q])
+    assert set(q.tolist()) == set(np.nonzero(oatt.any(axis=1))[0].tolist())
+    kf, kt = device.weights_rows(small_index, q, rows)
+    okf, okt = run.weights(order=1)
+    assert np.array_equal(kf, okf) and np.array_equal(kt, okt)
+    # a second batch accumulates into the same rows
+    al.submit(seq, off)
+    al.wait()
+    q2, rows2 = al.attempts_rows()
+    assert np.array_equal(q2, q) and np.array_equal(rows2, 2 * rows)
+    al.close()
+
+
+def test_allreduce_over_ctxs_and_fixed_layout(small_index):
+    """groot_hip_attempts_allreduce: two ctxs (here on one device: summed by a kernel; on distinct devices: RCCL) end up
+    with the union layout and the totals; a caller-owned table (the torch tensor bench.py all-reduces) holds the counts"""
+    import torch
+
+    cat, o, lens = synth.reference_sequences(small_index)
+    a_seq, a_off, _ = synth.reads_np(cat, o, lens, 3000, 100)
+    b_seq, b_off, _ = synth.reads_np(cat, o, lens, 2500, 120, first=50_000, min_len=90)
+    run = O.Run(small_index)
+    run.batch(a_seq, a_off)
+    run.batch(b_seq, b_off, first_read_id=3000)
+    als = [device.Aligner(small_index, max_batch_reads=4096) for _ in range(2)]
+    als[0].submit(a_seq, a_off); als[0].wait()
+    als[1].submit(b_seq, b_off); als[1].wait()
+    device.attempts_allreduce(als)
+    oatt = run.attempts()
+    for al in als:
+        dense = al.attempts()
+        assert np.array_equal(dense[: oatt.shape[0]], oatt)
+    q0, r0 = als[0].attempts_rows()
+    q1, r1 = als[1].attempts_rows()
+    assert np.array_equal(q0, q1) and np.array_equal(r0, r1)
+    for al in als:
+        al.close()
+    # fixed layout in a caller-owned buffer
+    al = device.Aligner(small_index, max_batch_reads=4096)
+    nw = al.attempts_shape()[1]
+    table = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    al.attempts_layout([70], table.data_ptr())
+    al.submit(a_seq, a_off); al.wait()
+    run_a = O.Run(small_index)
+    run_a.batch(a_seq, a_off)
+    assert np.array_equal(table.cpu().numpy().astype(np.uint32), run_a.attempts()[70])
+    al.submit(b_seq, b_off)                     # kmerCounts outside the fixed layout: refused, not dropped silently
+    with pytest.raises(host.GrootError) as e:
+        al.wait()
+    assert e.value.code == -6
+    al.close()
+
+
+def test_results_on_device_and_legacy_reads(small_index):
+    batches = make_batches(small_index, 2, 1800)
+    _, per = oracle_of(small_index, batches[:1])
+    al = device.Aligner(small_index, max_batch_reads=4096, results_on_device=True, keep_sketches=True)
+    al.submit(*batches[0])
+    al.wait()
+    recs = al.alns()                           # read_travs copies out of HBM on demand
+    assert len(recs) == len(per[0]) and all(np.array_equal(recs[f], per[0][f]) for f in per[0].dtype.names)
+    seeds0 = al.seeds()
+    assert len(seeds0)
+    # seeds / sketches live in the shared work buffers: gone once a newer batch has been submitted
+    al.submit(*batches[0]); al.submit(*batches[1])
+    al.wait()
+    with pytest.raises(host.GrootError) as e:
+        al.seeds()
+    assert e.value.code == -9
+    al.wait()
+    assert len(al.seeds())
+    al.close()
+
+
+def test_corrupt_view_is_refused(small_index):
+    """groot_hip_open runs the consistency pass before uploading anything"""
+    import copy
+    import ctypes as C
+
+    v = copy.copy(small_index.view)
+    bad = small_index.arrays["edges"].copy()
+    bad[0] = 0xFFFFFFF0
+    v.edges = bad.ctypes.data_as(C.POINTER(C.c_uint32))
+
+    class Fake:
+        view = v
+
+    with pytest.raises(host.GrootError) as e:
+        device.Aligner(Fake, max_batch_reads=1024)
+    assert e.value.code == -3

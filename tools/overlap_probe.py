@@ -16,7 +16,7 @@ def main():
     import bench
     from groot_amd import device, synth
     dev = torch.device("cuda", 0)
-    index = bench.load_index()
+    index, _ = bench.load_index()
     cat, off, lens = synth.reference_sequences(index)
     cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, off, lens))
     R, L = args.reads, bench.READ_LEN

@@ -19,7 +19,7 @@ def main():
     from oracle import oracle_py as O
     from test_gpu_parity import assert_same, run_both
 
-    index = bench.load_index()
+    index, _ = bench.load_index()
     cat, o, lens = synth.reference_sequences(index)
     comp = bytes.maketrans(b"ACGTN", b"TGCAN")
     for seed in range(n_seeds):

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from groot_amd import device, synth
 dev = torch.device("cuda", 0)
-index = bench.load_index()
+index, _ = bench.load_index()
 cat, off, lens = synth.reference_sequences(index)
 cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, off, lens))
 R, L = 2_000_000, 100
