@@ -113,6 +113,8 @@ def host_fed(index, d_seq, R, steps, depth=3):
     lens = np.full(R, READ_LEN, dtype=np.uint16)
     al = device.Aligner(index, device=torch.cuda.current_device(), max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
                         pipeline_depth=depth)
+    al.set_profiling(True)
+    stage = {}
     bufs = [al.acquire() for _ in range(depth)]
     for b in bufs:
         b["packed"][: len(packed)] = packed
@@ -137,16 +139,21 @@ def host_fed(index, d_seq, R, steps, depth=3):
         if al.in_flight()[0] == depth:
             r = al.collect(copy=False)
             trav_bytes += r["n_travs"] * (20 + 8 * index.view.path_words)
+            for k, v in r["ms"].items():
+                stage[k] = stage.get(k, 0.0) + v
             al.release(r["ticket"])
             done += 1
     while done < steps:
         r = al.collect(copy=False)
         trav_bytes += r["n_travs"] * (20 + 8 * index.view.path_words)
+        for k, v in r["ms"].items():
+            stage[k] = stage.get(k, 0.0) + v
         al.release(r["ticket"])
         done += 1
     dt = time.perf_counter() - t0
     out = {"value": steps * R / dt / 1e6, "unit": "Mreads/s", "steps": steps, "batches_in_flight": depth, "ms_per_batch": dt / steps * 1e3,
            "h2d_bytes_per_read": (len(packed) + 2 * R + 9 * len(exc_pos)) / R, "d2h_bytes_per_read": trav_bytes / (steps * R),
+           "stage_ms_per_batch": {k: v / steps for k, v in stage.items()},
            "what": "one ctx, one index replica: pinned staging -> H2D (2-bit bases + u16 lengths) -> kernels -> D2H of the traversal "
                    "records into pinned host memory; first submit -> last collect"}
     # the plain-ASCII entry point with pageable caller memory (what a cgo caller handing over Go slices gets)

@@ -6,9 +6,11 @@
 //        cmd/align.go:30-197 + src/pipeline/sketch.go (DataStreamer..GraphPruner): BAM on stdout, weighted GFAs in
 //        graphDir, the reference's log lines in --log (default groot.log)
 //
-// Extra flags: --gpu <id> (device), --batch <reads> (reads per device batch), --bam <file> (Info.Sketch.BAMout).
+// Extra flags: --gpu <id> (device) or --gpus <N> (reads shard over N GPUs), --batch <reads> (reads per device batch),
+// --maxReadLen, --bam <file> (Info.Sketch.BAMout), --bamLevel, --stats <json>; index: --writeGob.
 // The align hot path runs only on the GPU: no device -> error, never a CPU fallback.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +18,9 @@
 #include <condition_variable>
 #include <cstring>
 #include <ctime>
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -61,9 +66,11 @@ struct Args {
     double cov_cutoff = 0.97;
     bool low_cov = false;
     std::vector<std::string> fastq;
-    int proc = 1, gpu = 0;
-    bool gpu_given = false;
-    uint32_t k = 31, s = 21, w = 100, x = 8, y = 4, max_span = 30, batch = 1u << 20;
+    int proc = 1, gpu = 0, gpus = 0, ctx_per_gpu = 1, bam_level = -1;
+    bool gpu_given = false, write_gob = false;
+    uint32_t k = 31, s = 21, w = 100, x = 8, y = 4, max_span = 30, batch = 1u << 20, max_read_len = 512, depth = 3;
+    uint64_t block_bytes = 0;
+    std::string stats_file;
     double threshold = 0.99, min_kmer_cov = 1.0;
     bool no_align = false, fasta = false;
 };
@@ -87,8 +94,10 @@ void usage()
             "groot-hip %s (MI355X-native groot align hot path)\n\n"
             "  groot-hip index -m <msaDir> -i <indexDir> [-k 31] [-s 21] [-w 100] [-x 8] [-y 4] [--maxSketchSpan 30] [-p N] [--log F]\n"
             "                  [--gpu 0]      (sketch the graph windows on that GPU instead of the host)\n"
+            "                  [--writeGob]   (also write the reference's groot.gg + groot.lshe: experimental, unpinned against a Go-written file)\n"
             "  groot-hip align -i <indexDir> -f <fastq>[,<fastq>...] [-t 0.99] [-c 1.0] [-g <graphDir>] [--noAlign] [-p N] [--log F]\n"
-            "                  [--gpu 0] [--batch 1048576] [--bam out.bam]      (BAM goes to stdout unless --bam)\n"
+            "                  [--gpu 0 | --gpus N] [--batch 1048576] [--maxReadLen 512] [--bam out.bam] [--bamLevel -1..9] [--stats f.json]\n"
+            "                  (BAM goes to stdout unless --bam; --gpus N shards the reads over N GPUs, index replicated)\n"
             "  groot-hip report [--bamFile x.bam] [-c 0.97] [--lowCov] [--log F]      (BAM from stdin unless --bamFile)\n",
             groot_host_version());
 }
@@ -131,6 +140,14 @@ Args parse(int argc, char **argv)
         else if (f == "--profiling") {}
         else if (f == "--gpu") { a.gpu = atoi(v().c_str()); a.gpu_given = true; }
         else if (f == "--batch") a.batch = (uint32_t)atol(v().c_str());
+        else if (f == "--gpus") a.gpus = atoi(v().c_str());
+        else if (f == "--ctxPerGpu") a.ctx_per_gpu = std::max(1, atoi(v().c_str()));
+        else if (f == "--maxReadLen") a.max_read_len = (uint32_t)atol(v().c_str());
+        else if (f == "--depth") a.depth = (uint32_t)atol(v().c_str());
+        else if (f == "--bamLevel") a.bam_level = atoi(v().c_str());
+        else if (f == "--blockBytes") a.block_bytes = (uint64_t)atoll(v().c_str());
+        else if (f == "--stats") a.stats_file = v();
+        else if (f == "--writeGob") a.write_gob = true;
         else if (f == "--bam") a.bam_out = v();
         else if (f == "-h" || f == "--help") { usage(); exit(0); }
         else { fprintf(stderr, "unknown flag: %s\n", f.c_str()); usage(); exit(1); }
@@ -232,14 +249,78 @@ int run_index(const Args &a)   // cmd/index.go:57-133
     const std::string out = a.index_dir + "/groot.gidx";
     logf("writing index files in \"%s\"...", a.index_dir.c_str());
     if (groot_index_save(idx, out.c_str())) die("%s", groot_host_last_error());
-    // and the reference's own files (cmd/index.go:130-131), so that `groot align|haplotype` can use this directory too
-    if (groot_index_save_gob(idx, a.index_dir.c_str(), a.max_span)) die("%s", groot_host_last_error());
+    // the reference's own files (cmd/index.go:130-131) only on request: no Go-written groot.gg / groot.lshe has been
+    // round-tripped yet, so a layout or hash-constant slip would make the reference mis-seed silently
+    if (a.write_gob) {
+        logf("\twriting groot.gg + groot.lshe (experimental: not yet checked against files written by the reference)");
+        if (groot_index_save_gob(idx, a.index_dir.c_str(), a.max_span)) die("%s", groot_host_last_error());
+    }
     groot_index_free(idx);
     logf("finished in %.3fs", seconds_since(t0));
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
+// align: parse | map | write as three overlapping stages.
+//   producer thread   groot_reads_next: FASTQ text -> parsed + packed batches (reader thread per file, parse over -p cores)
+//   mapper threads    one per GPU: groot_hip_submit_packed16 / groot_hip_collect, several batches in flight per ctx
+//   writer thread     batches back in input order: traversal records -> sam.Records -> BGZF over -p cores
+// The reference's pipeline has the same shape with goroutines and channels (DataStreamer -> FastqHandler -> ReadMapper with
+// its bamwriter goroutine, sketch.go:41-350, boss.go:86-104); reads shard over the GPUs batch by batch, the index is
+// replicated, and the only exchange is the sum of the IncrementSubPath call counts at the end (RCCL).
+struct WorkItem {
+    uint64_t seq = 0;                 // position of the batch in the input
+    groot_reads_batch *batch = nullptr;
+    groot_reads_view view{};
+    // filled by the mapper
+    int gpu = -1;
+    groot_batch_result res{};
+};
+
+template <class T> struct BoundedQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<T> q;
+    size_t cap;
+    bool closed = false;
+    explicit BoundedQueue(size_t c) : cap(c) {}
+    void push(T v)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return q.size() < cap; });
+        q.push_back(std::move(v));
+        cv.notify_all();
+    }
+    // 1 = got one, 0 = none right now (only when !block), -1 = closed and empty
+    int pop(T &out, bool block)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (block) cv.wait(lk, [&] { return !q.empty() || closed; });
+        if (q.empty()) return closed ? -1 : 0;
+        out = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return 1;
+    }
+    void close()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        closed = true;
+        cv.notify_all();
+    }
+};
+
+struct Gpu {
+    int device = 0;
+    groot_ctx *ctx = nullptr;
+    uint32_t max_read_len = 0;
+    std::mutex mu;                    // tickets the writer is done with (the ctx itself belongs to the mapper thread)
+    std::condition_variable cv;
+    std::vector<uint64_t> done_tickets;
+    uint32_t held = 0, inflight = 0;
+    std::deque<WorkItem> pending;     // submitted, in order
+};
+
 int run_align(const Args &a)   // cmd/align.go:54-163
 {
     if (a.index_dir.empty()) { puts("please specify a directory with the index files (--indexDir)"); return 1; }
@@ -291,131 +372,251 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     logf("loading the graphs...");
     logf("\tnumber of variation graphs: %u", v.n_graphs);
     logf("rebuilding the LSH Ensemble...");
-    groot_params prm;
-    groot_params_default(&prm);
-    prm.containment_threshold = a.threshold;
-    prm.no_exact_align = a.no_align ? 1 : 0;
-    prm.max_batch_reads = a.batch;
-    prm.max_read_len = 512;
-    groot_ctx *ctx = nullptr;
-    if (groot_hip_open(&ctx, a.gpu, &v, &prm)) die("%s", groot_hip_last_error(nullptr));
+    // ---- one ctx per GPU (index replicated), opened concurrently ----
+    int n_dev = 0;
+    if (groot_hip_device_count(&n_dev) || n_dev == 0) die("no HIP device available (groot-hip align has no CPU fallback): %s", groot_hip_last_error(nullptr));
+    std::vector<int> devices;
+    if (a.gpus > 0) {
+        if (a.gpus > n_dev) die("--gpus %d but only %d device(s) visible", a.gpus, n_dev);
+        for (int i = 0; i < a.gpus; i++) devices.push_back(i);
+    } else devices.push_back(a.gpu);
+    for (int extra = 1; extra < a.ctx_per_gpu; extra++)          // test hook: several ctxs on one device (exercises the N>1 path on a one-GPU box)
+        for (size_t i = 0, n = devices.size() / (size_t)extra; i < n; i++) devices.push_back(devices[i]);
+    const uint32_t depth = std::max(2u, a.depth);
+    auto params_for = [&](uint32_t max_read_len) {
+        groot_params prm;
+        groot_params_default(&prm);
+        prm.containment_threshold = a.threshold;
+        prm.no_exact_align = a.no_align ? 1 : 0;
+        prm.max_batch_reads = a.batch;
+        prm.max_read_len = max_read_len;
+        prm.max_batch_bases = (uint64_t)a.batch * std::min<uint32_t>(max_read_len, 512);
+        prm.pipeline_depth = depth;
+        return prm;
+    };
+    std::vector<std::unique_ptr<Gpu>> gpus;
+    for (int d : devices) {
+        std::unique_ptr<Gpu> g(new Gpu());
+        g->device = d; g->max_read_len = a.max_read_len;
+        gpus.push_back(std::move(g));
+    }
+    {
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(gpus.size());
+        for (size_t i = 0; i < gpus.size(); i++)
+            th.emplace_back([&, i]() {
+                groot_params prm = params_for(gpus[i]->max_read_len);
+                if (groot_hip_open(&gpus[i]->ctx, gpus[i]->device, &v, &prm)) errs[i] = groot_hip_last_error(nullptr);
+            });
+        for (auto &t : th) t.join();
+        for (auto &e : errs) if (!e.empty()) die("%s", e.c_str());
+    }
+    const uint64_t max_batch_bases = (uint64_t)a.batch * std::min<uint32_t>(a.max_read_len, 512);
     logf("\tcontainment threshold: %.2f", a.threshold);
     if (a.no_align) logf("\tprevent exact alignments and using approximated mapping only");
     logf("initialising alignment pipeline...");
     logf("\tinitialising the processes");
     logf("\tconnecting data streams");
     logf("\tnumber of processes added to the alignment pipeline: 5");
+    if (gpus.size() > 1) logf("\treads shard over %zu GPU contexts (index replicated)", gpus.size());
+    const double load_s = seconds_since(t0);
 
     groot_bam *bam = nullptr;
     if (!a.no_align && groot_bam_open(a.bam_out.empty() ? nullptr : a.bam_out.c_str(), &v, nullptr, &bam)) die("%s", groot_host_last_error());
-    if (bam) groot_bam_set_threads(bam, a.proc > 0 ? (uint32_t)a.proc : 0);   // -p: BGZF write concurrency
+    const uint32_t cores = a.proc > 0 ? (uint32_t)a.proc : 0;
+    if (bam) { groot_bam_set_threads(bam, cores); if (groot_bam_set_level(bam, a.bam_level)) die("%s", groot_host_last_error()); }
 
     std::vector<const char *> files;
     for (auto &f : a.fastq) files.push_back(f.c_str());
-    groot_fastq *fq = nullptr;
-    if (groot_fastq_open(files.empty() ? nullptr : files.data(), (uint32_t)files.size(), &fq)) die("%s", groot_host_last_error());
+    groot_reads *reads = nullptr;
+    if (groot_reads_open(files.empty() ? nullptr : files.data(), (uint32_t)files.size(), cores, a.block_bytes, a.batch, max_batch_bases, &reads))
+        die("%s", groot_host_last_error());
     logf("now streaming reads...");
+    auto t_stream = std::chrono::steady_clock::now();
 
-    // DataStreamer/FastqHandler run ahead of the mapper (the reference connects them with buffered channels,
-    // pipeline.go:5): a reader thread parses batch i+1 while batch i is on the GPU and in the BAM writer
-    const uint64_t seq_cap = (uint64_t)a.batch * prm.max_read_len, name_cap = (uint64_t)a.batch * 256;
-    struct Batch {
-        std::vector<uint8_t> seq, qual;
-        std::vector<char> names;
-        std::vector<uint64_t> seq_off, name_off;
-        int64_t n = 0;
-        std::string err;
-    } bufs[2];
-    for (auto &bf : bufs) {
-        bf.seq.resize(seq_cap); bf.qual.resize(seq_cap); bf.names.resize(name_cap);
-        bf.seq_off.resize(a.batch + 1); bf.name_off.resize(a.batch + 1);
-    }
-    std::mutex mu;
-    std::condition_variable cv;
-    int filled[2] = {0, 0};      // 0 = free for the reader, 1 = ready for the mapper
-    bool reader_done = false;
-    std::thread reader([&]() {
-        for (int slot = 0;; slot ^= 1) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return filled[slot] == 0; });
-            }
-            Batch &bf = bufs[slot];
-            bf.n = groot_fastq_next_batch(fq, a.batch, bf.seq.data(), bf.qual.data(), bf.seq_off.data(), seq_cap, bf.names.data(),
-                                          bf.name_off.data(), name_cap);
-            if (bf.n < 0) bf.err = groot_host_last_error();
-            const bool last = bf.n <= 0;
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                filled[slot] = 1;
-                if (last) reader_done = true;
-            }
-            cv.notify_all();
-            if (last) break;
+    BoundedQueue<WorkItem> parsed(gpus.size() + 2);
+    BoundedQueue<WorkItem> mapped(gpus.size() * depth + 2);
+    std::mutex fatal_mu;
+    std::string fatal;
+    std::atomic<bool> failed{false};
+    auto fail_with = [&](const std::string &msg) {
+        std::lock_guard<std::mutex> lk(fatal_mu);
+        if (fatal.empty()) fatal = msg;
+        failed = true;
+        parsed.close(); mapped.close();
+        for (auto &g : gpus) { std::lock_guard<std::mutex> l2(g->mu); g->cv.notify_all(); }
+    };
+
+    std::atomic<uint64_t> length_total{0};
+    std::thread producer([&]() {
+        uint64_t seq = 0;
+        for (;;) {
+            if (failed) break;
+            WorkItem w;
+            if (groot_reads_next(reads, &w.batch)) { fail_with(groot_host_last_error()); break; }
+            if (!w.batch) break;
+            groot_reads_batch_view(w.batch, &w.view);
+            length_total += w.view.n_bases;
+            w.seq = seq++;
+            parsed.push(std::move(w));
         }
+        parsed.close();
     });
-    std::vector<groot_trav> travs;
-    std::vector<uint64_t> masks;
-    uint64_t received = 0, length_total = 0, mapped = 0, multimapped = 0, alignments = 0;
-    uint32_t first_id = 0;
-    for (int slot = 0;; slot ^= 1) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return filled[slot] == 1; });
+
+    std::atomic<int> mappers_left{(int)gpus.size()};
+    std::vector<std::thread> mappers;
+    for (size_t gi = 0; gi < gpus.size(); gi++)
+        mappers.emplace_back([&, gi]() {
+            Gpu &g = *gpus[gi];
+            bool input_done = false;
+            auto drain_released = [&](bool wait) {
+                std::unique_lock<std::mutex> lk(g.mu);
+                if (wait) g.cv.wait(lk, [&] { return !g.done_tickets.empty() || failed; });
+                for (uint64_t t : g.done_tickets) { groot_hip_release(g.ctx, t); g.held--; }
+                g.done_tickets.clear();
+            };
+            auto collect_one = [&]() -> bool {
+                WorkItem w = std::move(g.pending.front());
+                g.pending.pop_front();
+                const int rc = groot_hip_collect(g.ctx, &w.res);
+                // the reference's panics (short read, RevComplement on a byte > 'T') and over-long reads end the run
+                if (rc) { fail_with(groot_hip_last_error(g.ctx)); return false; }
+                g.inflight--; g.held++;
+                w.gpu = (int)gi;
+                mapped.push(std::move(w));
+                return true;
+            };
+            // a batch with a read longer than the ctx was opened for: finish what is in flight, carry the call counts over
+            // into a ctx with room for it (the reference has no read-length limit)
+            auto grow_ctx = [&](uint32_t need) -> bool {
+                while (g.inflight) if (!collect_one()) return false;
+                while (g.held && !failed) drain_released(true);
+                if (failed) return false;
+                uint32_t n_rows = 0, nw = 0;
+                if (groot_hip_attempts_export(g.ctx, nullptr, nullptr, 0, &n_rows, &nw)) { fail_with(groot_hip_last_error(g.ctx)); return false; }
+                std::vector<uint32_t> qv(n_rows), cnt((size_t)n_rows * nw);
+                if (n_rows && groot_hip_attempts_export(g.ctx, qv.data(), cnt.data(), n_rows, &n_rows, &nw)) { fail_with(groot_hip_last_error(g.ctx)); return false; }
+                groot_hip_close(g.ctx);
+                g.ctx = nullptr;
+                g.max_read_len = std::min<uint32_t>(65535, need + need / 2);
+                groot_params prm = params_for(g.max_read_len);
+                logf("\tread of %u bases: reopening the GPU context for reads up to %u bases", need, g.max_read_len);
+                if (groot_hip_open(&g.ctx, g.device, &v, &prm)) { fail_with(groot_hip_last_error(nullptr)); return false; }
+                if (n_rows && groot_hip_attempts_import(g.ctx, qv.data(), cnt.data(), n_rows)) { fail_with(groot_hip_last_error(g.ctx)); return false; }
+                return true;
+            };
+            while (!failed) {
+                drain_released(false);
+                const uint32_t free_slots = depth - g.held - g.inflight;
+                if (!input_done && free_slots > 0) {
+                    WorkItem w;
+                    const int got = parsed.pop(w, g.inflight == 0 && g.held == 0);
+                    if (got < 0) input_done = true;
+                    else if (got > 0) {
+                        if (w.view.max_len > g.max_read_len && !grow_ctx(w.view.max_len)) break;
+                        if (groot_hip_submit_packed16(g.ctx, w.view.packed, w.view.seq_len, w.view.n_reads, 0, w.view.exc_pos, w.view.exc_byte, w.view.n_exc)) {
+                            fail_with(groot_hip_last_error(g.ctx));
+                            break;
+                        }
+                        g.inflight++;
+                        g.pending.push_back(std::move(w));
+                        continue;
+                    }
+                }
+                if (g.inflight) { if (!collect_one()) break; continue; }
+                if (input_done && g.held == 0) break;
+                if (g.held) drain_released(true);               // everything is with the writer: wait for a slot
+                else if (!input_done) {                          // nothing to do but wait for input
+                    WorkItem w;
+                    const int got = parsed.pop(w, true);
+                    if (got < 0) { input_done = true; continue; }
+                    if (got > 0) {
+                        if (w.view.max_len > g.max_read_len && !grow_ctx(w.view.max_len)) break;
+                        if (groot_hip_submit_packed16(g.ctx, w.view.packed, w.view.seq_len, w.view.n_reads, 0, w.view.exc_pos, w.view.exc_byte, w.view.n_exc)) {
+                            fail_with(groot_hip_last_error(g.ctx));
+                            break;
+                        }
+                        g.inflight++;
+                        g.pending.push_back(std::move(w));
+                    }
+                }
+            }
+            if (--mappers_left == 0) mapped.close();
+        });
+
+    // ---- writer: batches in input order ----
+    uint64_t received = 0, mapped_reads = 0, multimapped = 0, alignments = 0;
+    {
+        std::map<uint64_t, WorkItem> waiting;
+        uint64_t next_seq = 0;
+        for (;;) {
+            WorkItem w;
+            const int got = mapped.pop(w, true);
+            if (got < 0) break;
+            waiting.emplace(w.seq, std::move(w));
+            while (!waiting.empty() && waiting.begin()->first == next_seq) {
+                WorkItem it = std::move(waiting.begin()->second);
+                waiting.erase(waiting.begin());
+                next_seq++;
+                const groot_counts &c = it.res.counts;
+                received += c.received; mapped_reads += c.mapped; multimapped += c.multimapped; alignments += c.alignments;
+                if (bam && it.res.n_travs && !failed) {
+                    uint64_t nrec = 0;
+                    if (groot_bam_write_batch(bam, &v, &it.view, 0, it.res.travs, it.res.masks, it.res.n_travs, &nrec)) fail_with(groot_host_last_error());
+                    else if (nrec != c.alignments)
+                        fail_with("internal error: " + std::to_string(nrec) + " records written, " + std::to_string(c.alignments) + " alignments counted");
+                }
+                groot_reads_batch_free(it.batch);
+                Gpu &g = *gpus[(size_t)it.gpu];
+                { std::lock_guard<std::mutex> lk(g.mu); g.done_tickets.push_back(it.res.ticket); }
+                g.cv.notify_all();
+            }
         }
-        Batch &bf = bufs[slot];
-        const int64_t n = bf.n;
-        if (n < 0) { reader.join(); die("%s", bf.err.c_str()); }
-        if (n == 0) break;
-        length_total += bf.seq_off[n];
-        if (groot_hip_submit(ctx, bf.seq.data(), bf.seq_off.data(), (uint32_t)n, first_id)) die("%s", groot_hip_last_error(ctx));
-        groot_counts c;
-        if (groot_hip_wait(ctx, &c)) die("%s", groot_hip_last_error(ctx));   // the reference's panics become fatal errors
-        received += c.received; mapped += c.mapped; multimapped += c.multimapped; alignments += c.alignments;
-        if (!a.no_align && c.travs) {
-            travs.resize(c.travs);
-            masks.resize(c.travs * v.path_words);
-            uint64_t nt = 0;
-            if (groot_hip_read_travs(ctx, travs.data(), masks.data(), c.travs, &nt)) die("%s", groot_hip_last_error(ctx));
-            // traversal records -> sam.Records -> BGZF, in parallel over chunks of traversals
-            groot_read_batch rb{bf.seq.data(), bf.qual.data(), bf.seq_off.data(), bf.names.data(), bf.name_off.data(), (uint32_t)n, first_id};
-            uint64_t nrec = 0;
-            if (groot_bam_write_travs(bam, &v, &rb, travs.data(), masks.data(), nt, &nrec)) die("%s", groot_host_last_error());
-            if (nrec != c.alignments) die("internal error: %llu records written, %llu alignments counted", (unsigned long long)nrec, (unsigned long long)c.alignments);
+        // after a failure: hand back whatever is still queued so that the mappers can finish
+        for (auto &kv : waiting) {
+            groot_reads_batch_free(kv.second.batch);
+            Gpu &g = *gpus[(size_t)kv.second.gpu];
+            { std::lock_guard<std::mutex> lk(g.mu); g.done_tickets.push_back(kv.second.res.ticket); }
+            g.cv.notify_all();
         }
-        first_id += (uint32_t)n;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            filled[slot] = 0;
-        }
-        cv.notify_all();
     }
-    reader.join();
-    (void)reader_done;
-    groot_fastq_close(fq);
+    for (auto &t : mappers) t.join();
+    producer.join();
+    if (failed) {
+        // unblock a producer that may sit in push()
+        die("%s", fatal.c_str());
+    }
+    groot_reads_close(reads);
     if (received == 0) die("no fastq reads received");                                           // sketch.go:275-277
     logf("\tnumber of reads received from input: %llu", (unsigned long long)received);           // sketch.go:278-280
-    logf("\tmean read length: %.0f", (double)length_total / (double)received);
+    logf("\tmean read length: %.0f", (double)length_total.load() / (double)received);
     logf("\tnumber of reads sketched: %llu", (unsigned long long)received);                      // sketch.go:321
+    const uint64_t bam_bytes = bam ? groot_bam_bytes_written(bam) : 0;
     if (bam && groot_bam_close(bam)) die("%s", groot_host_last_error());
+    const double stream_s = seconds_since(t_stream);
+    auto t_post = std::chrono::steady_clock::now();
 
     int rc = 0;
-    if (mapped == 0) {
+    if (mapped_reads == 0) {
         logf("no reads could be mapped to the reference graphs");                                // sketch.go:328-334
     } else {
-        logf("\ttotal number of unmapped reads: %llu", (unsigned long long)(received - mapped)); // sketch.go:335-339
-        logf("\ttotal number of mapped reads: %llu", (unsigned long long)mapped);
-        logf("\t\tmapped to one graph: %llu", (unsigned long long)(mapped - multimapped));
+        logf("\ttotal number of unmapped reads: %llu", (unsigned long long)(received - mapped_reads)); // sketch.go:335-339
+        logf("\ttotal number of mapped reads: %llu", (unsigned long long)mapped_reads);
+        logf("\t\tmapped to one graph: %llu", (unsigned long long)(mapped_reads - multimapped));
         logf("\t\tmapped to multiple graphs: %llu", (unsigned long long)multimapped);
         logf("\ttotal number of exact alignments: %llu", (unsigned long long)alignments);
-        // graph weights: exact call counts from the device, one replay of IncrementSubPath on the host
-        uint32_t nq = 0, nw = 0;
-        groot_hip_attempts_shape(ctx, &nq, &nw);
-        std::vector<uint32_t> counts((size_t)nq * nw);
-        if (groot_hip_attempts_read(ctx, counts.data(), counts.size())) die("%s", groot_hip_last_error(ctx));
+        // graph weights: exact call counts from the devices (summed over the GPUs: one RCCL all-reduce of a table with one row
+        // per kmerCount that occurred), one replay of IncrementSubPath on the host
+        std::vector<groot_ctx *> ctxs;
+        for (auto &g : gpus) ctxs.push_back(g->ctx);
+        if (groot_hip_attempts_allreduce(ctxs.data(), (int)ctxs.size())) die("%s", groot_hip_last_error(ctxs[0]));
+        uint32_t n_rows = 0, nw = 0;
+        if (groot_hip_attempts_export(ctxs[0], nullptr, nullptr, 0, &n_rows, &nw)) die("%s", groot_hip_last_error(ctxs[0]));
+        std::vector<uint32_t> qv(n_rows), counts((size_t)n_rows * nw);
+        if (n_rows && groot_hip_attempts_export(ctxs[0], qv.data(), counts.data(), n_rows, &n_rows, &nw)) die("%s", groot_hip_last_error(ctxs[0]));
         std::vector<double> kf(v.n_nodes);
         std::vector<uint64_t> kt(v.n_graphs);
-        if (groot_host_weights(&v, counts.data(), nq, kf.data(), kt.data())) die("%s", groot_host_last_error());
+        if (groot_host_weights_rows(&v, qv.data(), n_rows, counts.data(), kf.data(), kt.data())) die("%s", groot_host_last_error());
         uint64_t total_kmers = 0;
         for (auto t : kt) total_kmers += t;
         logf("processing graphs...");
@@ -426,14 +627,11 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         for (uint32_t g = 0; g < v.n_graphs; g++) {
             if (!gk[g]) continue;
             kept_graphs++;
-            uint32_t np = 0;
-            for (uint32_t p = v.graph_path_off[g]; p < v.graph_path_off[g + 1]; p++) np += pk[p];
             // sketch.go:409: len(g.Paths) is never shrunk by Prune, so the reference logs the full path count
             logf("\tgraph %u has %u remaining paths after weighting and pruning", g, v.graph_path_off[g + 1] - v.graph_path_off[g]);
             for (uint32_t p = v.graph_path_off[g]; p < v.graph_path_off[g + 1]; p++)
                 logf("\t- [%.*s]", (int)(v.path_name_off[p + 1] - v.path_name_off[p]), v.path_names + v.path_name_off[p]);
             kept_paths += v.graph_path_off[g + 1] - v.graph_path_off[g];
-            (void)np;
         }
         logf("\ttotal number of graphs pruned: %u", v.n_graphs);                                 // sketch.go:421-427
         if (!kept_graphs) logf("\tno graphs remaining after pruning");
@@ -449,9 +647,20 @@ int run_align(const Args &a)   // cmd/align.go:54-163
             }
         }
     }
-    groot_hip_close(ctx);
+    for (auto &g : gpus) groot_hip_close(g->ctx);
     groot_index_free(idx);
-    logf("finished in %.3fs", seconds_since(t0));
+    const double post_s = seconds_since(t_post), total_s = seconds_since(t0);
+    if (!a.stats_file.empty()) {
+        FILE *sf = fopen(a.stats_file.c_str(), "w");
+        if (sf) {
+            fprintf(sf, "{\"reads\": %llu, \"mapped\": %llu, \"alignments\": %llu, \"gpu_contexts\": %zu, \"load_s\": %.6f, \"stream_s\": %.6f, "
+                        "\"post_s\": %.6f, \"total_s\": %.6f, \"bam_bytes\": %llu, \"bam_level\": %d, \"threads\": %u}\n",
+                    (unsigned long long)received, (unsigned long long)mapped_reads, (unsigned long long)alignments, gpus.size(), load_s, stream_s,
+                    post_s, total_s, (unsigned long long)bam_bytes, a.bam_level, cores ? cores : std::thread::hardware_concurrency());
+            fclose(sf);
+        }
+    }
+    logf("finished in %.3fs", total_s);
     return rc;
 }
 

@@ -1609,6 +1609,32 @@ int groot_hip_attempts_layout(groot_ctx *c, const uint32_t *q_values, uint32_t n
     return GROOT_OK;
 }
 
+int groot_hip_attempts_import(groot_ctx *c, const uint32_t *q_values, const uint32_t *counts, uint32_t n_rows)
+{
+    if (!c || (n_rows && (!q_values || !counts))) return GROOT_E_INVALID;
+    if (!idle(c)) return fail(c, GROOT_E_STATE, "a batch is in flight");
+    if (c->att_external) return fail(c, GROOT_E_STATE, "the table lives in a caller-owned buffer");
+    std::vector<uint32_t> qs;
+    if (int rc = table_rows(c, qs)) return rc;
+    std::vector<uint32_t> all(qs);
+    all.insert(all.end(), q_values, q_values + n_rows);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    if (int rc = groot_hip_attempts_layout(c, all.data(), (uint32_t)all.size(), nullptr)) return rc;
+    if (!n_rows || !c->n_windows) return GROOT_OK;
+    DevBuf<uint32_t> tmp;
+    HIP_TRY(c, tmp.alloc(c->n_windows));
+    for (uint32_t r = 0; r < n_rows; r++) {
+        const uint32_t row = (uint32_t)(std::lower_bound(all.begin(), all.end(), q_values[r]) - all.begin());
+        HIP_TRY(c, hipMemcpy(tmp.p, counts + (size_t)r * c->n_windows, (size_t)c->n_windows * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(add_u32_kernel, dim3((unsigned)std::min<size_t>((c->n_windows + kBlock - 1) / kBlock, 65535)), dim3(kBlock), 0, c->stream,
+                           c->attempts_ptr + (size_t)row * c->n_windows, tmp.p, (size_t)c->n_windows);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return GROOT_OK;
+}
+
 int groot_hip_attempts_device(groot_ctx *c, void **d_table, uint32_t *n_rows, uint32_t *n_windows)
 {
     if (!c || !d_table) return GROOT_E_INVALID;

@@ -23,17 +23,19 @@ struct groot_bam {
     std::vector<uint8_t> out;
     uint32_t n_ref = 0;
     unsigned threads = 1;         // BGZF workers for large groot_bam_write calls (bam.NewWriter's write concurrency)
+    int level = Z_DEFAULT_COMPRESSION;   // biogo's bgzf.NewWriter default = gzip.DefaultCompression
+    uint64_t bytes_out = 0;       // compressed bytes written so far
 };
 
 static const size_t kBgzfBlock = 0xff00;   // max uncompressed payload per block
 
 // one BGZF member for data[0..n) into out; returns its size or a negative error
-static long compress_block(const uint8_t *data, size_t n, std::vector<uint8_t> &out)
+static long compress_block(const uint8_t *data, size_t n, std::vector<uint8_t> &out, int level = Z_DEFAULT_COMPRESSION)
 {
     out.resize(18 + compressBound((uLong)n) + 8);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return GROOT_E_NOMEM;
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return GROOT_E_NOMEM;
     zs.next_in = const_cast<Bytef *>(data);
     zs.avail_in = (uInt)n;
     zs.next_out = out.data() + 18;
@@ -56,9 +58,10 @@ static long compress_block(const uint8_t *data, size_t n, std::vector<uint8_t> &
 
 static int flush_block(groot_bam *b, const uint8_t *data, size_t n)
 {
-    const long total = compress_block(data, n, b->out);
+    const long total = compress_block(data, n, b->out, b->level);
     if (total < 0) return set_error((int)total, "BGZF compression failed");
     if (fwrite(b->out.data(), 1, (size_t)total, b->f) != (size_t)total) return set_error(GROOT_E_IO, "BAM write failed");
+    b->bytes_out += (uint64_t)total;
     return GROOT_OK;
 }
 
@@ -247,7 +250,7 @@ int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
                     sizes[c] = -1000 - (long)c;
                     continue;
                 }
-                sizes[c] = compress_block(raw.data(), raw.size(), outs[c]);
+                sizes[c] = compress_block(raw.data(), raw.size(), outs[c], b->level);
             }
         };
         const unsigned nt = (unsigned)std::min<size_t>(b->threads, n_chunks);
@@ -268,6 +271,7 @@ int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
             }
             if (sizes[c] < 0) return set_error((int)sizes[c], "BGZF compression failed");
             if (fwrite(outs[c].data(), 1, (size_t)sizes[c], b->f) != (size_t)sizes[c]) return set_error(GROOT_E_IO, "BAM write failed");
+            b->bytes_out += (uint64_t)sizes[c];
         }
         return GROOT_OK;
     }
@@ -276,10 +280,22 @@ int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
     return put(b, buf.data(), buf.size());
 }
 
-int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_read_batch *rb, const groot_trav *travs,
-                          const uint64_t *masks, uint64_t n_trav, uint64_t *n_records)
+} // extern "C"
+
+// one read of a batch as the BAM writer needs it
+struct ReadRef {
+    const char *name; uint32_t name_len;
+    const uint8_t *seq, *qual;       // qual may be NULL
+    uint32_t len, qual_len;          // qual_len < len: the missing quality bytes are written as '!' (the reference never checks the two lengths, seqio.go:175-178)
+};
+
+// traversal records of one batch -> sam.Records (alignment.go:113-156) -> BGZF blocks, in parallel over chunks of
+// traversals; blocks are written in traversal order = read order.  read(r, ref) fills the read's fields, false if r is
+// out of range.
+template <class ReadFn>
+static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn read, const groot_trav *travs, const uint64_t *masks, uint64_t n_trav,
+                            uint64_t *n_records)
 {
-    if (!b || !ix || !rb || (n_trav && (!travs || !masks))) return set_error(GROOT_E_INVALID, "null argument");
     if (n_records) *n_records = 0;
     if (!n_trav) return GROOT_OK;
     if (!b->block.empty()) {
@@ -293,8 +309,9 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
     std::vector<int> errs(n_chunks, 0);
     std::vector<uint64_t> nrec(n_chunks, 0);
     std::atomic<size_t> next{0};
+    const int level = b->level;
     auto work = [&]() {
-        std::vector<uint8_t> raw, blk, rcs, rcq;
+        std::vector<uint8_t> raw, blk, rcs, rcq, padq;
         std::vector<groot_aln_record> recs;
         for (;;) {
             const size_t c = next.fetch_add(1);
@@ -303,10 +320,15 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
             const uint64_t t0 = c * kChunk, t1 = std::min<uint64_t>(n_trav, t0 + kChunk);
             for (uint64_t t = t0; t < t1; t++) {
                 const groot_trav &tr = travs[t];
-                const uint32_t r = tr.read_id - rb->first_read_id;
-                if (r >= rb->n_reads || tr.node >= ix->n_nodes || tr.graph_id >= ix->n_graphs) { errs[c] = GROOT_E_INVALID; break; }
-                const uint64_t s0 = rb->seq_off[r], len = rb->seq_off[r + 1] - s0;
-                const uint8_t *sq = rb->seq + s0, *ql = rb->qual ? rb->qual + s0 : nullptr;
+                ReadRef rd;
+                if (!read(tr.read_id, rd) || tr.node >= ix->n_nodes || tr.graph_id >= ix->n_graphs) { errs[c] = GROOT_E_INVALID; break; }
+                const uint64_t len = rd.len;
+                const uint8_t *sq = rd.seq, *ql = rd.qual;
+                if (ql && rd.qual_len < len) {                    // pad a short quality line to the sequence
+                    padq.assign(len, '!');
+                    memcpy(padq.data(), ql, rd.qual_len);
+                    ql = padq.data();
+                }
                 if (tr.flags & GROOT_TRAV_RC) {                   // seqio.go:120-133
                     rcs.resize(len); rcq.resize(len);
                     for (uint64_t i = 0; i < len; i++) {
@@ -314,7 +336,7 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
                         rcs[i] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'N' ? 'N' : 0;
                         rcq[i] = ql ? ql[len - 1 - i] : 0xff;
                     }
-                    sq = rcs.data(); ql = rb->qual ? rcq.data() : nullptr;
+                    sq = rcs.data(); ql = ql ? rcq.data() : nullptr;
                 }
                 const uint8_t sc = (tr.flags & GROOT_TRAV_START_CLIP) ? 1 : 0, ec = (tr.flags & GROOT_TRAV_END_CLIP) ? 1 : 0;
                 bool first = (tr.flags & GROOT_TRAV_FIRST) != 0;
@@ -329,8 +351,8 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
                         for (uint32_t j = np0; j < np1; j++)
                             if (ix->np_path[j] == p) { pos = ix->np_pos[j] + tr.offset; break; }   // alignment.go:296
                         groot_aln_record rec;
-                        rec.name = rb->names + rb->name_off[r];
-                        rec.name_len = (uint32_t)(rb->name_off[r + 1] - rb->name_off[r]);
+                        rec.name = rd.name;
+                        rec.name_len = rd.name_len;
                         rec.seq = sq; rec.qual = ql;
                         rec.seq_len = (uint32_t)len - sc - ec;                                    // alignment.go:117-122
                         rec.ref_id = ix->graph_path_off[tr.graph_id] + p;
@@ -344,11 +366,11 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
                 }
                 if (errs[c]) break;
                 nrec[c] += recs.size();
-                format_records(recs.data(), 0, recs.size(), raw);   // rcs/rcq stay valid until here
+                format_records(recs.data(), 0, recs.size(), raw);   // rcs/rcq/padq stay valid until here
             }
             if (errs[c]) continue;
             for (size_t o = 0; o < raw.size(); o += kBgzfBlock) {   // records may span BGZF blocks
-                const long sz = compress_block(raw.data() + o, std::min(kBgzfBlock, raw.size() - o), blk);
+                const long sz = compress_block(raw.data() + o, std::min(kBgzfBlock, raw.size() - o), blk, level);
                 if (sz < 0) { errs[c] = (int)sz; break; }
                 outs[c].insert(outs[c].end(), blk.begin(), blk.begin() + sz);
             }
@@ -363,11 +385,59 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
     for (size_t c = 0; c < n_chunks; c++) {
         if (errs[c]) return set_error(errs[c], "could not build the BAM records of traversal chunk %zu", c);
         if (!outs[c].empty() && fwrite(outs[c].data(), 1, outs[c].size(), b->f) != outs[c].size()) return set_error(GROOT_E_IO, "BAM write failed");
+        b->bytes_out += outs[c].size();
         total += nrec[c];
     }
     if (n_records) *n_records = total;
     return GROOT_OK;
 }
+
+extern "C" {
+
+int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_read_batch *rb, const groot_trav *travs,
+                          const uint64_t *masks, uint64_t n_trav, uint64_t *n_records)
+{
+    if (!b || !ix || !rb || (n_trav && (!travs || !masks))) return set_error(GROOT_E_INVALID, "null argument");
+    auto read = [rb](uint32_t read_id, ReadRef &o) -> bool {
+        const uint32_t r = read_id - rb->first_read_id;
+        if (r >= rb->n_reads) return false;
+        const uint64_t s0 = rb->seq_off[r];
+        o.len = o.qual_len = (uint32_t)(rb->seq_off[r + 1] - s0);
+        o.seq = rb->seq + s0; o.qual = rb->qual ? rb->qual + s0 : nullptr;
+        o.name = rb->names + rb->name_off[r];
+        o.name_len = (uint32_t)(rb->name_off[r + 1] - rb->name_off[r]);
+        return true;
+    };
+    return write_travs_impl(b, ix, read, travs, masks, n_trav, n_records);
+}
+
+int groot_bam_write_batch(groot_bam *b, const groot_index_view *ix, const groot_reads_view *rv, uint32_t first_read_id, const groot_trav *travs,
+                          const uint64_t *masks, uint64_t n_trav, uint64_t *n_records)
+{
+    if (!b || !ix || !rv || (n_trav && (!travs || !masks))) return set_error(GROOT_E_INVALID, "null argument");
+    auto read = [rv, first_read_id](uint32_t read_id, ReadRef &o) -> bool {
+        const uint32_t r = read_id - first_read_id;
+        if (r >= rv->n_reads) return false;
+        o.len = rv->seq_len[r];
+        o.seq = rv->text + rv->seq_pos[r];
+        o.qual = rv->text + rv->qual_pos[r];
+        o.qual_len = std::min<uint32_t>(rv->qual_len[r], o.len);
+        o.name = reinterpret_cast<const char *>(rv->text + rv->name_pos[r]);
+        o.name_len = rv->name_len[r];
+        return true;
+    };
+    return write_travs_impl(b, ix, read, travs, masks, n_trav, n_records);
+}
+
+int groot_bam_set_level(groot_bam *b, int level)
+{
+    if (!b) return set_error(GROOT_E_INVALID, "null argument");
+    if (level < -1 || level > 9) return set_error(GROOT_E_INVALID, "BGZF compression level %d not in [-1, 9]", level);
+    b->level = level;
+    return GROOT_OK;
+}
+
+uint64_t groot_bam_bytes_written(const groot_bam *b) { return b ? b->bytes_out : 0; }
 
 int groot_bam_close(groot_bam *b)
 {

@@ -265,6 +265,12 @@ class Aligner:
                                                     C.byref(nr), C.byref(nw)))
         return q, cnt
 
+    def attempts_import(self, q_values, counts):
+        """groot_hip_attempts_import: add exported rows back (a re-opened ctx carries its counts over)"""
+        q = np.ascontiguousarray(q_values, dtype=np.uint32)
+        cnt = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._check(lib().groot_hip_attempts_import(self._h, _ffi.as_ptr(q, C.c_uint32), _ffi.as_ptr(cnt, C.c_uint32), C.c_uint32(len(q))))
+
     def attempts_layout(self, q_values, d_table=None):
         """groot_hip_attempts_layout: fix the rows (ascending kmerCounts); d_table = caller-owned device buffer or None"""
         q = np.ascontiguousarray(q_values, dtype=np.uint32)

@@ -228,6 +228,63 @@ class FastqReader:
     __del__ = close
 
 
+class ReadsView(C.Structure):
+    """groot_reads_view"""
+    _fields_ = [("n_reads", C.c_uint32), ("max_len", C.c_uint32), ("n_bases", C.c_uint64), ("n_exc", C.c_uint64),
+                ("packed", C.POINTER(C.c_uint8)), ("seq_len", C.POINTER(C.c_uint16)), ("exc_pos", C.POINTER(C.c_uint64)),
+                ("exc_byte", C.POINTER(C.c_uint8)), ("text", C.POINTER(C.c_uint8)), ("name_pos", C.POINTER(C.c_uint32)),
+                ("name_len", C.POINTER(C.c_uint32)), ("seq_pos", C.POINTER(C.c_uint32)), ("qual_pos", C.POINTER(C.c_uint32)),
+                ("qual_len", C.POINTER(C.c_uint32))]
+
+
+class ParallelReads:
+    """groot_reads_*: parallel FASTQ ingest (reader thread per file, parse + 2-bit pack over all cores); batches carry the
+    wire format of groot_hip_submit_packed16 and positions into the FASTQ text"""
+
+    def __init__(self, files, threads=0, block_bytes=0, max_batch_reads=0, max_batch_bases=0):
+        self._h = C.c_void_p()
+        arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+        _check(lib().groot_reads_open(arr, C.c_uint32(len(files)), C.c_uint32(threads), C.c_uint64(block_bytes), C.c_uint32(max_batch_reads),
+                                      C.c_uint64(max_batch_bases), C.byref(self._h)))
+
+    def batches(self):
+        L = lib()
+        L.groot_reads_batch_free.argtypes = [C.c_void_p]
+        L.groot_reads_batch_free.restype = None
+        L.groot_reads_batch_view.argtypes = [C.c_void_p, C.POINTER(ReadsView)]
+        L.groot_reads_batch_view.restype = None
+        while True:
+            b = C.c_void_p()
+            _check(L.groot_reads_next(self._h, C.byref(b)))
+            if not b.value:
+                return
+            v = ReadsView()
+            L.groot_reads_batch_view(b, C.byref(v))
+            n = v.n_reads
+            out = {"n": n, "max_len": v.max_len, "n_bases": int(v.n_bases),
+                   "packed": _ffi._np_view(v.packed, (v.n_bases + 3) // 4, np.uint8).copy(),
+                   "seq_len": _ffi._np_view(v.seq_len, n, np.uint16).copy(),
+                   "exc_pos": _ffi._np_view(v.exc_pos, v.n_exc, np.uint64).copy(),
+                   "exc_byte": _ffi._np_view(v.exc_byte, v.n_exc, np.uint8).copy()}
+            pos = {k: _ffi._np_view(getattr(v, k), n, np.uint32) for k in ("name_pos", "name_len", "seq_pos", "qual_pos", "qual_len")}
+            text_end = max(int((pos["qual_pos"] + pos["qual_len"]).max()), int((pos["seq_pos"] + out["seq_len"]).max())) if n else 0
+            text = _ffi._np_view(v.text, text_end, np.uint8)
+            out["names"] = [bytes(text[int(p):int(p) + int(l)]) for p, l in zip(pos["name_pos"], pos["name_len"])]
+            out["seqs"] = [bytes(text[int(p):int(p) + int(l)]) for p, l in zip(pos["seq_pos"], out["seq_len"])]
+            out["quals"] = [bytes(text[int(p):int(p) + int(l)]) for p, l in zip(pos["qual_pos"], pos["qual_len"])]
+            L.groot_reads_batch_free(b)
+            yield out
+
+    def close(self):
+        if self._h:
+            lib().groot_reads_close.argtypes = [C.c_void_p]
+            lib().groot_reads_close.restype = None
+            lib().groot_reads_close(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
 class BamWriter:
     """setupBAM + the record collector of theBoss (src/pipeline/boss.go:45-105,225-240)"""
 

@@ -185,6 +185,9 @@ int groot_hip_attempts_export(groot_ctx *ctx, uint32_t *q_values, uint32_t *coun
  * afterwards); existing counts are copied into it; a kmerCount outside the layout then fails the batch with
  * GROOT_E_NOSPACE.  Only while nothing is in flight. */
 int groot_hip_attempts_layout(groot_ctx *ctx, const uint32_t *q_values, uint32_t n_q, void *d_table);
+/* Adds exported rows back (same shapes as groot_hip_attempts_export): a host that re-opens its ctx, e.g. for longer
+ * reads, carries the counts over.  kmerCounts the table lacks get rows.  Only while nothing is in flight. */
+int groot_hip_attempts_import(groot_ctx *ctx, const uint32_t *q_values, const uint32_t *counts, uint32_t n_rows);
 int groot_hip_attempts_device(groot_ctx *ctx, void **d_table, uint32_t *n_rows, uint32_t *n_windows);
 int groot_hip_attempts_reset(groot_ctx *ctx);
 /* SURVEY 8e / north_star: the one exchange of a multi-GPU run.  Brings every ctx to the union row layout and sums the

@@ -197,6 +197,42 @@ typedef struct groot_read_batch {
 int groot_bam_write_travs(groot_bam *bam, const groot_index_view *idx, const groot_read_batch *batch, const groot_trav *travs,
                           const uint64_t *masks, uint64_t n_trav, uint64_t *n_records);
 int groot_bam_close(groot_bam *bam);
+/* BGZF compression level (-1 = zlib default = what bgzf.NewWriter uses in the reference, 0 = stored .. 9) */
+int groot_bam_set_level(groot_bam *bam, int level);
+uint64_t groot_bam_bytes_written(const groot_bam *bam);
+
+/* ---- parallel FASTQ ingest (src/pipeline/sketch.go:41-77,213-236; seqio.go:173-188) --------------------------------
+ * One reader thread per input file (the next few files are opened ahead, so several gzip streams inflate at once), the
+ * calling thread frames the text at record boundaries, and n_threads workers find the line breaks, parse the records
+ * and pack the bases into the wire format of groot_hip_submit_packed16.  Batches come out in input order; lines of
+ * consecutive files form one stream; a trailing partial record is dropped (FastqHandler.Run).  Records hold positions
+ * into the batch's own copy of the FASTQ text: nothing is copied per read. */
+typedef struct groot_reads groot_reads;
+typedef struct groot_reads_batch groot_reads_batch;
+typedef struct groot_reads_view {
+    uint32_t n_reads, max_len;
+    uint64_t n_bases, n_exc;
+    const uint8_t *packed;         /* 2-bit bases, (n_bases+3)/4 bytes                      */
+    const uint16_t *seq_len;       /* [n_reads]                                             */
+    const uint64_t *exc_pos;       /* [n_exc] bytes other than ACGT, ascending position     */
+    const uint8_t *exc_byte;
+    const uint8_t *text;           /* FASTQ text the positions below point into             */
+    const uint32_t *name_pos, *name_len;   /* read.ID[1:] (the record name, alignment.go:119) */
+    const uint32_t *seq_pos;       /* read.Seq, seq_len[i] bytes                            */
+    const uint32_t *qual_pos, *qual_len;   /* read.Qual as it came                           */
+} groot_reads_view;
+/* n_files == 0 reads stdin; n_threads 0 = all cores; block_bytes 0 = 256 MB of text per block; a batch holds at most
+ * max_batch_reads reads (0 = 1<<20) and max_batch_bases bases (0 = 256 per read) */
+int groot_reads_open(const char *const *files, uint32_t n_files, uint32_t n_threads, uint64_t block_bytes, uint32_t max_batch_reads,
+                     uint64_t max_batch_bases, groot_reads **out);
+int groot_reads_next(groot_reads *r, groot_reads_batch **out);   /* *out = NULL at the end of the input */
+void groot_reads_batch_view(const groot_reads_batch *b, groot_reads_view *view);
+void groot_reads_batch_free(groot_reads_batch *b);
+uint64_t groot_reads_count(const groot_reads *r);
+void groot_reads_close(groot_reads *r);
+/* collector for such a batch: traversal records -> sam.Records -> BGZF, parallel like groot_bam_write_travs */
+int groot_bam_write_batch(groot_bam *bam, const groot_index_view *idx, const groot_reads_view *reads, uint32_t first_read_id,
+                          const groot_trav *travs, const uint64_t *masks, uint64_t n_trav, uint64_t *n_records);
 
 /* ---- packing reads for groot_hip_submit_packed (include/groot_hip.h) ------------------------------------ */
 /* packed[(n_bases+3)/4]; exceptions (bytes other than A C G T, e.g. N or lower case) in ascending position, at most

@@ -29,6 +29,9 @@ def test_index_subcommand_and_align_without_gpu(cli, msa_dir, tmp_path):
     log = str(tmp_path / "index.log")
     r = run([cli, "index", "-m", msa_dir, "-i", idx_dir, "--log", log, "-p", "4"])
     assert r.returncode == 0, r.stderr
+    assert not os.path.exists(os.path.join(idx_dir, "groot.gg"))      # the reference's gob files are opt-in (unpinned against Go)
+    r = run([cli, "index", "-m", msa_dir, "-i", idx_dir, "--log", log, "-p", "4", "--writeGob"])
+    assert r.returncode == 0, r.stderr
     text = open(log).read()
     for line in ("i am groot (version 1.1.2)", "starting the index subcommand", "\tk-mer size: 31", "\tsketch size: 21",
                  "\tgraph window size: 100", "\tnumber of groot graphs built: 583", "\t\tgraphs sketched: 583"):
@@ -143,6 +146,67 @@ def test_travis_e2e_flow(cli, msa_dir, tmp_path):
     assert refs2 == refs and recs2 == recs
 
 
+def _gfas(d):
+    out = {}
+    for f in sorted(os.listdir(d)):
+        out[f] = [ln for ln in open(os.path.join(d, f)) if not ln.startswith("#")]     # the comment lines carry a timestamp
+    return out
+
+
+@pytest.mark.gpu
+def test_reads_shard_over_several_contexts(cli, argannot_index, tmp_path):
+    """`--gpus N`: batches go round the GPU contexts, records come back in input order, the call counts are summed
+    (groot_hip_attempts_allreduce) before the graphs are weighted -- BAM records and GFAs equal the one-context run.  One GPU
+    here, so the contexts share it (--ctxPerGpu): the same code path with the RCCL ring replaced by its same-device sum."""
+    idx_dir = tmp_path / "idx"
+    idx_dir.mkdir()
+    argannot_index.save(str(idx_dir / "groot.gidx"))
+    fqs = ",".join(os.path.join(DATA, f) for f in ("full-argannot-perfect-reads-small.fq.gz", "full-argannot-perfect-reads-small-variable-rl.fq.gz"))
+    outs = []
+    for tag, extra in (("one", []), ("three", ["--ctxPerGpu", "3", "--depth", "2"])):
+        bam, graphs, stats = str(tmp_path / f"{tag}.bam"), str(tmp_path / f"g_{tag}"), str(tmp_path / f"{tag}.json")
+        r = run([cli, "align", "-i", str(idx_dir), "-f", fqs, "--log", str(tmp_path / f"{tag}.log"), "-g", graphs, "--bam", bam, "--batch", "190",
+                 "-p", "4", "-t", "0.97", "--bamLevel", "1", "--stats", stats] + extra)
+        assert r.returncode == 0, r.stderr
+        import json
+        st = json.load(open(stats))
+        assert st["gpu_contexts"] == (3 if extra else 1) and st["reads"] == 2000 and st["bam_bytes"] > 0
+        outs.append((read_bam(bam), _gfas(graphs), open(str(tmp_path / f"{tag}.log")).read()))
+    (t1, refs1, recs1), g1, log1 = outs[0]
+    (t3, refs3, recs3), g3, log3 = outs[1]
+    assert refs1 == refs3 and recs1 == recs3 and len(recs1) > 2000
+    assert g1 == g3 and len(g1) > 0
+    for key in ("total number of mapped reads", "mapped to multiple graphs", "total number of exact alignments", "total number of k-mers projected"):
+        assert [ln.split(" ", 2)[2] for ln in log1.splitlines() if key in ln] == [ln.split(" ", 2)[2] for ln in log3.splitlines() if key in ln] != []
+
+
+@pytest.mark.gpu
+def test_reads_longer_than_the_context_was_opened_for(cli, argannot_index, tmp_path):
+    """the reference has no read-length limit: a batch holding a longer read re-opens the GPU context (call counts carried
+    over) instead of aborting the run"""
+    idx_dir = tmp_path / "idx"
+    idx_dir.mkdir()
+    argannot_index.save(str(idx_dir / "groot.gidx"))
+    short = read_fastq(os.path.join(DATA, "full-argannot-perfect-reads-small.fq.gz"))[:400]
+    gene = argannot_index.path_sequence(5, 0)
+    long_read = bytes(gene[:600]) if len(gene) >= 600 else bytes(gene)
+    fq = tmp_path / "mixed.fq"
+    with open(fq, "wb") as f:
+        for i, (n, s, q) in enumerate(short):
+            f.write(b"@" + n + b"\n" + s + b"\n+\n" + q + b"\n")
+            if i == 250:
+                f.write(b"@long\n" + long_read + b"\n+\n" + b"I" * len(long_read) + b"\n")
+    res = []
+    for tag, mrl in (("grow", "160"), ("big", "1024")):
+        bam, log = str(tmp_path / f"{tag}.bam"), str(tmp_path / f"{tag}.log")
+        r = run([cli, "align", "-i", str(idx_dir), "-f", str(fq), "--log", log, "-g", str(tmp_path / f"g_{tag}"), "--bam", bam, "--batch", "128",
+                 "--maxReadLen", mrl, "-p", "2"])
+        assert r.returncode == 0, r.stderr
+        res.append((read_bam(bam)[2], _gfas(str(tmp_path / f"g_{tag}")), open(log).read()))
+    assert "reopening the GPU context" in res[0][2] and "reopening the GPU context" not in res[1][2]
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and len(res[0][0]) > 400
+
+
 @pytest.mark.gpu
 def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     """bench.py as the driver launches it for N>1 (torch.distributed.run, one rank per GPU).  This box has one GPU, so both
@@ -164,3 +228,6 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     assert one.returncode == 0, one.stderr[-2000:]
     single = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert single["n_gpus"] == 1 and single["config"]["per_step_counts"]["received"] == 300000
+    # the PCIe- and host-inclusive legs ride on the same line
+    assert single["host_fed"]["value"] > 0 and single["host_fed"]["d2h_bytes_per_read"] > 20, single["host_fed"]
+    assert single["cli_e2e"]["value"] > 0 and single["cli_e2e"]["reads"] == 300000, single["cli_e2e"]

@@ -205,10 +205,12 @@ def test_results_on_device_and_legacy_reads(small_index):
 
 def test_corrupt_view_is_refused(small_index):
     """groot_hip_open runs the consistency pass before uploading anything"""
-    import copy
     import ctypes as C
 
-    v = copy.copy(small_index.view)
+    from groot_amd._ffi import IndexView
+
+    v = IndexView()
+    C.memmove(C.byref(v), C.byref(small_index.view), C.sizeof(IndexView))
     bad = small_index.arrays["edges"].copy()
     bad[0] = 0xFFFFFFF0
     v.edges = bad.ctypes.data_as(C.POINTER(C.c_uint32))
