@@ -36,6 +36,24 @@ HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29
 PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
 
 
+def usable_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup CPU quota) -- the GPU boxes show 256 hardware threads and grant 16"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, round(q / p)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -88,10 +106,11 @@ def cpu_baseline(index_path, seconds):
 
     one_n = 150_000
     one, one_wall = run(1, one_n, 0)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     per = int(max(50_000, min(600_000, one * 1e6 * seconds * 0.6)) // 25_000 * 25_000)   # SMT siblings run slower than a lone thread
     allv, wall = run(cores, per, 1_000_000)
-    return {"value": allv, "unit": "Mreads/s", "cores": cores, "kind": "port",
+    return {"value": allv, "unit": "Mreads/s", "cores": cores, "kind": "port", "hardware_threads": os.cpu_count(),
+            "cores_note": "cores = CPUs this container may use (min of affinity mask and cgroup CPU quota); the box shows more hardware threads than it grants",
             "sample": f"{cores} oracle processes x {per} reads of the same synthetic stream, started together, {wall:.1f} s wall "
                       f"(records dropped per 25k-read chunk as the reference streams them to the BAM)",
             "single_core": {"value": one, "sample": f"{one_n} reads, one process, {one_wall:.1f} s"},
@@ -215,7 +234,7 @@ def cli_e2e(index, d_seq, n_reads, bam_level):
         bam = os.path.join(td, "out.bam")
         stats = os.path.join(td, "stats.json")
         cmd = [exe, "align", "-i", idx_dir, "-f", fq, "-g", os.path.join(td, "graphs"), "--bam", bam, "--log", os.path.join(td, "groot.log"),
-               "-p", str(os.cpu_count() or 1), "--bamLevel", str(bam_level), "--stats", stats]
+               "-p", str(usable_cpus()), "--bamLevel", str(bam_level), "--stats", stats, "--batch", "262144"]
         t0 = time.perf_counter()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         wall = time.perf_counter() - t0

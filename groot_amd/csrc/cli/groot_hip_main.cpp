@@ -448,12 +448,17 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     };
 
     std::atomic<uint64_t> length_total{0};
+    double parse_s = 0, bam_s = 0;                    // busy time of the producer / the writer
+    std::atomic<uint64_t> collect_wait_us{0}, n_batches{0};
     std::thread producer([&]() {
         uint64_t seq = 0;
         for (;;) {
             if (failed) break;
             WorkItem w;
-            if (groot_reads_next(reads, &w.batch)) { fail_with(groot_host_last_error()); break; }
+            auto tp = std::chrono::steady_clock::now();
+            const int prc = groot_reads_next(reads, &w.batch);
+            parse_s += seconds_since(tp);
+            if (prc) { fail_with(groot_host_last_error()); break; }
             if (!w.batch) break;
             groot_reads_batch_view(w.batch, &w.view);
             length_total += w.view.n_bases;
@@ -478,7 +483,10 @@ int run_align(const Args &a)   // cmd/align.go:54-163
             auto collect_one = [&]() -> bool {
                 WorkItem w = std::move(g.pending.front());
                 g.pending.pop_front();
+                auto tc = std::chrono::steady_clock::now();
                 const int rc = groot_hip_collect(g.ctx, &w.res);
+                collect_wait_us += (uint64_t)(seconds_since(tc) * 1e6);
+                n_batches++;
                 // the reference's panics (short read, RevComplement on a byte > 'T') and over-long reads end the run
                 if (rc) { fail_with(groot_hip_last_error(g.ctx)); return false; }
                 g.inflight--; g.held++;
@@ -562,7 +570,10 @@ int run_align(const Args &a)   // cmd/align.go:54-163
                 received += c.received; mapped_reads += c.mapped; multimapped += c.multimapped; alignments += c.alignments;
                 if (bam && it.res.n_travs && !failed) {
                     uint64_t nrec = 0;
-                    if (groot_bam_write_batch(bam, &v, &it.view, 0, it.res.travs, it.res.masks, it.res.n_travs, &nrec)) fail_with(groot_host_last_error());
+                    auto tw = std::chrono::steady_clock::now();
+                    const int wrc = groot_bam_write_batch(bam, &v, &it.view, 0, it.res.travs, it.res.masks, it.res.n_travs, &nrec);
+                    bam_s += seconds_since(tw);
+                    if (wrc) fail_with(groot_host_last_error());
                     else if (nrec != c.alignments)
                         fail_with("internal error: " + std::to_string(nrec) + " records written, " + std::to_string(c.alignments) + " alignments counted");
                 }
@@ -654,9 +665,11 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         FILE *sf = fopen(a.stats_file.c_str(), "w");
         if (sf) {
             fprintf(sf, "{\"reads\": %llu, \"mapped\": %llu, \"alignments\": %llu, \"gpu_contexts\": %zu, \"load_s\": %.6f, \"stream_s\": %.6f, "
-                        "\"post_s\": %.6f, \"total_s\": %.6f, \"bam_bytes\": %llu, \"bam_level\": %d, \"threads\": %u}\n",
+                        "\"post_s\": %.6f, \"total_s\": %.6f, \"bam_bytes\": %llu, \"bam_level\": %d, \"threads\": %u, \"batches\": %llu, "
+                        "\"parse_busy_s\": %.6f, \"bam_busy_s\": %.6f, \"collect_wait_s\": %.6f}\n",
                     (unsigned long long)received, (unsigned long long)mapped_reads, (unsigned long long)alignments, gpus.size(), load_s, stream_s,
-                    post_s, total_s, (unsigned long long)bam_bytes, a.bam_level, cores ? cores : std::thread::hardware_concurrency());
+                    post_s, total_s, (unsigned long long)bam_bytes, a.bam_level, cores ? cores : groot_host_usable_cpus(),
+                    (unsigned long long)n_batches.load(), parse_s, bam_s, (double)collect_wait_us.load() / 1e6);
             fclose(sf);
         }
     }

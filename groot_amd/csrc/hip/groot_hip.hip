@@ -94,7 +94,7 @@ struct Slot {
     PinBuf<DeviceCounters> h_ctr;
     PinBuf<groot_trav> h_trav;
     PinBuf<uint64_t> h_mask;
-    uint32_t n_trav = 0;
+    uint32_t n_trav = 0, copied = 0;               // records of the batch / records the copy-out enqueued at submit covers
     bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
     hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
     hipEvent_t ev[7]{};                    // stage boundaries on the compute stream (profiling)
@@ -133,6 +133,7 @@ struct groot_ctx {
     std::deque<Slot *> inflight;           // submission order: IN_FLIGHT / D2H_ISSUED
     uint64_t next_ticket = 1;
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
+    double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
     Slot *work_owner = nullptr;            // whose seeds / sketches the shared work buffers hold
     uint64_t work_ticket = 0;
 
@@ -470,8 +471,12 @@ static int alloc_seed_slots(groot_ctx *c, uint32_t slots)
 static int alloc_trav(groot_ctx *c, Slot *s, uint32_t cap)
 {
     s->trav_cap = cap;
-    HIP_TRY(c, s->d_trav.alloc(cap));
-    HIP_TRY(c, s->d_mask.alloc((size_t)cap * c->pw_view));
+    HIP_TRY(c, s->d_trav.alloc((size_t)cap + 2));
+    HIP_TRY(c, s->d_mask.alloc((size_t)cap * c->pw_view + 2));
+    if (!c->prm.results_on_device) {
+        HIP_TRY(c, s->h_trav.alloc((size_t)cap + 2));
+        HIP_TRY(c, s->h_mask.alloc((size_t)cap * c->pw_view + 2));
+    }
     return GROOT_OK;
 }
 
@@ -757,7 +762,21 @@ static int enqueue(groot_ctx *c, Slot *s)
     }
     if (int rc = run_batch_async(c, s, true)) return rc;
     HIP_TRY(c, hipEventRecord(s->ev_compute, c->stream));
+    // Copy-out on its own stream with no host in between.  The record count is only known on the device, and asking for it
+    // would put a host round trip between the last kernel and the copy; so the copy engine is given a PREDICTED count now
+    // -- records per read of the latest finished batch, plus a margin -- and collect fetches the rest in the rare batch
+    // that has more.  (A device-driven copy kernel writing straight into pinned host memory gets the exact size too, but
+    // its posted PCIe writes back up into the write path the other kernels share: the next batch's first memory-bound
+    // kernel stalled until the copy was through.  Measured, dropped.)
     HIP_TRY(c, hipStreamWaitEvent(c->d2h_stream, s->ev_compute, 0));
+    if (!c->prm.results_on_device) {
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h0, c->d2h_stream));
+        const uint64_t predicted = (uint64_t)((double)s->n_reads * c->trav_per_read * 1.06) + 4096;
+        s->copied = (uint32_t)std::min<uint64_t>(predicted, s->trav_cap);
+        HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->copied * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_mask.p, (size_t)s->copied * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h, c->d2h_stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(s->h_ctr.p, s->d_ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->d2h_stream));
     HIP_TRY(c, hipEventRecord(s->ev_ctr, c->d2h_stream));
     s->state = Slot::IN_FLIGHT;
@@ -777,6 +796,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
     };
     DeviceCounters first = h;
     bool have_first = false;              // weights + read counters already taken from an earlier pass
+    bool redone = false;
     for (int attempt = 0; s->n_reads; attempt++) {
         const uint32_t fl = h.flags;
         if (!(fl & (kFlagSeedOverflow | kFlagQOverflow | kFlagOvfOverflow | kFlagTravOverflow))) break;
@@ -804,6 +824,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
             if (fl & kFlagTravOverflow) { if (int rc = alloc_trav(c, s, h.n_trav + h.n_trav / 8 + 1024)) return rc; }
         }
         if (int rc = run_batch_async(c, s, redo_weights)) return rc;
+        redone = true;
         DeviceCounters again{};
         if (int rc = refetch(again)) return rc;
         if (have_first) {
@@ -847,16 +868,17 @@ static int finish_counters(groot_ctx *c, Slot *s)
         fprintf(stderr, "\n");
     }
 #endif
-    // copy-out of the records (exact size now known), overlapping whatever the compute stream does next
+    // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
+    if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
     if (!c->prm.results_on_device && s->n_trav) {
-        HIP_TRY(c, s->h_trav.reserve(s->trav_cap));
-        HIP_TRY(c, s->h_mask.reserve((size_t)s->trav_cap * c->pw_view));
-        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h0, c->d2h_stream));
-        HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->n_trav * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
-        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_mask.p, (size_t)s->n_trav * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
+        const uint32_t have = redone ? 0 : std::min(s->copied, s->n_trav);      // a redo re-made the records: fetch them all
+        if (have < s->n_trav) {
+            HIP_TRY(c, hipMemcpy(s->h_trav.p + have, s->d_trav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_trav), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(s->h_mask.p + (size_t)have * c->pw_view, s->d_mask.p + (size_t)have * c->pw_view,
+                                 (size_t)(s->n_trav - have) * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        }
         s->host_results = true;
     }
-    HIP_TRY(c, hipEventRecord(s->ev_d2h, c->d2h_stream));
     s->state = Slot::D2H_ISSUED;
     return GROOT_OK;
 }
@@ -886,10 +908,9 @@ static int collect_impl(groot_ctx *c, Slot **out)
     if (c->inflight.empty()) return fail(c, GROOT_E_STATE, "no batch submitted");
     HIP_TRY(c, hipSetDevice(c->device));
     Slot *s = c->inflight.front();
-    if (s->state == Slot::IN_FLIGHT) {
+    if (s->state == Slot::IN_FLIGHT) {       // waits for the batch's counters, which travel behind its records
         if (int rc = progress(c, s)) return rc;
     }
-    HIP_TRY(c, hipEventSynchronize(s->ev_d2h));
     if (c->profiling && s->n_reads) {
         if (s->input != Slot::IN_DEVICE) (void)hipEventElapsedTime(&s->ms.h2d, s->ev_h2d0, s->ev_h2d);
         (void)hipEventElapsedTime(&s->ms.unpack, s->ev[0], s->ev[1]);
@@ -898,7 +919,7 @@ static int collect_impl(groot_ctx *c, Slot **out)
         (void)hipEventElapsedTime(&s->ms.align, s->ev[3], s->ev[4]);
         (void)hipEventElapsedTime(&s->ms.sort, s->ev[4], s->ev[5]);
         (void)hipEventElapsedTime(&s->ms.total, s->ev[0], s->ev[5]);
-        if (s->host_results) (void)hipEventElapsedTime(&s->ms.d2h, s->ev_d2h0, s->ev_d2h);
+        if (!c->prm.results_on_device) (void)hipEventElapsedTime(&s->ms.d2h, s->ev_d2h0, s->ev_d2h);
     }
     c->inflight.pop_front();
     s->state = Slot::COLLECTED;

@@ -12,6 +12,10 @@
 #include <cstring>
 #include <ctime>
 #include <thread>
+
+#include <cerrno>
+#include <sys/uio.h>
+#include <unistd.h>
 #include <zlib.h>
 
 using namespace groot;
@@ -209,7 +213,7 @@ static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i
 int groot_bam_set_threads(groot_bam *b, uint32_t n_threads)
 {
     if (!b) return set_error(GROOT_E_INVALID, "null argument");
-    b->threads = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    b->threads = n_threads ? n_threads : usable_cpus();
     return GROOT_OK;
 }
 
@@ -384,9 +388,26 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
     uint64_t total = 0;
     for (size_t c = 0; c < n_chunks; c++) {
         if (errs[c]) return set_error(errs[c], "could not build the BAM records of traversal chunk %zu", c);
-        if (!outs[c].empty() && fwrite(outs[c].data(), 1, outs[c].size(), b->f) != outs[c].size()) return set_error(GROOT_E_IO, "BAM write failed");
-        b->bytes_out += outs[c].size();
         total += nrec[c];
+    }
+    // the compressed chunks go out in order with gathered writes straight from the workers' buffers (no stdio copy)
+    if (fflush(b->f) != 0) return set_error(GROOT_E_IO, "BAM write failed");
+    const int fd = fileno(b->f);
+    std::vector<struct iovec> iov;
+    for (size_t c = 0; c < n_chunks;) {
+        iov.clear();
+        size_t bytes = 0;
+        for (; c < n_chunks && iov.size() < 512; c++)
+            if (!outs[c].empty()) { iov.push_back({outs[c].data(), outs[c].size()}); bytes += outs[c].size(); }
+        size_t first = 0;
+        while (first < iov.size()) {
+            const ssize_t w = writev(fd, iov.data() + first, (int)(iov.size() - first));
+            if (w < 0) { if (errno == EINTR) continue; return set_error(GROOT_E_IO, "BAM write failed"); }
+            size_t left = (size_t)w;
+            while (first < iov.size() && left >= iov[first].iov_len) { left -= iov[first].iov_len; first++; }
+            if (first < iov.size() && left) { iov[first].iov_base = (char *)iov[first].iov_base + left; iov[first].iov_len -= left; }
+        }
+        b->bytes_out += bytes;
     }
     if (n_records) *n_records = total;
     return GROOT_OK;

@@ -150,7 +150,7 @@ extern "C" int groot_host_pack_reads(const uint8_t *seq, uint64_t n_bases, uint8
                                      uint64_t exc_cap, uint64_t *n_exc, uint32_t n_threads)
 {
     if ((n_bases && (!seq || !packed)) || !n_exc) return groot::set_error(GROOT_E_INVALID, "null argument");
-    unsigned nt = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = n_threads ? n_threads : groot::usable_cpus();
     const uint64_t n_quads = (n_bases + 3) / 4;
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, n_quads / 65536 + 1));
     std::vector<std::vector<std::pair<uint64_t, uint8_t>>> exc(nt);

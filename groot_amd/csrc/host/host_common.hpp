@@ -12,6 +12,11 @@
 
 namespace groot {
 
+// CPUs this process may really use: min(affinity mask, cgroup CPU quota) -- containers often expose every hardware thread
+// of the box (std::thread::hardware_concurrency) while granting a fraction of them; oversubscribing that quota only adds
+// throttling stalls.  The "0 = all cores" defaults of this library mean this number.
+unsigned usable_cpus();
+
 // thread-local last-error string behind groot_host_last_error()
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 

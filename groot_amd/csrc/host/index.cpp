@@ -14,6 +14,7 @@
 #include "../common/view_check.hpp"
 
 #include <algorithm>
+#include <sched.h>
 #include <atomic>
 #include <cstring>
 #include <dirent.h>
@@ -554,7 +555,7 @@ static int build_from_files(const char *const *files, uint32_t n_files, const gr
     std::vector<Graph> graphs(n_files);
     std::vector<std::string> errs(n_files);
     std::vector<int> rcs(n_files, 0);
-    unsigned nt = p->n_threads ? p->n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = p->n_threads ? p->n_threads : usable_cpus();
     nt = std::min<unsigned>(nt, n_files);
     std::atomic<uint32_t> next{0};
     auto work = [&]() {
@@ -603,7 +604,39 @@ template <class T> static bool get_vec(std::ifstream &i, std::vector<T> &v)
     return true;
 }
 
+namespace groot {
+unsigned usable_cpus()
+{
+    static const unsigned cached = []() -> unsigned {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+        // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64];
+            long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            long long qv = -1, period = 0;
+            if (fscanf(g, "%lld", &qv) != 1) qv = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+            if (qv > 0 && period > 0) quota = (double)qv / (double)period;
+        }
+        if (quota >= 1.0) n = std::min<unsigned>(n, (unsigned)(quota + 0.5));
+        if (const char *e = getenv("GROOT_THREADS")) { const int v = atoi(e); if (v > 0) n = (unsigned)v; }
+        return std::max(1u, n);
+    }();
+    return cached;
+}
+} // namespace groot
+
 extern "C" {
+
+uint32_t groot_host_usable_cpus(void) { return groot::usable_cpus(); }
 
 const char *groot_host_last_error(void) { return g_err.c_str(); }
 const char *groot_host_version(void) { return "1.1.2"; }   // src/version/version.go:5-17

@@ -18,6 +18,10 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+
+#include <cerrno>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 using namespace groot;
@@ -56,23 +60,49 @@ struct Source {
 
     void run()
     {
-        gzFile fh = path.empty() ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");   // gzread handles plain files transparently
-        if (!fh) { finish("cannot open " + (path.empty() ? std::string("stdin") : path)); return; }
-        gzbuffer(fh, 1u << 20);
+        // gzip streams go through zlib; anything else is read straight into the block (gzread would copy it through its
+        // own buffer at a fraction of the page-cache rate)
+        const int fd = path.empty() ? 0 : open(path.c_str(), O_RDONLY);
+        if (fd < 0) { finish("cannot open " + path); return; }
+        unsigned char magic[2] = {0, 0};
+        size_t have_magic = 0;
+        while (have_magic < 2) {
+            const ssize_t n = read(fd, magic + have_magic, 2 - have_magic);
+            if (n <= 0) break;
+            have_magic += (size_t)n;
+        }
+        // (stdin is scanned as it comes, as in the reference: sketch.go:45-53 wraps only named *.gz files in a gzip reader)
+        const bool gz = !path.empty() && have_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b && lseek(fd, 0, SEEK_SET) == 0;
+        gzFile fh = nullptr;
+        if (gz) {
+            fh = gzdopen(fd, "rb");
+            if (!fh) { close(fd); finish("cannot open " + path); return; }
+            gzbuffer(fh, 1u << 20);
+        }
         char last = '\n';
+        bool first = true;
         for (;;) {
             std::unique_ptr<RawBlock> b(new RawBlock());
             b->buf.resize(kHeadroom + block_bytes + 1);
+            char *dst = b->buf.data() + kHeadroom;
             size_t fill = 0;
             bool eof = false;
+            if (first && !gz) { memcpy(dst, magic, have_magic); fill = have_magic; }
+            first = false;
             while (fill < block_bytes) {
-                const int n = gzread(fh, b->buf.data() + kHeadroom + fill, (unsigned)std::min<size_t>(block_bytes - fill, 1u << 30));
-                if (n < 0) { gzclose(fh); finish("read error in FASTQ input " + path); return; }
+                const size_t want = std::min<size_t>(block_bytes - fill, 1u << 30);
+                const ssize_t n = gz ? (ssize_t)gzread(fh, dst + fill, (unsigned)want) : read(fd, dst + fill, want);
+                if (n < 0) {
+                    if (!gz && errno == EINTR) continue;
+                    if (gz) gzclose(fh); else if (fd) close(fd);
+                    finish("read error in FASTQ input " + path);
+                    return;
+                }
                 if (n == 0) { eof = true; break; }
                 fill += (size_t)n;
             }
-            if (fill) last = b->buf[kHeadroom + fill - 1];
-            if (eof && last != '\n') { b->buf[kHeadroom + fill++] = '\n'; last = '\n'; }   // a last line without '\n' ends at the file end
+            if (fill) last = dst[fill - 1];
+            if (eof && last != '\n') { dst[fill++] = '\n'; last = '\n'; }   // a last line without '\n' ends at the file end
             b->end = kHeadroom + fill;
             if (fill) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -83,7 +113,8 @@ struct Source {
             }
             if (eof) break;
         }
-        gzclose(fh);
+        if (gz) gzclose(fh);
+        else if (fd) close(fd);
         finish("");
     }
     void finish(const std::string &e)
@@ -345,7 +376,7 @@ int groot_reads_open(const char *const *files, uint32_t n_files, uint32_t n_thre
     if (!out || (n_files && !files)) return set_error(GROOT_E_INVALID, "null argument");
     std::unique_ptr<groot_reads> r(new groot_reads());
     for (uint32_t i = 0; i < n_files; i++) r->files.push_back(files[i]);
-    r->n_threads = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
+    r->n_threads = n_threads ? n_threads : usable_cpus();
     r->block_bytes = (size_t)std::min<uint64_t>(block_bytes ? block_bytes : (256ull << 20), 3ull << 30);
     r->max_batch_reads = max_batch_reads ? max_batch_reads : (1u << 20);
     r->max_batch_bases = max_batch_bases ? max_batch_bases : (uint64_t)r->max_batch_reads * 256;

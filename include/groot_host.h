@@ -38,6 +38,9 @@ extern "C" {
 typedef struct groot_index groot_index; /* owning handle; groot_index_view() borrows from it */
 
 const char *groot_host_last_error(void);
+/* CPUs this process may really use = min(affinity mask, cgroup CPU quota), or $GROOT_THREADS: what "0 = all cores"
+ * means throughout this library (a container may show 256 hardware threads and grant 16) */
+uint32_t groot_host_usable_cpus(void);
 const char *groot_host_version(void); /* "1.1.2": must equal Info.Version (cmd/align.go:96) */
 
 /* ---- index: `groot index` (cmd/index.go:44-52 defaults k=31 s=21 w=100 x=8 y=4) ---------------- */
