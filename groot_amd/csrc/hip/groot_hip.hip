@@ -402,46 +402,45 @@ template <int S, int MAXK, int M5> static void launch_seed_sm(const SeedArgs &a,
 
 static bool seed_supported(uint32_t s, uint32_t max_k)
 {
-    if (max_k != 4) return false;
-    switch (s) {
-    case 8: case 10: case 12: case 16: case 20: case 21: case 24: case 28: case 30: case 32: case 36: case 40: case 42: case 48: case 50:
-    case 56: case 64: return true;
-    default: return false;
-    }
+    // any `groot index -s / -y` (cmd/index.go:45-49): sizes without a compiled instance run the run-time-sized kernel
+    return s >= 1 && s <= (uint32_t)kGenericMaxS && max_k >= 1 && max_k <= s;
 }
 
-static void launch_seed(uint32_t s, const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
+static void launch_seed(uint32_t s, uint32_t max_k, const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
 {
     // low 5 bits of k * multiSeed: kernels specialised on it replace the per-slot 64-bit multiplies by adds
     const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (s == 21) {   // `groot index` default sketch size, for the common k-mer sizes
-        if (m5 == 6) return launch_seed_sm<21, 4, 6>(a, dump, grid, lds, st);     // k = 31 (default), 63
-        if (m5 == 10) return launch_seed_sm<21, 4, 10>(a, dump, grid, lds, st);   // k = 41
-        if (m5 == 14) return launch_seed_sm<21, 4, 14>(a, dump, grid, lds, st);   // k = 51
-        if (m5 == 2) return launch_seed_sm<21, 4, 2>(a, dump, grid, lds, st);     // k = 21
+    if (max_k == 4) {
+        if (s == 21) {   // `groot index` default sketch size, for the common k-mer sizes
+            if (m5 == 6) return launch_seed_sm<21, 4, 6>(a, dump, grid, lds, st);     // k = 31 (default), 63
+            if (m5 == 10) return launch_seed_sm<21, 4, 10>(a, dump, grid, lds, st);   // k = 41
+            if (m5 == 14) return launch_seed_sm<21, 4, 14>(a, dump, grid, lds, st);   // k = 51
+            if (m5 == 2) return launch_seed_sm<21, 4, 2>(a, dump, grid, lds, st);     // k = 21
+        }
+        if (s == 20 && m5 == 6) return launch_seed_sm<20, 4, 6>(a, dump, grid, lds, st);    // travis e2e: -k 31 -s 20
+        if (s == 30 && m5 == 14) return launch_seed_sm<30, 4, 14>(a, dump, grid, lds, st);  // pipeline tests: k = 51, s = 30
+        switch (s) {
+        case 8: return launch_seed_sm<8, 4, -1>(a, dump, grid, lds, st);
+        case 10: return launch_seed_sm<10, 4, -1>(a, dump, grid, lds, st);
+        case 12: return launch_seed_sm<12, 4, -1>(a, dump, grid, lds, st);
+        case 16: return launch_seed_sm<16, 4, -1>(a, dump, grid, lds, st);
+        case 20: return launch_seed_sm<20, 4, -1>(a, dump, grid, lds, st);
+        case 21: return launch_seed_sm<21, 4, -1>(a, dump, grid, lds, st);
+        case 24: return launch_seed_sm<24, 4, -1>(a, dump, grid, lds, st);
+        case 28: return launch_seed_sm<28, 4, -1>(a, dump, grid, lds, st);
+        case 30: return launch_seed_sm<30, 4, -1>(a, dump, grid, lds, st);
+        case 32: return launch_seed_sm<32, 4, -1>(a, dump, grid, lds, st);
+        case 36: return launch_seed_sm<36, 4, -1>(a, dump, grid, lds, st);
+        case 40: return launch_seed_sm<40, 4, -1>(a, dump, grid, lds, st);
+        case 42: return launch_seed_sm<42, 4, -1>(a, dump, grid, lds, st);
+        case 48: return launch_seed_sm<48, 4, -1>(a, dump, grid, lds, st);
+        case 50: return launch_seed_sm<50, 4, -1>(a, dump, grid, lds, st);
+        case 56: return launch_seed_sm<56, 4, -1>(a, dump, grid, lds, st);
+        case 64: return launch_seed_sm<64, 4, -1>(a, dump, grid, lds, st);
+        default: break;
+        }
     }
-    if (s == 20 && m5 == 6) return launch_seed_sm<20, 4, 6>(a, dump, grid, lds, st);    // travis e2e: -k 31 -s 20
-    if (s == 30 && m5 == 14) return launch_seed_sm<30, 4, 14>(a, dump, grid, lds, st);  // pipeline tests: k = 51, s = 30
-    switch (s) {
-    case 8: launch_seed_sm<8, 4, -1>(a, dump, grid, lds, st); break;
-    case 10: launch_seed_sm<10, 4, -1>(a, dump, grid, lds, st); break;
-    case 12: launch_seed_sm<12, 4, -1>(a, dump, grid, lds, st); break;
-    case 16: launch_seed_sm<16, 4, -1>(a, dump, grid, lds, st); break;
-    case 20: launch_seed_sm<20, 4, -1>(a, dump, grid, lds, st); break;
-    case 21: launch_seed_sm<21, 4, -1>(a, dump, grid, lds, st); break;
-    case 24: launch_seed_sm<24, 4, -1>(a, dump, grid, lds, st); break;
-    case 28: launch_seed_sm<28, 4, -1>(a, dump, grid, lds, st); break;
-    case 30: launch_seed_sm<30, 4, -1>(a, dump, grid, lds, st); break;
-    case 32: launch_seed_sm<32, 4, -1>(a, dump, grid, lds, st); break;
-    case 36: launch_seed_sm<36, 4, -1>(a, dump, grid, lds, st); break;
-    case 40: launch_seed_sm<40, 4, -1>(a, dump, grid, lds, st); break;
-    case 42: launch_seed_sm<42, 4, -1>(a, dump, grid, lds, st); break;
-    case 48: launch_seed_sm<48, 4, -1>(a, dump, grid, lds, st); break;
-    case 50: launch_seed_sm<50, 4, -1>(a, dump, grid, lds, st); break;
-    case 56: launch_seed_sm<56, 4, -1>(a, dump, grid, lds, st); break;
-    case 64: launch_seed_sm<64, 4, -1>(a, dump, grid, lds, st); break;
-    default: break;
-    }
+    launch_seed_sm<0, 0, -1>(a, dump, grid, lds, st);   // run-time sketch size / hash functions per band
 }
 
 static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
@@ -534,7 +533,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
-    launch_seed(c->s, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
+    launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(1), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
@@ -1014,7 +1013,8 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         if (!why.empty()) return fail(c, GROOT_E_FORMAT, "inconsistent index view: %s", why.c_str());
     }
     if (!seed_supported(v->sketch_size, v->max_k))
-        return fail(c, GROOT_E_UNSUPPORTED, "sketch size %u with maxK %u has no compiled kernel (see launch_seed)", v->sketch_size, v->max_k);
+        return fail(c, GROOT_E_UNSUPPORTED, "sketch size %u with maxK %u is outside what the kernels handle (1 <= maxK <= sketch size <= %d)", v->sketch_size,
+                    v->max_k, kGenericMaxS);
     c->s = v->sketch_size; c->k = v->kmer_size; c->max_k = v->max_k; c->l_max = v->sketch_size / v->max_k;
     c->pw_view = v->path_words; c->pw = round_pw(v->path_words);
     if (!c->pw) return fail(c, GROOT_E_UNSUPPORTED, "graphs with more than 704 paths are not supported (path_words=%u)", v->path_words);
@@ -1827,7 +1827,7 @@ int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
     a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.q_seen = nullptr; a.ctr = ctr.p;
-    launch_seed(c->s, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
+    launch_seed(c->s, c->max_k, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
     HIP_TRY(c, hipGetLastError());
     DeviceCounters h{};
     HIP_TRY(c, hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));

@@ -154,9 +154,14 @@ constexpr uint32_t kLdsReads = 4096 + 192;       // staged read bytes (16-byte a
 // slots i < 32 then equal C0 + (i ^ M5) with C0 = (k*multiSeed) & ~31, so h*c_i for all slots comes from ONE
 // 64-bit multiply (h*C0) and a running sum (+h per step) instead of a quarter-rate 64-bit multiply per slot.
 // M5 < 0: generic path (any k, any S).
+// S = 0 / MAXK = 0: sketch size and hash functions per band are taken from the index at run time (any `groot index -s / -y`,
+// cmd/index.go:45-49): the minima then live in an array indexed at run time (private memory), which is correct and slow;
+// the sizes people use have compiled instances.
+constexpr int kGenericMaxS = 256;      // largest sketch the run-time-sized instance handles
 template <int S, int MAXK, bool DUMP, int M5>
-__global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(SeedArgs a)
+__global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_kernel(SeedArgs a)
 {
+    constexpr int SM = S ? S : kGenericMaxS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *tabF = reinterpret_cast<uint64_t *>(smem + kLdsTabF);
     uint64_t *tabFout = reinterpret_cast<uint64_t *>(smem + kLdsTabFout);
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
     const DeviceIndex &ix = a.ix;
     const unsigned tid = threadIdx.x;
     const uint32_t k = ix.k;
+    const int s_ = S ? S : (int)ix.s, maxk_ = MAXK ? MAXK : (int)ix.max_k;
     {
         const uint64_t sd = seed_tab(tid);
         tabF[tid] = sd;
@@ -214,9 +220,9 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
         return;
     }
     // ---- KHF sketch (khf.go:35-55): per slot i, min over k-mers of MultiHash_i(canonical ntHash) ----
-    uint64_t m[S];
+    uint64_t m[SM];
 #pragma unroll
-    for (int i = 0; i < S; i++) m[i] = ~0ULL;
+    for (int i = 0; i < s_; i++) m[i] = ~0ULL;
     const uint64_t M = (uint64_t)k * GROOT_MULTI_SEED;
     const uint32_t nk = len - k + 1;
     unsigned high = 0;                       // any byte > 'T': RevComplement would panic (seqio.go:126)
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
         for (uint32_t j = 0;;) {
             const uint64_t h = fh < rh ? fh : rh;          // canonical
             m[0] = h < m[0] ? h : m[0];
-            if (M5 >= 0 && S <= 32) {
+            if (M5 >= 0 && S > 0 && S <= 32) {
                 uint64_t acc = h * (M & ~31ULL);           // = h * c_i for the slot with (i ^ M5) == 0
 #pragma unroll
                 for (int d = 0; d < 32; d++) {
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
                 }
             } else {
 #pragma unroll
-                for (int i = 1; i < S; i++) {
+                for (int i = 1; i < s_; i++) {
                     uint64_t t = h * ((uint64_t)i ^ M);
                     t ^= t >> GROOT_MULTI_SHIFT;
                     m[i] = t < m[i] ? t : m[i];
@@ -261,12 +267,12 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
     else sketch(a.seq + o0);                         // span too large for LDS: straight from HBM
     if (DUMP) {
 #pragma unroll
-        for (int i = 0; i < S; i++) a.sketch_out[(size_t)r * S + i] = m[i];
+        for (int i = 0; i < s_; i++) a.sketch_out[(size_t)r * s_ + i] = m[i];
     }
 
     // ---- ContainmentIndex.Query (lshe.go:153-175) ----
     const uint32_t q = nk;                                 // kmerCount, boss.go:169
-    const uint32_t min_eq = q <= ix.max_q ? ix.q_min_eq[q] : (uint32_t)S + 1;
+    const uint32_t min_eq = q <= ix.max_q ? ix.q_min_eq[q] : (uint32_t)s_ + 1;
     uint32_t min_win = kEmpty;
     uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;   // first four seeds, for the read record
     auto hit = [&](uint32_t id) {
@@ -275,44 +281,44 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
         n_hits++;
         min_win = min(min_win, id);
     };
-    if (min_eq == (uint32_t)S) {
+    if (min_eq == (uint32_t)s_) {
         // Containment > t needs every slot equal: windows with an identical sketch.  One probe
         // sequence of the exact-match table (all such windows are consecutive probes).
         uint64_t hs = GROOT_SKETCH_HASH_INIT;
 #pragma unroll
-        for (int i = 0; i < S; i++) hs = sketch_hash_step(hs, m[i]);
+        for (int i = 0; i < s_; i++) hs = sketch_hash_step(hs, m[i]);
         const uint32_t tag = (uint32_t)(hs >> 32);
         for (uint32_t slot = (uint32_t)hs & ix.exact_mask;; slot = (slot + 1) & ix.exact_mask) {
             const ExactEntry e = ix.exact[slot];
             if (e.id == kEmpty) break;
             if (e.tag != tag) continue;
-            const uint64_t *ws = ix.win_sketch + (size_t)e.id * S;
+            const uint64_t *ws = ix.win_sketch + (size_t)e.id * s_;
             bool same = true;
 #pragma unroll
-            for (int i = 0; i < S; i++) same &= ws[i] == m[i];
+            for (int i = 0; i < s_; i++) same &= ws[i] == m[i];
             if (same) hit(e.id);
         }
-    } else if (min_eq < (uint32_t)S) {
+    } else if (min_eq < (uint32_t)s_) {
         // General LSH Forest query: bands b < L, prefix of K hash values (low 32 bits) per band;
         // a window found through band b is skipped if an earlier band already returned it.
-        constexpr int LMAX = S / MAXK;
+        const int lmax_ = s_ / maxk_;
         const uint32_t K = ix.q_k[q], L = ix.q_l[q];
         const uint32_t n = ix.n_windows;
-        constexpr int SL = S < 32 ? S : 32;                 // slots covered by the row signatures
+        const int sl_ = s_ < 32 ? s_ : 32;                  // slots covered by the row signatures
         uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < SL; i++) rs[i >> 2] |= sig8(m[i]) << (8 * (i & 3));
+        for (int i = 0; i < sl_; i++) rs[i >> 2] |= sig8(m[i]) << (8 * (i & 3));
 #pragma unroll
-        for (int b = 0; b < LMAX; b++) {
+        for (int b = 0; b < lmax_; b++) {
             if ((uint32_t)b >= L) break;
-            const uint32_t *keys = ix.band_keys + (size_t)b * n * MAXK;
+            const uint32_t *keys = ix.band_keys + (size_t)b * n * maxk_;
             const uint32_t *ids = ix.band_ids + (size_t)b * n;
             auto cmp = [&](uint32_t e) {      // -1 / 0 / +1 : table entry e vs query prefix
-                const uint32_t *ke = keys + (size_t)e * MAXK;
+                const uint32_t *ke = keys + (size_t)e * maxk_;
 #pragma unroll
-                for (int j = 0; j < MAXK; j++) {
+                for (int j = 0; j < maxk_; j++) {
                     if ((uint32_t)j >= K) break;
-                    const uint32_t qv = (uint32_t)m[b * MAXK + j], kv = ke[j];
+                    const uint32_t qv = (uint32_t)m[b * maxk_ + j], kv = ke[j];
                     if (kv != qv) return kv < qv ? -1 : 1;
                 }
                 return 0;
@@ -322,9 +328,9 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
             if (K >= 1) {
                 uint64_t hk = GROOT_SKETCH_HASH_INIT;
 #pragma unroll
-                for (int j = 0; j < MAXK; j++)
-                    if ((uint32_t)j < K) hk = sketch_hash_step(hk, (uint32_t)m[b * MAXK + j]);
-                const ExactEntry *tab = ix.band_hash + (((size_t)b * MAXK + (K - 1)) << ix.band_hash_bits);
+                for (int j = 0; j < maxk_; j++)
+                    if ((uint32_t)j < K) hk = sketch_hash_step(hk, (uint32_t)m[b * maxk_ + j]);
+                const ExactEntry *tab = ix.band_hash + (((size_t)b * maxk_ + (K - 1)) << ix.band_hash_bits);
                 const uint32_t hmask = (1u << ix.band_hash_bits) - 1u, tag = (uint32_t)(hk >> 32);
                 for (uint32_t slot = (uint32_t)hk & hmask;; slot = (slot + 1) & hmask) {
                     const ExactEntry e = tab[slot];
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
                 }
             }
             const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * 32);
-            const uint32_t e_end = lo < n ? lo + ix.band_run[((size_t)b * MAXK + (K - 1)) * n + lo] : n;   // rows with this prefix
+            const uint32_t e_end = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
             for (uint32_t e = lo; e < e_end; e++) {
                 // slots whose signature bytes agree (pad bytes are zero on both sides): an upper bound of the equal slots
                 const uint4 sa = sigs[2 * (size_t)e], sb = sigs[2 * (size_t)e + 1];
@@ -344,24 +350,24 @@ __global__ __launch_bounds__(kBlock, GROOT_SEED_WAVES) void sketch_seed_kernel(S
                     const uint32_t x = ws8[i] ^ rs[i];
                     same += __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));
                 }
-                if (same - (32u - SL) + (uint32_t)(S - SL) < min_eq) continue;
+                if (same - (32u - (uint32_t)sl_) + (uint32_t)(s_ - sl_) < min_eq) continue;
                 const uint32_t id = ids[e];
-                const uint64_t *ws = ix.win_sketch + (size_t)id * S;
+                const uint64_t *ws = ix.win_sketch + (size_t)id * s_;
                 uint32_t eq = 0;
                 bool earlier = false;
 #pragma unroll
-                for (int bb = 0; bb < LMAX; bb++) {
+                for (int bb = 0; bb < lmax_; bb++) {
                     bool pm = true;
 #pragma unroll
-                    for (int j = 0; j < MAXK; j++) {
-                        const uint64_t wv = ws[bb * MAXK + j];
-                        eq += wv == m[bb * MAXK + j];
-                        if ((uint32_t)j < K) pm &= (uint32_t)wv == (uint32_t)m[bb * MAXK + j];
+                    for (int j = 0; j < maxk_; j++) {
+                        const uint64_t wv = ws[bb * maxk_ + j];
+                        eq += wv == m[bb * maxk_ + j];
+                        if ((uint32_t)j < K) pm &= (uint32_t)wv == (uint32_t)m[bb * maxk_ + j];
                     }
                     if (bb < b && pm) earlier = true;
                 }
 #pragma unroll
-                for (int i = LMAX * MAXK; i < S; i++) eq += ws[i] == m[i];
+                for (int i = lmax_ * maxk_; i < s_; i++) eq += ws[i] == m[i];
                 if (!earlier && eq >= min_eq) hit(id);
             }
         }

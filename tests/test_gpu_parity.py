@@ -308,12 +308,17 @@ def test_long_reads_take_the_unstaged_variant(msa_dir, threshold):
     al.close()
 
 
-@pytest.mark.parametrize("k,sketch,w", [(11, 8, 50), (15, 16, 60), (21, 24, 80), (31, 32, 100), (25, 42, 120), (31, 64, 100), (9, 10, 40),
-                                          (13, 12, 50), (27, 28, 90), (31, 36, 100), (31, 40, 100), (21, 48, 100), (31, 50, 100), (31, 56, 110)])
-def test_other_index_parameters(msa_dir, k, sketch, w):
+@pytest.mark.parametrize("k,sketch,w,y", [(11, 8, 50, 4), (15, 16, 60, 4), (21, 24, 80, 4), (31, 32, 100, 4), (25, 42, 120, 4), (31, 64, 100, 4),
+                                            (9, 10, 40, 4), (13, 12, 50, 4), (27, 28, 90, 4), (31, 36, 100, 4), (31, 40, 100, 4), (21, 48, 100, 4),
+                                            (31, 50, 100, 4), (31, 56, 110, 4),
+                                            # any `groot index -s / -y` (cmd/index.go:45-49): the run-time-sized kernel instance
+                                            (31, 25, 100, 2), (31, 25, 100, 8), (21, 7, 60, 3), (31, 21, 100, 1), (31, 21, 100, 7), (25, 100, 90, 5),
+                                            (31, 33, 100, 4)])
+def test_other_index_parameters(msa_dir, k, sketch, w, y):
     """every compiled sketch size (and k-mer sizes that take the generic multiplier path / leave fewer than 12 bases to the
-    prefix tables' second 6-mer): window-sized and shorter reads, both strands, two thresholds"""
-    index = host.Index.from_msa_files(host.msa_files(msa_dir)[:8], host.index_params(k=k, s=sketch, w=w))
+    prefix tables' second 6-mer) and sizes / hash-functions-per-band without a compiled instance: window-sized and shorter
+    reads, both strands, two thresholds"""
+    index = host.Index.from_msa_files(host.msa_files(msa_dir)[:8], host.index_params(k=k, s=sketch, w=w, y=y))
     cat, o, lens = synth.reference_sequences(index)
     rng = np.random.default_rng(k * 1000 + sketch)
     comp = bytes.maketrans(b"ACGTN", b"TGCAN")
