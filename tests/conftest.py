@@ -30,6 +30,15 @@ def native_libs():
 def hip_lib(native_libs):
     import __graft_entry__ as g
 
+    # torch bundles its own HIP runtime: when a test uses torch tensors next to libgroot_hip.so, torch has to bring its copy
+    # up first (the other order leaves torch with "No HIP GPUs are available"), whatever order the tests run in
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     return g.build_hip()
 
 
