@@ -157,14 +157,14 @@ def host_fed(index, d_seq, R, steps, depth=3):
         al.submit_acquired(b["ticket"], R, len(exc_pos))
         if al.in_flight()[0] == depth:
             r = al.collect(copy=False)
-            trav_bytes += r["n_travs"] * (20 + 8 * index.view.path_words)
+            trav_bytes += r["n_travs"] * 20 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4
             for k, v in r["ms"].items():
                 stage[k] = stage.get(k, 0.0) + v
             al.release(r["ticket"])
             done += 1
     while done < steps:
         r = al.collect(copy=False)
-        trav_bytes += r["n_travs"] * (20 + 8 * index.view.path_words)
+        trav_bytes += r["n_travs"] * 20 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4
         for k, v in r["ms"].items():
             stage[k] = stage.get(k, 0.0) + v
         al.release(r["ticket"])

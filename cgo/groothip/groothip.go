@@ -229,7 +229,7 @@ type Result struct {
 	NumReads  int
 	Counts    Counts
 	Travs     []Trav
-	Masks     []uint64 // PathWords words per traversal: bit p = local path id p
+	Masks     []uint64 // PathWords words per traversal: bit p = local path id p (widened from the compact wire form)
 	PathWords int
 }
 
@@ -254,7 +254,11 @@ func (c *Ctx) Collect() (*Result, error) {
 		uint64(r.counts.seeds), uint64(r.counts.travs), uint64(r.counts.revcomp_panics), uint64(r.counts.short_reads)}
 	if n > 0 {
 		res.Travs = (*[1 << 28]Trav)(unsafe.Pointer(r.travs))[:n:n]
-		res.Masks = (*[1 << 30]uint64)(unsafe.Pointer(r.masks))[: n*res.PathWords : n*res.PathWords]
+		// the path sets travel compact (as many words as the traversal's graph has paths / 64); widen them once per batch
+		res.Masks = make([]uint64, n*res.PathWords)
+		if rc := C.groot_host_unpack_masks(&c.idx.view, r.travs, C.uint64_t(n), r.masks, (*C.uint64_t)(unsafe.Pointer(&res.Masks[0]))); rc != 0 {
+			return nil, fmt.Errorf("groot_host_unpack_masks: %s", C.GoString(C.groot_host_last_error()))
+		}
 	}
 	return res, nil
 }

@@ -571,7 +571,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
                 if (bam && it.res.n_travs && !failed) {
                     uint64_t nrec = 0;
                     auto tw = std::chrono::steady_clock::now();
-                    const int wrc = groot_bam_write_batch(bam, &v, &it.view, 0, it.res.travs, it.res.masks, it.res.n_travs, &nrec);
+                    const int wrc = groot_bam_write_batch(bam, &v, &it.view, 0, it.res.travs, it.res.masks, it.res.mask_ckpt, it.res.n_travs, &nrec);
                     bam_s += seconds_since(tw);
                     if (wrc) fail_with(groot_host_last_error());
                     else if (nrec != c.alignments)

@@ -29,6 +29,8 @@ struct DeviceCounters {
     unsigned int max_seeds;     // largest per-read seed count seen
     unsigned int flags;
     unsigned int q_rows;        // rows of the call-count table in use after this batch (may exceed its capacity: then kFlagQOverflow)
+    unsigned int mask_words;    // 64-bit words of the compact path sets of this batch (mask_compact_kernel)
+    unsigned int pad2;
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };

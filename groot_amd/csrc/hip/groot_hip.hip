@@ -93,8 +93,12 @@ struct Slot {
     DevBuf<DeviceCounters> d_ctr;
     PinBuf<DeviceCounters> h_ctr;
     PinBuf<groot_trav> h_trav;
-    PinBuf<uint64_t> h_mask;
+    PinBuf<uint64_t> h_mask;                       // COMPACT path sets: ceil(paths(graph) / 64) words per traversal
+    PinBuf<uint32_t> h_ckpt;                       // offset into h_mask of every 256th traversal
+    DevBuf<uint64_t> d_cmask;                      // the compact copy the copy-out takes (host-result mode)
+    DevBuf<uint32_t> d_mwords, d_moff, d_ckpt;
     uint32_t n_trav = 0, copied = 0;               // records of the batch / records the copy-out enqueued at submit covers
+    uint64_t n_mask_words = 0, copied_words = 0;
     bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
     hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
     hipEvent_t ev[7]{};                    // stage boundaries on the compute stream (profiling)
@@ -134,6 +138,9 @@ struct groot_ctx {
     uint64_t next_ticket = 1;
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
     double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
+    double words_per_trav = 0;             // compact path-set words per traversal, likewise (0 = not seen yet: path_words)
+    DevBuf<uint8_t> graph_words;           // ceil(paths / 64) per graph
+    std::vector<uint8_t> h_graph_words;
     Slot *work_owner = nullptr;            // whose seeds / sketches the shared work buffers hold
     uint64_t work_ticket = 0;
 
@@ -475,6 +482,11 @@ static int alloc_trav(groot_ctx *c, Slot *s, uint32_t cap)
     if (!c->prm.results_on_device) {
         HIP_TRY(c, s->h_trav.alloc((size_t)cap + 2));
         HIP_TRY(c, s->h_mask.alloc((size_t)cap * c->pw_view + 2));
+        HIP_TRY(c, s->h_ckpt.alloc((size_t)cap / 256 + 2));
+        HIP_TRY(c, s->d_cmask.alloc((size_t)cap * c->pw_view + 2));
+        HIP_TRY(c, s->d_mwords.alloc(cap));
+        HIP_TRY(c, s->d_moff.alloc(cap));
+        HIP_TRY(c, s->d_ckpt.alloc((size_t)cap / 256 + 2));
     }
     return GROOT_OK;
 }
@@ -615,6 +627,21 @@ static int launch_order_stage(groot_ctx *c, Slot *s)
                        c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, s->first_read_id, s->d_trav.p,
                        s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
     HIP_TRY(c, hipGetLastError());
+    if (!c->prm.results_on_device) {
+        // compact path sets for the copy-out (kernels.hpp): words per traversal, their exclusive scan, the copy
+        const dim3 g((s->trav_cap + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(mask_words_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_ctr.p, s->trav_cap, c->graph_words.p, s->d_mwords.p);
+        size_t tb = 0;
+        HIP_TRY(c, rocprim::exclusive_scan(nullptr, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
+        if (tb > c->scan_tmp.n) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, c->scan_tmp.alloc(tb + tb / 4));
+        }
+        HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
+        hipLaunchKernelGGL(mask_compact_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_mask.p, c->pw_view, s->d_ctr.p, s->trav_cap,
+                           c->graph_words.p, s->d_moff.p, s->d_cmask.p, s->d_ckpt.p);
+        HIP_TRY(c, hipGetLastError());
+    }
     return GROOT_OK;
 }
 
@@ -772,8 +799,11 @@ static int enqueue(groot_ctx *c, Slot *s)
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h0, c->d2h_stream));
         const uint64_t predicted = (uint64_t)((double)s->n_reads * c->trav_per_read * 1.06) + 4096;
         s->copied = (uint32_t)std::min<uint64_t>(predicted, s->trav_cap);
+        const double wpt = c->words_per_trav > 0 ? c->words_per_trav : (double)c->pw_view;
+        s->copied_words = std::min<uint64_t>((uint64_t)((double)s->copied * wpt * 1.04) + 4096, (uint64_t)s->trav_cap * c->pw_view);
         HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->copied * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
-        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_mask.p, (size_t)s->copied * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_cmask.p, (size_t)s->copied_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->copied / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h_stream));
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h, c->d2h_stream));
     }
     HIP_TRY(c, hipMemcpyAsync(s->h_ctr.p, s->d_ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->d2h_stream));
@@ -869,13 +899,17 @@ static int finish_counters(groot_ctx *c, Slot *s)
 #endif
     // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
     if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
+    s->n_mask_words = s->n_trav ? h.mask_words : 0;
     if (!c->prm.results_on_device && s->n_trav) {
+        c->words_per_trav = (double)s->n_mask_words / (double)s->n_trav;
         const uint32_t have = redone ? 0 : std::min(s->copied, s->n_trav);      // a redo re-made the records: fetch them all
         if (have < s->n_trav) {
             HIP_TRY(c, hipMemcpy(s->h_trav.p + have, s->d_trav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_trav), hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(s->h_mask.p + (size_t)have * c->pw_view, s->d_mask.p + (size_t)have * c->pw_view,
-                                 (size_t)(s->n_trav - have) * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->n_trav / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
         }
+        const uint64_t have_w = redone ? 0 : std::min<uint64_t>(s->copied_words, s->n_mask_words);
+        if (have_w < s->n_mask_words)
+            HIP_TRY(c, hipMemcpy(s->h_mask.p + have_w, s->d_cmask.p + have_w, (size_t)(s->n_mask_words - have_w) * sizeof(uint64_t), hipMemcpyDeviceToHost));
         s->host_results = true;
     }
     s->state = Slot::D2H_ISSUED;
@@ -1056,6 +1090,12 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
+    {
+        std::vector<uint8_t> gw(v->n_graphs, 1);
+        for (uint32_t g = 0; g < v->n_graphs; g++) gw[g] = (uint8_t)std::max<uint32_t>(1, (v->graph_path_off[g + 1] - v->graph_path_off[g] + 63) / 64);
+        HIP_TRY(c, upload(c->graph_words, gw.data(), gw.size()));
+        c->h_graph_words = gw;
+    }
     {
         std::vector<WinRec> wr(v->n_windows);
         for (uint32_t w = 0; w < v->n_windows; w++) {
@@ -1440,6 +1480,8 @@ int groot_hip_collect(groot_ctx *c, groot_batch_result *out)
     out->n_travs = s->n_trav;
     out->travs = s->host_results ? s->h_trav.p : nullptr;
     out->masks = s->host_results ? s->h_mask.p : nullptr;
+    out->mask_ckpt = s->host_results ? s->h_ckpt.p : nullptr;
+    out->n_mask_words = s->host_results ? s->n_mask_words : 0;
     out->d_travs = s->d_trav.p; out->d_masks = s->d_mask.p;
     out->path_words = c->pw_view;
     out->status = s->status;
@@ -1496,7 +1538,15 @@ int groot_hip_read_travs(groot_ctx *c, groot_trav *out, uint64_t *masks, uint64_
     const uint64_t m = std::min<uint64_t>(cap, s->n_trav);
     if (s->host_results) {
         if (m && out) memcpy(out, s->h_trav.p, m * sizeof(groot_trav));
-        if (m && masks) memcpy(masks, s->h_mask.p, m * c->pw_view * sizeof(uint64_t));
+        if (m && masks) {        // compact path sets back to path_words words per traversal
+            memset(masks, 0, m * c->pw_view * sizeof(uint64_t));
+            uint64_t o = 0;
+            for (uint64_t i = 0; i < m; i++) {
+                const uint32_t w = c->h_graph_words[s->h_trav.p[i].graph_id];
+                memcpy(masks + i * c->pw_view, s->h_mask.p + o, (size_t)w * sizeof(uint64_t));
+                o += w;
+            }
+        }
     } else {
         if (m && out) HIP_TRY(c, hipMemcpy(out, s->d_trav.p, m * sizeof(groot_trav), hipMemcpyDeviceToHost));
         if (m && masks) HIP_TRY(c, hipMemcpy(masks, s->d_mask.p, m * c->pw_view * sizeof(uint64_t), hipMemcpyDeviceToHost));

@@ -1138,5 +1138,30 @@ __global__ __launch_bounds__(kBlock) void order_ovf_kernel(const groot_trav *ovf
     for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = ovf_mask[o * pw_in + w];
 }
 
+// ---- compact path sets for the copy-out --------------------------------------------------------------------
+// A traversal's path set needs only as many 64-bit words as its graph has paths (one word for 579 of the 583 arg-annot.90
+// graphs, three for the widest): the copy-out carries ceil(paths(graph) / 64) words per traversal instead of path_words,
+// 33 instead of 46 bytes per read over PCIe.  words[i] for traversal i (0 beyond the batch's count), an exclusive scan of
+// them (rocprim), then the copy; every 256th offset is kept as a checkpoint for the host.
+__global__ __launch_bounds__(kBlock) void mask_words_kernel(const groot_trav *__restrict__ trav, const DeviceCounters *ctr, uint32_t cap,
+                                                          const uint8_t *__restrict__ graph_words, uint32_t *__restrict__ words)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap) return;
+    words[i] = i < min(ctr->n_trav, cap) ? graph_words[trav[i].graph_id] : 0u;
+}
+__global__ __launch_bounds__(kBlock) void mask_compact_kernel(const groot_trav *__restrict__ trav, const uint64_t *__restrict__ mask, uint32_t pw_in,
+                                                            DeviceCounters *ctr, uint32_t cap, const uint8_t *__restrict__ graph_words,
+                                                            const uint32_t *__restrict__ off, uint64_t *__restrict__ out, uint32_t *__restrict__ ckpt)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n = min(ctr->n_trav, cap);
+    if (i >= n) return;
+    const uint32_t o = off[i], w = graph_words[trav[i].graph_id];
+    for (uint32_t x = 0; x < w; x++) out[(size_t)o + x] = mask[(size_t)i * pw_in + x];
+    if ((i & 255u) == 0) ckpt[i >> 8] = o;
+    if (i == n - 1) ctr->mask_words = o + w;
+}
+
 // sketch-only entry (groot_hip_sketch): reuse K1 with an index that has no windows
 } // namespace groot

@@ -297,8 +297,8 @@ struct ReadRef {
 // traversals; blocks are written in traversal order = read order.  read(r, ref) fills the read's fields, false if r is
 // out of range.
 template <class ReadFn>
-static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn read, const groot_trav *travs, const uint64_t *masks, uint64_t n_trav,
-                            uint64_t *n_records)
+static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn read, const groot_trav *travs, const uint64_t *masks,
+                            const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records)
 {
     if (n_records) *n_records = 0;
     if (!n_trav) return GROOT_OK;
@@ -322,6 +322,7 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
             if (c >= n_chunks) break;
             raw.clear();
             const uint64_t t0 = c * kChunk, t1 = std::min<uint64_t>(n_trav, t0 + kChunk);
+            uint64_t moff = mask_ckpt ? mask_ckpt[c] : 0;        // compact path sets: a checkpoint per chunk (kChunk = 256 traversals)
             for (uint64_t t = t0; t < t1; t++) {
                 const groot_trav &tr = travs[t];
                 ReadRef rd;
@@ -346,8 +347,11 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                 bool first = (tr.flags & GROOT_TRAV_FIRST) != 0;
                 recs.clear();
                 const uint32_t np0 = ix->node_np_off[tr.node], np1 = ix->node_np_off[tr.node + 1];
-                for (uint32_t w = 0; w < pw; w++) {
-                    uint64_t m = masks[t * pw + w];
+                const uint32_t gw = mask_ckpt ? std::max<uint32_t>(1, (ix->graph_path_off[tr.graph_id + 1] - ix->graph_path_off[tr.graph_id] + 63) / 64) : pw;
+                const uint64_t *mk = mask_ckpt ? masks + moff : masks + t * pw;
+                moff += gw;
+                for (uint32_t w = 0; w < gw; w++) {
+                    uint64_t m = mk[w];
                     while (m) {
                         const uint32_t p = w * 64 + (uint32_t)__builtin_ctzll(m);
                         m &= m - 1;
@@ -429,11 +433,11 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
         o.name_len = (uint32_t)(rb->name_off[r + 1] - rb->name_off[r]);
         return true;
     };
-    return write_travs_impl(b, ix, read, travs, masks, n_trav, n_records);
+    return write_travs_impl(b, ix, read, travs, masks, nullptr, n_trav, n_records);
 }
 
 int groot_bam_write_batch(groot_bam *b, const groot_index_view *ix, const groot_reads_view *rv, uint32_t first_read_id, const groot_trav *travs,
-                          const uint64_t *masks, uint64_t n_trav, uint64_t *n_records)
+                          const uint64_t *masks, const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records)
 {
     if (!b || !ix || !rv || (n_trav && (!travs || !masks))) return set_error(GROOT_E_INVALID, "null argument");
     auto read = [rv, first_read_id](uint32_t read_id, ReadRef &o) -> bool {
@@ -447,7 +451,7 @@ int groot_bam_write_batch(groot_bam *b, const groot_index_view *ix, const groot_
         o.name_len = rv->name_len[r];
         return true;
     };
-    return write_travs_impl(b, ix, read, travs, masks, n_trav, n_records);
+    return write_travs_impl(b, ix, read, travs, masks, mask_ckpt, n_trav, n_records);
 }
 
 int groot_bam_set_level(groot_bam *b, int level)

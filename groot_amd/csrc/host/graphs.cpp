@@ -6,6 +6,8 @@
 //   src/graph/graphio.go:19-112              SaveGraphAsGFA (dialect pinned by src/graph/test2.gfa)
 #include "host_common.hpp"
 
+#include <algorithm>
+
 #include <cstring>
 #include <ctime>
 
@@ -92,6 +94,21 @@ int groot_host_weights(const groot_index_view *ix, const uint32_t *attempts, uin
             const uint32_t c = attempts[(size_t)q * ix->n_windows + w];
             for (uint32_t i = 0; i < c; i++) increment_sub_path(ix, w, double(q), kf, kt);
         }
+    return GROOT_OK;
+}
+
+int groot_host_unpack_masks(const groot_index_view *ix, const groot_trav *travs, uint64_t n_trav, const uint64_t *compact, uint64_t *out)
+{
+    if (!ix || (n_trav && (!travs || !compact || !out))) return set_error(GROOT_E_INVALID, "null argument");
+    const uint32_t pw = ix->path_words;
+    uint64_t o = 0;
+    for (uint64_t i = 0; i < n_trav; i++) {
+        const uint32_t g = travs[i].graph_id;
+        if (g >= ix->n_graphs) return set_error(GROOT_E_INVALID, "traversal %llu: graph id out of range", (unsigned long long)i);
+        const uint32_t w = std::max<uint32_t>(1, (ix->graph_path_off[g + 1] - ix->graph_path_off[g] + 63) / 64);
+        for (uint32_t x = 0; x < pw; x++) out[i * pw + x] = x < w ? compact[o + x] : 0;
+        o += w;
+    }
     return GROOT_OK;
 }
 

@@ -47,7 +47,8 @@ class BatchBuffers(C.Structure):
 class BatchResult(C.Structure):
     """groot_batch_result"""
     _fields_ = [("ticket", C.c_uint64), ("first_read_id", C.c_uint32), ("n_reads", C.c_uint32), ("counts", Counts),
-                ("travs", C.c_void_p), ("masks", C.c_void_p), ("n_travs", C.c_uint64), ("d_travs", C.c_void_p),
+                ("travs", C.c_void_p), ("masks", C.c_void_p), ("mask_ckpt", C.c_void_p), ("n_mask_words", C.c_uint64),
+                ("n_travs", C.c_uint64), ("d_travs", C.c_void_p),
                 ("d_masks", C.c_void_p), ("path_words", C.c_uint32), ("status", C.c_int32), ("ms", StageMs)]
 
 
@@ -73,6 +74,16 @@ def device_count():
     n = C.c_int(0)
     rc = lib().groot_hip_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def unpack_masks(index, travs, compact_masks):
+    """groot_host_unpack_masks: the compact path sets of collect(copy=False) -> [n, path_words]"""
+    travs = np.ascontiguousarray(travs, dtype=TRAV_DTYPE)
+    cm = np.ascontiguousarray(compact_masks, dtype=np.uint64)
+    out = np.zeros((len(travs), index.view.path_words), dtype=np.uint64)
+    host._check(host.lib().groot_host_unpack_masks(C.byref(index.view), travs.ctypes.data_as(C.c_void_p), C.c_uint64(len(travs)),
+                                                   _ffi.as_ptr(cm, C.c_uint64), _ffi.as_ptr(out, C.c_uint64)))
+    return out
 
 
 def expand_alns(index, travs, masks):
@@ -175,13 +186,19 @@ class Aligner:
         n = int(r.n_travs)
         if r.travs and n:
             t = _ffi._np_view(C.cast(r.travs, C.POINTER(C.c_uint8)), n * TRAV_DTYPE.itemsize, np.uint8).view(TRAV_DTYPE)
-            m = _ffi._np_view(C.cast(r.masks, C.POINTER(C.c_uint64)), n * r.path_words, np.uint64).reshape(n, r.path_words)
             if copy:
-                t, m = t.copy(), m.copy()
+                # the compact path sets widened to path_words words per traversal (groot_host_unpack_masks)
+                m = np.zeros((n, r.path_words), dtype=np.uint64)
+                host._check(host.lib().groot_host_unpack_masks(C.byref(self.index.view), C.c_void_p(r.travs), C.c_uint64(n), C.c_void_p(r.masks),
+                                                               _ffi.as_ptr(m, C.c_uint64)))
+                t = t.copy()
+            else:
+                m = _ffi._np_view(C.cast(r.masks, C.POINTER(C.c_uint64)), int(r.n_mask_words), np.uint64)   # compact, as handed out
         else:
             t, m = np.zeros(0, dtype=TRAV_DTYPE), np.zeros((0, self.path_words), dtype=np.uint64)
         return {"ticket": int(r.ticket), "first_read_id": int(r.first_read_id), "n_reads": int(r.n_reads), "counts": r.counts.as_dict(),
-                "status": int(r.status), "n_travs": n, "travs": t, "masks": m, "d_travs": r.d_travs, "d_masks": r.d_masks,
+                "status": int(r.status), "n_travs": n, "travs": t, "masks": m, "n_mask_words": int(r.n_mask_words), "d_travs": r.d_travs,
+                "d_masks": r.d_masks,
                 "ms": {k: float(getattr(r.ms, k)) for k, _ in StageMs._fields_}}
 
     def release(self, ticket):

@@ -229,5 +229,5 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     single = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert single["n_gpus"] == 1 and single["config"]["per_step_counts"]["received"] == 300000
     # the PCIe- and host-inclusive legs ride on the same line
-    assert single["host_fed"]["value"] > 0 and single["host_fed"]["d2h_bytes_per_read"] > 20, single["host_fed"]
-    assert single["cli_e2e"]["value"] > 0 and single["cli_e2e"]["reads"] == 300000, single["cli_e2e"]
+    assert single["host_fed"].get("value", 0) > 0 and single["host_fed"]["d2h_bytes_per_read"] > 20, single["host_fed"]
+    assert single["cli_e2e"].get("value", 0) > 0 and single["cli_e2e"]["reads"] == 300000, single["cli_e2e"]
