@@ -630,7 +630,8 @@ static int launch_order_stage(groot_ctx *c, Slot *s)
     if (!c->prm.results_on_device) {
         // compact path sets for the copy-out (kernels.hpp): words per traversal, their exclusive scan, the copy
         const dim3 g((s->trav_cap + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(mask_words_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_ctr.p, s->trav_cap, c->graph_words.p, s->d_mwords.p);
+        hipLaunchKernelGGL(mask_words_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_ctr.p, s->trav_cap, c->graph_words.p, (uint32_t)c->h_graph_words.size(),
+                           s->d_mwords.p);
         size_t tb = 0;
         HIP_TRY(c, rocprim::exclusive_scan(nullptr, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
         if (tb > c->scan_tmp.n) {
@@ -639,7 +640,7 @@ static int launch_order_stage(groot_ctx *c, Slot *s)
         }
         HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
         hipLaunchKernelGGL(mask_compact_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_mask.p, c->pw_view, s->d_ctr.p, s->trav_cap,
-                           c->graph_words.p, s->d_moff.p, s->d_cmask.p, s->d_ckpt.p);
+                           c->graph_words.p, (uint32_t)c->h_graph_words.size(), s->d_moff.p, s->d_cmask.p, s->d_ckpt.p);
         HIP_TRY(c, hipGetLastError());
     }
     return GROOT_OK;
@@ -688,7 +689,9 @@ static int ensure_slot(groot_ctx *c, Slot *s, Slot::Input in, uint64_t n_exc)
     if (!s->d_ctr.p) {
         HIP_TRY(c, s->d_ctr.alloc(1));
         HIP_TRY(c, s->h_ctr.alloc(1));
-        if (int rc = alloc_trav(c, s, std::max<uint32_t>(1024, R + R / 4))) return rc;
+        // (GROOT_TEST_SMALL_BUFFERS: start with buffers that every batch outgrows, so that the tests walk the grow-and-redo paths)
+        static const bool tiny = getenv("GROOT_TEST_SMALL_BUFFERS") != nullptr;
+        if (int rc = alloc_trav(c, s, tiny ? 64u : std::max<uint32_t>(1024, R + R / 4))) return rc;
     }
     if (in == Slot::IN_DEVICE) return GROOT_OK;
     HIP_TRY(c, s->d_seq.reserve(B + 64));
@@ -862,6 +865,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
             merged.n_trav = again.n_trav; merged.alignments = again.alignments; merged.seeds = again.seeds; merged.max_seeds = again.max_seeds;
             merged.flags = keep | again.flags;
             merged.q_rows = again.q_rows;
+            merged.mask_words = again.mask_words;
             h = merged;
         } else h = again;
     }
@@ -1241,7 +1245,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->trav_cnt.alloc(R));
     HIP_TRY(c, c->trav_off.alloc(R));
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
-    if (int rc = alloc_ovf(c, std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
+    if (int rc = alloc_ovf(c, getenv("GROOT_TEST_SMALL_BUFFERS") ? 2u : std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);

@@ -221,3 +221,38 @@ def test_corrupt_view_is_refused(small_index):
     with pytest.raises(host.GrootError) as e:
         device.Aligner(Fake, max_batch_reads=1024)
     assert e.value.code == -3
+
+
+def test_grow_and_redo_paths_inside_the_pipeline(small_index, monkeypatch):
+    """every buffer starts too small (seed slots, overflow lists, ordered output, call-count rows): each batch is redone after
+    the buffers grew, with other batches in flight, and still equals the oracle -- records, path sets, counters, call counts"""
+    monkeypatch.setenv("GROOT_TEST_SMALL_BUFFERS", "1")
+    cat, o, lens = synth.reference_sequences(small_index)
+    batches = []
+    for b in range(5):
+        seq, off, _ = synth.reads_np(cat, o, lens, 900 + 50 * b, 140, first=b * 77_000, min_len=70)
+        batches.append((seq, off))
+    run, per = oracle_of(small_index, batches, threshold=0.9)
+    al = device.Aligner(small_index, threshold=0.9, max_batch_reads=2048, max_read_len=160, max_seeds_per_read=1, pipeline_depth=3)
+    got = []
+    first = 0
+    for seq, off in batches:
+        pk, ln, ep, eb = wire(seq, off)
+        al.submit_packed16(pk, ln, ep, eb, first_read_id=first)
+        first += len(off) - 1
+        if al.in_flight()[0] == 3:
+            r = al.collect()
+            got.append(r); al.release(r["ticket"])
+    while al.in_flight()[0]:
+        r = al.collect()
+        got.append(r); al.release(r["ticket"])
+    for r, exp in zip(got, per):
+        recs = device.expand_alns(small_index, r["travs"], r["masks"])
+        assert len(recs) == len(exp) == r["counts"]["alignments"]
+        for f in exp.dtype.names:
+            assert np.array_equal(recs[f], exp[f]), f
+    oc = run.counts()
+    assert all(sum(r["counts"][k] for r in got) == oc[k] for k in ("received", "mapped", "multimapped", "alignments", "seeds"))
+    att, oatt = al.attempts(), run.attempts()
+    assert np.array_equal(att[: oatt.shape[0]], oatt) and not att[oatt.shape[0]:].any()
+    al.close()
