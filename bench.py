@@ -171,7 +171,8 @@ def host_fed(index, d_seq, R, steps, depth=3):
         done += 1
     dt = time.perf_counter() - t0
     out = {"value": steps * R / dt / 1e6, "unit": "Mreads/s", "steps": steps, "batches_in_flight": depth, "ms_per_batch": dt / steps * 1e3,
-           "h2d_bytes_per_read": (len(packed) + 2 * R + 9 * len(exc_pos)) / R, "d2h_bytes_per_read": trav_bytes / (steps * R),
+           "h2d_bytes_per_read": (len(packed) + 9 * len(exc_pos)) / R,   # (all reads are 100 bp: the length array stays at home)
+           "d2h_bytes_per_read": trav_bytes / (steps * R),
            "stage_ms_per_batch": {k: v / steps for k, v in stage.items()},
            "what": "one ctx, one index replica: pinned staging -> H2D (2-bit bases + u16 lengths) -> kernels -> D2H of the traversal "
                    "records into pinned host memory; first submit -> last collect"}

@@ -72,6 +72,7 @@ struct Slot {
     State state = FREE;
     uint64_t ticket = 0;
     uint32_t n_reads = 0, first_read_id = 0, max_len = 0;
+    uint32_t uniform_len = 0;              // IN_PACKED16: every read has this length (0 = lengths differ): no length array on the wire
     uint64_t n_bases = 0, n_exc = 0;
     enum Input { IN_ASCII, IN_PACKED, IN_PACKED16, IN_DEVICE } input = IN_ASCII;
     const uint8_t *ext_seq = nullptr;      // IN_DEVICE
@@ -757,7 +758,7 @@ static int enqueue(groot_ctx *c, Slot *s)
             HIP_TRY(c, hipMemcpyAsync(s->d_packed.p, s->h_bases.p, (size_t)((s->n_bases + 3) / 4), hipMemcpyHostToDevice, h));
             if (s->input == Slot::IN_PACKED)
                 HIP_TRY(c, hipMemcpyAsync(s->d_off.p, s->h_off.p, ((size_t)s->n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h));
-            else
+            else if (!s->uniform_len)
                 HIP_TRY(c, hipMemcpyAsync(s->d_len.p, s->h_len.p, (size_t)s->n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, h));
             if (s->n_exc) {
                 HIP_TRY(c, hipMemcpyAsync(s->d_exc_pos.p, s->h_exc_pos.p, s->n_exc * sizeof(uint64_t), hipMemcpyHostToDevice, h));
@@ -777,7 +778,11 @@ static int enqueue(groot_ctx *c, Slot *s)
             hipLaunchKernelGGL(patch_reads_kernel, dim3((unsigned)((s->n_exc + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
                                s->d_exc_pos.p, s->d_exc_byte.p, s->n_exc, s->d_seq.p);
         HIP_TRY(c, hipGetLastError());
-        if (s->input == Slot::IN_PACKED16) {
+        if (s->input == Slot::IN_PACKED16 && s->uniform_len) {
+            hipLaunchKernelGGL(uniform_offsets_kernel, dim3((s->n_reads + kBlock) / kBlock), dim3(kBlock), 0, c->stream, s->d_off.p, s->n_reads,
+                               s->uniform_len);
+            HIP_TRY(c, hipGetLastError());
+        } else if (s->input == Slot::IN_PACKED16) {
             HIP_TRY(c, hipMemsetAsync(s->d_off.p, 0, sizeof(uint64_t), c->stream));
             auto in = rocprim::make_transform_iterator(s->d_len.p, LenToU64());
             size_t tmp_bytes = 0;
@@ -800,10 +805,12 @@ static int enqueue(groot_ctx *c, Slot *s)
     HIP_TRY(c, hipStreamWaitEvent(c->d2h_stream, s->ev_compute, 0));
     if (!c->prm.results_on_device) {
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h0, c->d2h_stream));
-        const uint64_t predicted = (uint64_t)((double)s->n_reads * c->trav_per_read * 1.06) + 4096;
+        // margin: a few standard deviations of a per-read count over n reads, at least 1 %
+        const double margin = 1.0 + std::max(0.01, 4.0 / std::sqrt((double)s->n_reads + 1.0));
+        const uint64_t predicted = (uint64_t)((double)s->n_reads * c->trav_per_read * margin) + 1024;
         s->copied = (uint32_t)std::min<uint64_t>(predicted, s->trav_cap);
         const double wpt = c->words_per_trav > 0 ? c->words_per_trav : (double)c->pw_view;
-        s->copied_words = std::min<uint64_t>((uint64_t)((double)s->copied * wpt * 1.04) + 4096, (uint64_t)s->trav_cap * c->pw_view);
+        s->copied_words = std::min<uint64_t>((uint64_t)((double)s->copied * wpt * margin) + 1024, (uint64_t)s->trav_cap * c->pw_view);
         HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->copied * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_cmask.p, (size_t)s->copied_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(c, hipMemcpyAsync(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->copied / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h_stream));
@@ -1326,11 +1333,12 @@ static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads
     return GROOT_OK;
 }
 
-static int check_lengths(groot_ctx *c, const uint16_t *len, uint32_t n_reads, uint64_t *total, uint32_t *max_len)
+static int check_lengths(groot_ctx *c, const uint16_t *len, uint32_t n_reads, uint64_t *total, uint32_t *max_len, uint32_t *min_len)
 {
     uint64_t sum = 0;
-    uint32_t longest = 0;
-    for (uint32_t i = 0; i < n_reads; i++) { sum += len[i]; longest = std::max<uint32_t>(longest, len[i]); }
+    uint32_t longest = 0, shortest = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n_reads; i++) { sum += len[i]; longest = std::max<uint32_t>(longest, len[i]); shortest = std::min<uint32_t>(shortest, len[i]); }
+    *min_len = shortest;
     if (sum > c->prm.max_batch_bases)
         return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)sum, (unsigned long long)c->prm.max_batch_bases);
     *total = sum; *max_len = longest;
@@ -1396,9 +1404,9 @@ int groot_hip_submit_packed16(groot_ctx *c, const uint8_t *packed, const uint16_
     if (n_reads && (!packed || !seq_len)) return fail(c, GROOT_E_INVALID, "null read buffers");
     if (n_exc && (!exc_pos || !exc_byte)) return fail(c, GROOT_E_INVALID, "null exception list");
     uint64_t total = 0;
-    uint32_t max_len = 0;
+    uint32_t max_len = 0, min_len = 0;
     if (n_reads) {
-        if (int rc = check_lengths(c, seq_len, n_reads, &total, &max_len)) return rc;
+        if (int rc = check_lengths(c, seq_len, n_reads, &total, &max_len, &min_len)) return rc;
         if (int rc = check_exceptions(c, exc_pos, n_exc, total)) return rc;
     }
     Slot *s = nullptr;
@@ -1407,9 +1415,10 @@ int groot_hip_submit_packed16(groot_ctx *c, const uint8_t *packed, const uint16_
     s->input = Slot::IN_PACKED16; s->n_reads = n_reads; s->first_read_id = first_read_id;
     s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
+    s->uniform_len = n_reads && min_len == max_len ? max_len : 0;
     if (n_reads) {
         par_copy(s->h_bases.p, packed, (size_t)((total + 3) / 4));
-        par_copy(s->h_len.p, seq_len, (size_t)n_reads * sizeof(uint16_t));
+        if (!s->uniform_len) par_copy(s->h_len.p, seq_len, (size_t)n_reads * sizeof(uint16_t));
         if (n_exc) { memcpy(s->h_exc_pos.p, exc_pos, n_exc * sizeof(uint64_t)); memcpy(s->h_exc_byte.p, exc_byte, n_exc); }
     }
     return enqueue(c, s);
@@ -1445,14 +1454,15 @@ int groot_hip_submit_acquired(groot_ctx *c, uint64_t ticket, uint32_t n_reads, u
     if (n_reads > c->prm.max_batch_reads) return fail(c, GROOT_E_NOSPACE, "batch of %u reads exceeds max_batch_reads=%u", n_reads, c->prm.max_batch_reads);
     if (n_exc > s->h_exc_pos.n) return fail(c, GROOT_E_NOSPACE, "more exceptions than the acquired buffers hold");
     uint64_t total = 0;
-    uint32_t max_len = 0;
+    uint32_t max_len = 0, min_len = 0;
     if (n_reads) {
-        if (int rc = check_lengths(c, s->h_len.p, n_reads, &total, &max_len)) return rc;
+        if (int rc = check_lengths(c, s->h_len.p, n_reads, &total, &max_len, &min_len)) return rc;
         if (int rc = check_exceptions(c, s->h_exc_pos.p, n_exc, total)) return rc;
     }
     s->input = Slot::IN_PACKED16; s->n_reads = n_reads; s->first_read_id = first_read_id;
     s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
+    s->uniform_len = n_reads && min_len == max_len ? max_len : 0;
     s->state = Slot::FREE;           // enqueue re-labels it
     return enqueue(c, s);
 }

@@ -471,6 +471,13 @@ __global__ void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t
     ctr->q_rows = need;
 }
 
+// offsets of a batch whose reads all have the same length (then no length array travels): off[i] = i * len, i in [0, n]
+__global__ __launch_bounds__(kBlock) void uniform_offsets_kernel(uint64_t *__restrict__ off, uint32_t n, uint32_t len)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i <= n) off[i] = (uint64_t)i * len;
+}
+
 // read records in processing order: the align stage then fetches slot-consecutive (coalesced) records instead of
 // chasing perm[slot] -> read_rec[read]
 __global__ __launch_bounds__(kBlock) void gather_recs_kernel(const uint32_t *__restrict__ perm, const ReadRec *__restrict__ in,
