@@ -553,7 +553,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         });
 
     // ---- writer: batches in input order ----
-    uint64_t received = 0, mapped_reads = 0, multimapped = 0, alignments = 0;
+    uint64_t received = 0, mapped_reads = 0, multimapped = 0, alignments = 0, full_sketch = 0;
     {
         std::map<uint64_t, WorkItem> waiting;
         uint64_t next_seq = 0;
@@ -568,6 +568,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
                 next_seq++;
                 const groot_counts &c = it.res.counts;
                 received += c.received; mapped_reads += c.mapped; multimapped += c.multimapped; alignments += c.alignments;
+                full_sketch += c.full_sketch_reads;
                 if (bam && it.res.n_travs && !failed) {
                     uint64_t nrec = 0;
                     auto tw = std::chrono::steady_clock::now();
@@ -666,10 +667,10 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         if (sf) {
             fprintf(sf, "{\"reads\": %llu, \"mapped\": %llu, \"alignments\": %llu, \"gpu_contexts\": %zu, \"load_s\": %.6f, \"stream_s\": %.6f, "
                         "\"post_s\": %.6f, \"total_s\": %.6f, \"bam_bytes\": %llu, \"bam_level\": %d, \"threads\": %u, \"batches\": %llu, "
-                        "\"parse_busy_s\": %.6f, \"bam_busy_s\": %.6f, \"collect_wait_s\": %.6f}\n",
+                        "\"parse_busy_s\": %.6f, \"bam_busy_s\": %.6f, \"collect_wait_s\": %.6f, \"full_sketch_reads\": %llu}\n",
                     (unsigned long long)received, (unsigned long long)mapped_reads, (unsigned long long)alignments, gpus.size(), load_s, stream_s,
                     post_s, total_s, (unsigned long long)bam_bytes, a.bam_level, cores ? cores : groot_host_usable_cpus(),
-                    (unsigned long long)n_batches.load(), parse_s, bam_s, (double)collect_wait_us.load() / 1e6);
+                    (unsigned long long)n_batches.load(), parse_s, bam_s, (double)collect_wait_us.load() / 1e6, (unsigned long long)full_sketch);
             fclose(sf);
         }
     }

@@ -21,6 +21,7 @@ enum : uint32_t {
     kFlagQOverflow = 64u,     // more distinct kmerCounts among the seeded reads than the call-count table has rows
 };
 
+constexpr uint32_t kSeedShards = 64, kSeedShardStride = 16;   // seed-stage counters: one 128-byte line per shard
 constexpr uint32_t kOvfShards = 256;  // overflow traversal lists, picked by workgroup id: spreads the atomics
 
 struct DeviceCounters {
@@ -30,7 +31,7 @@ struct DeviceCounters {
     unsigned int flags;
     unsigned int q_rows;        // rows of the call-count table in use after this batch (may exceed its capacity: then kFlagQOverflow)
     unsigned int mask_words;    // 64-bit words of the compact path sets of this batch (mask_compact_kernel)
-    unsigned int pad2;
+    unsigned int todo_reads;    // reads sketch_sig_kernel handed to the full-width kernel (0 when that kernel ran alone)
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };
@@ -78,6 +79,16 @@ constexpr uint32_t kPrefixWords = 256;   // words per window in DeviceIndex::win
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
 
+// signature-table entry (sketch_sig_kernel): one per window, keyed by the top 27 bits of every sketch slot
+struct alignas(16) SigEntry {
+    uint32_t tag;          // high half of the signature hash
+    uint32_t id;           // window; kEmpty = free slot
+    uint32_t cls;          // windows with identical 64-bit sketches share a class
+    uint32_t text_len;     // bits 0..7: bases of the window's text that were verified at open (0: the window cannot confirm a read);
+                           // bits 8..15 / 16..23: first position of the smallest canonical k-mer hash in the forward / reverse-complement row
+};
+constexpr uint32_t kTextMax = 128;       // bases kept per window text (window + merged neighbours), per orientation
+
 // graph + window arrays resident in HBM (replicated per GPU)
 struct DeviceIndex {
     uint32_t k, s, w, num_window_kmers, n_windows, n_nodes, pw; // pw = path words on the device (>= view.path_words)
@@ -111,6 +122,12 @@ struct DeviceIndex {
     // IncrementSubPath call counts are kept per (kmerCount, window) only for the kmerCounts that occur: q_row[q] = row of
     // the call-count table holding kmerCount q, kEmpty until a seeded read with that q shows up (assign_q_rows_kernel)
     const uint32_t *q_row;          // [max_q + 1]
+    // sketch_sig_kernel: signature table (open addressing, windows inserted in ascending id like `exact`) and per window
+    // the bases it was sketched from -- WindowSize + MergeSpan of them along its first Ref path, 2 bits per base
+    // ((byte >> 1) & 3, base j at bits 2*(j%4) of byte j/4): forward row at byte w*2*kTextMax/4, reverse complement kTextMax/4 later; null = not available
+    const SigEntry *sig;
+    uint32_t sig_mask;
+    const uint8_t *win_text;
 };
 
 struct SeedArgs {
@@ -127,6 +144,9 @@ struct SeedArgs {
     uint32_t sort_span_bits;     // top bits of sort_key that hold min(contained nodes of the window, 2^bits-1); 0 = none
     ReadRec *read_rec;           // [n_reads]
     uint32_t *q_seen;            // [max_q + 1] set for every kmerCount of a seeded read that has no row yet; or null
+    unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
+    uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
+    uint32_t *todo_count;        // [1]
     DeviceCounters *ctr;
 };
 

@@ -131,6 +131,9 @@ struct groot_ctx {
     DevBuf<unsigned char> node_rec;
     DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
+    DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature table + window texts (absent: that kernel is not used)
+    DevBuf<uint8_t> win_text;
+    uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
 
     // pipeline
@@ -147,7 +150,8 @@ struct groot_ctx {
 
     // shared work buffers (compute stream only)
     uint32_t seed_slots = 0;
-    DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm;
+    DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, todo_list, todo_count;
+    DevBuf<unsigned long long> seed_shards;
     DevBuf<char> sort_tmp;
     DevBuf<ReadRec> read_rec, read_rec_sorted;
     DevBuf<uint64_t> sketches;
@@ -451,6 +455,30 @@ static void launch_seed(uint32_t s, uint32_t max_k, const SeedArgs &a, bool dump
     launch_seed_sm<0, 0, -1>(a, dump, grid, lds, st);   // run-time sketch size / hash functions per band
 }
 
+// sketch_sig_kernel + the list pass of sketch_seed_kernel behind it: instances for the (sketch size, k) pairs that have a
+// strength-reduced sketch_seed_kernel above
+template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((sketch_sig_kernel<S, M5>), grid, dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads, st, a);
+}
+static bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
+{
+    const uint32_t m5 = (uint32_t)(((uint64_t)k * GROOT_MULTI_SEED) & 31u);
+    if (max_k != 4) return false;
+    return (s == 21 && (m5 == 6 || m5 == 10 || m5 == 14 || m5 == 2)) || (s == 20 && m5 == 6) || (s == 30 && m5 == 14);
+}
+static void launch_sig(uint32_t s, const SeedArgs &a, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
+{
+    const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
+    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, grid, lds, list_grid, st);
+    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, grid, lds, list_grid, st);
+    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, grid, lds, list_grid, st);
+}
+
 static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
 {
     const size_t lds = a.lds_stride_dw ? (size_t)kBlock * a.lds_stride_dw * 4 + 16 : 0;
@@ -536,6 +564,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     a.sort_key = c->sort_key.p;
     a.read_rec = c->read_rec.p;
     a.q_seen = c->q_seen.p;
+    a.shards = c->seed_shards.p;
     a.ctr = s->d_ctr.p;
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
     // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
@@ -545,12 +574,21 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
-    const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
-    launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
+    if (c->dix.sig && !c->prm.keep_sketches) {
+        // signature kernel first; what it cannot decide goes through the full-width kernel, read by read
+        a.todo_list = c->todo_list.p;
+        a.todo_count = c->todo_count.p;
+        HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
+        const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 64;   // (+: the kernel reads whole register rows past a read)
+        launch_sig(c->s, a, grid, lds, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
+    } else {
+        const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
+        launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
+    }
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(1), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
-                       c->max_q, s->d_ctr.p);
+                       c->max_q, s->d_ctr.p, c->seed_shards.p);
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
@@ -873,6 +911,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
             merged.flags = keep | again.flags;
             merged.q_rows = again.q_rows;
             merged.mask_words = again.mask_words;
+            merged.todo_reads = again.todo_reads;
             h = merged;
         } else h = again;
     }
@@ -881,6 +920,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
     o.received = s->n_reads;              // boss.go:194 receivedReads++ for every read
     o.mapped = h.mapped; o.multimapped = h.multimapped; o.alignments = h.alignments; o.seeds = h.seeds;
     o.travs = s->n_trav; o.revcomp_panics = h.revcomp_panics; o.short_reads = h.short_reads;
+    o.full_sketch_reads = c->dix.sig && !c->prm.keep_sketches ? h.todo_reads : s->n_reads;
     if (s->status == GROOT_OK) {
         char buf[256];
         if (h.flags & kFlagLongRead) { s->status = GROOT_E_NOSPACE; snprintf(buf, sizeof buf, "a read is longer than max_read_len=%u", c->prm.max_read_len); s->status_msg = buf; }
@@ -895,6 +935,9 @@ static int finish_counters(groot_ctx *c, Slot *s)
             s->status_msg = buf;
         }
     }
+    if (getenv("GROOT_SIG_STATS"))
+        fprintf(stderr, "[groot sig] %u of %u reads went through the full-width sketch kernel (%u windows without a text)\n", h.todo_reads, s->n_reads,
+                c->sig_disabled);
 #ifdef GROOT_WORK_COUNTERS
     for (int e = 0; e < 32; e++)
         if (h.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, h.dbg[e], h.dbg[32 + e]);
@@ -1032,6 +1075,155 @@ void groot_hip_close(groot_ctx *ctx)
     delete ctx;
 }
 
+// ---------------------------------------------------------------------------------------------
+// sketch_sig_kernel's side of the index: window texts, proven against Key.Sketch, and the signature table
+// ---------------------------------------------------------------------------------------------
+// KHF sketches of n sequences of `len` bases each (concatenated), through the full-width kernel
+static int sketch_uniform(groot_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t len, uint64_t *out)
+{
+    DevBuf<uint64_t> sk, off;
+    DevBuf<uint8_t> seq;
+    DevBuf<DeviceCounters> ctr;
+    DevBuf<uint32_t> cnt;
+    const uint64_t total = (uint64_t)n * len;
+    HIP_TRY(c, sk.alloc((size_t)n * c->s));
+    HIP_TRY(c, off.alloc((size_t)n + 1));
+    HIP_TRY(c, seq.alloc(total + 64));
+    HIP_TRY(c, ctr.alloc(1));
+    HIP_TRY(c, cnt.alloc(n));
+    HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    const dim3 grid((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->stream, off.p, n, len);
+    SeedArgs a{};
+    a.ix = c->dix;
+    a.ix.max_q = 0;   // no lookup: every read gets min_eq = S+1
+    a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, c->prm.max_read_len);
+    a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * len + 32, kMaxLdsReadBytes);
+    a.seed_slots = 0; a.seed_count = cnt.p; a.seed_win = nullptr;
+    a.sketch_out = sk.p; a.ctr = ctr.p; a.shards = c->seed_shards.p;
+    launch_seed(c->s, c->max_k, a, true, grid, kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, sk.p, (size_t)n * c->s * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GROOT_OK;
+}
+
+static int build_signature_index(groot_ctx *c, const groot_index_view *v, const std::vector<uint32_t> &sketch_class)
+{
+    const uint32_t n = v->n_windows, s = v->sketch_size, w = v->window_size, k = v->kmer_size;
+    if (getenv("GROOT_NO_SIG") || !sig_supported(s, v->max_k, k) || w > kTextMax || w < k || !n) return GROOT_OK;
+    // 1. the bases every window was sketched from: WindowSize + MergeSpan of them along its first Ref path, starting at
+    //    (Key.Node, Key.OffSet) -- WindowGraph walks a path through the graph's nodes in order (graph.go:243-262) and merges
+    //    consecutive windows of equal sketch into the first one (:293-333).  Texts stop at a base other than ACGT.
+    std::vector<uint8_t> text((size_t)n * 2 * kTextMax + 64, 0);
+    std::vector<uint32_t> tlen(n, 0);
+    const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                for (uint32_t i = t; i < n; i += nt) {
+                    if (v->win_ref_off[i] == v->win_ref_off[i + 1]) continue;
+                    const uint32_t g = v->win_graph[i], p = v->win_ref[v->win_ref_off[i]];
+                    const uint32_t n1 = v->graph_node_off[g + 1];
+                    const uint32_t want = (uint32_t)std::min<uint64_t>(kTextMax, (uint64_t)w + v->win_merge_span[i]);
+                    uint8_t *fw = &text[(size_t)i * 2 * kTextMax], *rc = fw + kTextMax;
+                    uint32_t node = v->win_node[i], off = v->win_offset[i], got = 0;
+                    bool stop = false;
+                    for (; !stop && got < want && node < n1; node++, off = 0) {
+                        if (!((v->node_mask[(size_t)node * v->path_words + (p >> 6)] >> (p & 63)) & 1ULL)) {
+                            if (node == v->win_node[i]) stop = true;      // the window's own node is not on its path?
+                            continue;
+                        }
+                        const uint32_t s0 = v->node_seq_off[node], nlen = v->node_seq_off[node + 1] - s0;
+                        for (; off < nlen && got < want; off++) {
+                            const uint8_t b = v->bases[s0 + off];
+                            if (b != 'A' && b != 'C' && b != 'G' && b != 'T') { stop = true; break; }
+                            fw[got++] = b;
+                        }
+                    }
+                    if (got < w) { memset(fw, 0, kTextMax); continue; }
+                    tlen[i] = got;
+                    for (uint32_t j = 0; j < got; j++) {
+                        const uint8_t b = fw[got - 1 - j];
+                        rc[j] = b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A';
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    // 2. proof: every WindowSize-mer of both rows must reproduce Key.Sketch through the full-width kernel; a window
+    //    whose text does not is left without one (its reads take the full-width kernel)
+    {
+        const uint32_t chunk = 1u << 20;
+        std::vector<uint8_t> seqs;
+        std::vector<uint32_t> owner;
+        std::vector<uint64_t> sk;
+        auto flush = [&]() -> int {
+            if (owner.empty()) return GROOT_OK;
+            sk.resize(owner.size() * (size_t)s);
+            if (int rc = sketch_uniform(c, seqs.data(), (uint32_t)owner.size(), w, sk.data())) return rc;
+            for (size_t j = 0; j < owner.size(); j++)
+                if (memcmp(&sk[j * s], v->win_sketch + (size_t)owner[j] * s, (size_t)s * 8)) tlen[owner[j]] = 0;
+            seqs.clear(); owner.clear();
+            return GROOT_OK;
+        };
+        for (uint32_t i = 0; i < n; i++) {
+            if (!tlen[i]) continue;
+            for (uint32_t row = 0; row < 2; row++)
+                for (uint32_t o = 0; o + w <= tlen[i]; o++) {
+                    const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax + o];
+                    seqs.insert(seqs.end(), src, src + w);
+                    owner.push_back(i);
+                }
+            if (owner.size() >= chunk)
+                if (int rc = flush()) return rc;
+        }
+        if (int rc = flush()) return rc;
+        for (uint32_t i = 0; i < n; i++)
+            if (!tlen[i]) { c->sig_disabled++; memset(&text[(size_t)i * 2 * kTextMax], 0, 2 * kTextMax); }
+    }
+    // 3. where the smallest k-mer of every text row is (first occurrence), and the rows at 2 bits per base
+    std::vector<uint8_t> argmin((size_t)n * 2, 0);
+    {
+        DevBuf<uint8_t> d_text, d_pos;
+        DevBuf<uint32_t> d_len;
+        HIP_TRY(c, upload(d_text, text.data(), text.size()));
+        HIP_TRY(c, upload(d_len, tlen.data(), tlen.size()));
+        HIP_TRY(c, d_pos.alloc((size_t)n * 2));
+        hipLaunchKernelGGL(text_argmin_kernel, dim3((2 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, d_text.p, d_len.p, 2 * n, k, d_pos.p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(argmin.data(), d_pos.p, argmin.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    std::vector<uint8_t> packed((size_t)n * 2 * (kTextMax / 4) + 64, 0);
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t row = 0; row < 2; row++) {
+            const uint8_t *src = &text[((size_t)i * 2 + row) * kTextMax];
+            uint8_t *dst = &packed[((size_t)i * 2 + row) * (kTextMax / 4)];
+            for (uint32_t j = 0; j < tlen[i]; j++) dst[j >> 2] |= (uint8_t)(((src[j] >> 1) & 3u) << (2 * (j & 3)));
+        }
+    // 4. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
+    uint32_t cap = 16;
+    while (cap < 2 * (uint64_t)n) cap <<= 1;
+    std::vector<SigEntry> tab(cap, SigEntry{0, kEmpty, 0, 0});
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t x = GROOT_SIG_HASH_INIT;
+        for (uint32_t j = 0; j < s; j++) x = sig_hash_step(x, (uint32_t)(v->win_sketch[(size_t)i * s + j] >> 37));
+        x = sig_hash_fin(x);
+        uint32_t slot = (uint32_t)x & (cap - 1);
+        while (tab[slot].id != kEmpty) slot = (slot + 1) & (cap - 1);
+        tab[slot] = SigEntry{(uint32_t)(x >> 32), i, sketch_class[i], tlen[i] | ((uint32_t)argmin[2 * i] << 8) | ((uint32_t)argmin[2 * i + 1] << 16)};
+    }
+    HIP_TRY(c, upload(c->sig, tab.data(), tab.size()));
+    HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));
+    c->dix.sig = c->sig.p;
+    c->dix.sig_mask = cap - 1;
+    c->dix.win_text = c->win_text.p;
+    return GROOT_OK;
+}
+
 static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, const groot_params *p)
 {
     int ndev = 0;
@@ -1123,6 +1315,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
 
     // ---- lookup structures (the reference bootstraps its LSH forests at load too, lshe.go:95-147) ----
     const uint32_t n = v->n_windows, s = v->sketch_size;
+    std::vector<uint32_t> sketch_class(n);   // smallest window id with the same 64-bit sketch
     {   // exact-match table
         uint32_t cap = 16;
         while (cap < 2 * (uint64_t)n) cap <<= 1;
@@ -1131,7 +1324,11 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
             uint64_t h = GROOT_SKETCH_HASH_INIT;
             for (uint32_t i = 0; i < s; i++) h = sketch_hash_step(h, v->win_sketch[(size_t)w * s + i]);
             uint32_t slot = (uint32_t)h & (cap - 1);
-            while (tab[slot].id != kEmpty) slot = (slot + 1) & (cap - 1);
+            sketch_class[w] = w;
+            for (; tab[slot].id != kEmpty; slot = (slot + 1) & (cap - 1))
+                if (sketch_class[w] == w && tab[slot].tag == (uint32_t)(h >> 32) &&
+                    !memcmp(v->win_sketch + (size_t)tab[slot].id * s, v->win_sketch + (size_t)w * s, (size_t)s * 8))
+                    sketch_class[w] = sketch_class[tab[slot].id];
             tab[slot] = ExactEntry{(uint32_t)(h >> 32), w};
         }
         HIP_TRY(c, upload(c->exact, tab.data(), tab.size()));
@@ -1262,7 +1459,12 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
     HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
+    HIP_TRY(c, c->todo_list.alloc(R));
+    HIP_TRY(c, c->todo_count.alloc(1));
+    HIP_TRY(c, c->seed_shards.alloc((size_t)kSeedShards * kSeedShardStride));
+    HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));
     HIP_TRY(c, hipDeviceSynchronize());
+    if (int rc = build_signature_index(c, v, sketch_class)) return rc;
     return GROOT_OK;
 }
 
@@ -1890,7 +2092,7 @@ int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
-    a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.q_seen = nullptr; a.ctr = ctr.p;
+    a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.q_seen = nullptr; a.ctr = ctr.p; a.shards = c->seed_shards.p;
     launch_seed(c->s, c->max_k, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
     HIP_TRY(c, hipGetLastError());
     DeviceCounters h{};

@@ -142,6 +142,68 @@ constexpr uint32_t kLdsTabCout = 4096 + 64;      // u64[8]   ror(seedTab[c], 1)
 constexpr uint32_t kLdsTabCin = 4096 + 128;      // u64[8]   rol(seedTab[c], k-1)
 constexpr uint32_t kLdsReads = 4096 + 192;       // staged read bytes (16-byte aligned)
 
+// What every seed kernel leaves behind for one read once its seed windows are known (n_hits of them, the first four in
+// s0..s3, the smallest id in min_win): seed_count, the read record with the align stage's verdicts, its scheduling key,
+// the batch counters.
+__device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
+                                              const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
+                                              const uint32_t s2, const uint32_t s3, const bool high)
+{
+    const DeviceIndex &ix = a.ix;
+    a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
+    // scheduling key for the align stage: reads are processed in (first seed window, likely orientation) order so
+    // that neighbouring lanes walk the same graph nodes in step; reads without seeds sort to the end.  Processing
+    // order only -- every output is addressed by read.
+    // What the align stage will find for the read's first seed window, per orientation: levels 1-2 cannot start
+    // anywhere (prefix tables), the level-3 / level-4 single start position fails its first comparison (alignment.go:72-103).
+    // The align stage skips exactly these steps; the sort key groups reads whose orientations have work left, so that
+    // neighbouring lanes walk the same graph nodes in step.  Processing order only -- every output is addressed by read.
+    uint32_t verdicts = 0;
+    if (a.sort_key) {
+        uint32_t key = kEmpty;
+        if (n_hits) {
+            const WinRec wr = ix.win_rec[min_win];
+            const uint32_t *tab = ix.win_prefix + (size_t)min_win * kPrefixWords;
+            const uint8_t *p = a.seq + o0;
+            const bool in_node = wr.offset < wr.seed_len;         // else levels 3-4 are skipped (alignment.go:199-201)
+            const uint64_t g8 = in_node ? ld8(ix.bases + wr.seed_s0 + wr.offset) : 0;
+            const uint32_t m34 = min(min(wr.seed_len - wr.offset, len - 1), 8u);
+            uint32_t dead = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 2; t++) {
+                const uint64_t c0 = read_chunk(p, len, t, 0, 0), c1 = read_chunk(p, len, t, 0, 8);
+                uint32_t vt = prefix_absent(tab, c0, c1, len) ? kRecNo12F : 0u;
+                if (!in_node || !prefix_ok(g8, (c0 >> 8) | (c1 << 56), m34)) vt |= kRecNo3F;    // read[1:] at (seed, OffSet)
+                if (!in_node || !prefix_ok(g8, c0, m34)) vt |= kRecNo4F;                         // read[:len-1] there
+                if (vt == (kRecNo12F | kRecNo3F | kRecNo4F)) dead |= 2u >> t;
+                verdicts |= vt << (3 * t);
+            }
+            key = (min_win << 2) | dead;
+            if (a.sort_span_bits) {
+                // windows spanning a similar number of nodes need similar numbers of DFS steps: keep them together, and
+                const uint32_t nn = min(wr.cn_end - wr.cn_off, (1u << a.sort_span_bits) - 1u);
+                // longest walks first: the slow chunks are handed out early and the short ones fill the tail of the launch
+                key |= (((1u << a.sort_span_bits) - 1u) - nn) << (32u - a.sort_span_bits);
+            }
+        }
+        a.sort_key[r] = key;
+    }
+    if (a.read_rec) {
+        uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (high ? 0x80000000u : 0u));
+        rq[1] = make_uint4(s0, s1, s2, s3);
+    }
+    if (n_hits) {
+        if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;   // this kmerCount needs a row of the call-count table
+        // (sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per 10 M reads; assign_q_rows_kernel folds them)
+        unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
+        atomicAdd(sh, (unsigned long long)n_hits);
+        atomicMax(sh + 1, (unsigned long long)n_hits);
+        if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // K1+K2
 // ---------------------------------------------------------------------------------------------
@@ -158,7 +220,7 @@ constexpr uint32_t kLdsReads = 4096 + 192;       // staged read bytes (16-byte a
 // cmd/index.go:45-49): the minima then live in an array indexed at run time (private memory), which is correct and slow;
 // the sizes people use have compiled instances.
 constexpr int kGenericMaxS = 256;      // largest sketch the run-time-sized instance handles
-template <int S, int MAXK, bool DUMP, int M5>
+template <int S, int MAXK, bool DUMP, int M5, bool LIST = false>
 __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_kernel(SeedArgs a)
 {
     constexpr int SM = S ? S : kGenericMaxS;
@@ -185,22 +247,26 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         }
     }
     // ---- stage this block's reads: one contiguous span, 16 B per lane per load (coalesced) ----
-    const uint32_t r0 = blockIdx.x * kBlock;
-    const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
-    const uint64_t span0 = a.seq_off[r0], span1 = a.seq_off[r_end];
-    const uint64_t base16 = span0 & ~15ULL;
-    const uint64_t span_bytes = span1 - base16;
-    const bool in_lds = span_bytes <= a.lds_read_bytes;
-    if (in_lds) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_reads);
-        const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
-        for (uint32_t i = tid; i < n16; i += kBlock) dst[i] = src[i];
+    // (LIST: the reads named by a.todo_list, scattered over the batch: straight from HBM, no staging)
+    uint64_t base16 = 0;
+    bool in_lds = false;
+    if constexpr (!LIST) {
+        const uint32_t r0 = blockIdx.x * kBlock;
+        const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
+        const uint64_t span0 = a.seq_off[r0], span1 = a.seq_off[r_end];
+        base16 = span0 & ~15ULL;
+        const uint64_t span_bytes = span1 - base16;
+        in_lds = span_bytes <= a.lds_read_bytes;
+        if (in_lds) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds_reads);
+            const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
+            for (uint32_t i = tid; i < n16; i += kBlock) dst[i] = src[i];
+        }
     }
     __syncthreads();
 
-    const uint32_t r = r0 + tid;
-    if (r >= a.n_reads) return;
+    auto one_read = [&](const uint32_t r) {
     const uint64_t o0 = a.seq_off[r];
     const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
     uint32_t n_hits = 0;
@@ -372,55 +438,298 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
             }
         }
     }
-    a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
-    // scheduling key for the align stage: reads are processed in (first seed window, likely orientation) order so
-    // that neighbouring lanes walk the same graph nodes in step; reads without seeds sort to the end.  Processing
-    // order only -- every output is addressed by read.
-    // What the align stage will find for the read's first seed window, per orientation: levels 1-2 cannot start
-    // anywhere (prefix tables), the level-3 / level-4 single start position fails its first comparison (alignment.go:72-103).
-    // The align stage skips exactly these steps; the sort key groups reads whose orientations have work left, so that
-    // neighbouring lanes walk the same graph nodes in step.  Processing order only -- every output is addressed by read.
-    uint32_t verdicts = 0;
-    if (a.sort_key) {
-        uint32_t key = kEmpty;
-        if (n_hits) {
-            const WinRec wr = ix.win_rec[min_win];
-            const uint32_t *tab = ix.win_prefix + (size_t)min_win * kPrefixWords;
-            const uint8_t *p = a.seq + o0;
-            const bool in_node = wr.offset < wr.seed_len;         // else levels 3-4 are skipped (alignment.go:199-201)
-            const uint64_t g8 = in_node ? ld8(ix.bases + wr.seed_s0 + wr.offset) : 0;
-            const uint32_t m34 = min(min(wr.seed_len - wr.offset, len - 1), 8u);
-            uint32_t dead = 0;
+    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0);
+    };   // one_read
+    if constexpr (LIST) {
+        const uint32_t n_todo = *a.todo_count;
+        if (!blockIdx.x && !tid) a.ctr->todo_reads = n_todo;
+        for (uint32_t i = blockIdx.x * kBlock + tid; i < n_todo; i += gridDim.x * kBlock) one_read(a.todo_list[i]);
+    } else {
+        const uint32_t r = blockIdx.x * kBlock + tid;
+        if (r < a.n_reads) one_read(r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1+K2, fast path: sketch_sig_kernel
+// ---------------------------------------------------------------------------------------------
+// For reads whose Containment > t needs every sketch slot equal (the exact-table branch of sketch_seed_kernel) the seed
+// set is decided without ever forming the 64-bit minima:
+//  * MultiHash mixes with t ^= t >> 27, which leaves the top 27 bits of t alone, and truncation is monotone, so
+//    top27(min_j mix(t_j)) = min_j top27(t_j) = (min_j hi32(h_j * c_i)) >> 5: a running 32-bit minimum of the raw product's
+//    high word gives the top 27 bits of every slot EXACTLY -- two instructions per (k-mer, slot) (64-bit add, v_min_u32)
+//    instead of seven (add, shift, 2 xor, 64-bit compare, 2 selects);
+//  * a window can only equal the read's sketch if its signature (those 27 bits of all S slots) does: the signature table
+//    holds every window; no entry -> no seed, rigorously;
+//  * an entry is confirmed by TEXT: the window's sketch is the sketch of every WindowSize-mer of the bases it was merged
+//    from (graph.go:293-333; re-sketched and compared with Key.Sketch when the ctx is opened), so a read that equals one
+//    of them, or its reverse complement (canonical k-mer hashes), has exactly that sketch.  Its seeds are then all windows
+//    of the same sketch class, in table order = ascending window id, as the exact table would have returned them;
+//  * everything else -- a signature found but no text equal (reads with errors that keep all minimisers, windows merged
+//    from another path), bytes other than ACGT (their 2-bit codes say nothing), other lengths / thresholds (LSH-Forest
+//    branch), spans too long for the LDS -- goes onto a list and through sketch_seed_kernel<..., LIST> unchanged.
+// Reads are staged as 2-bit codes (6.4 KB per 256 x 100 bp instead of 25.6 KB), the rolling hash takes both strands'
+// table entries of the entering and the leaving base with one 16-byte LDS read each.
+#define GROOT_SIG_HASH_INIT 0x2545F4914F6CDD1DULL
+__host__ __device__ __forceinline__ uint64_t sig_hash_step(uint64_t x, uint32_t top27) { return ((x << 13) | (x >> 51)) ^ top27; }
+__host__ __device__ __forceinline__ uint64_t sig_hash_fin(uint64_t x)
+{
+    x *= 0xff51afd7ed558ccdULL;
+    return x ^ (x >> 32);
+}
+
+constexpr uint32_t kSigTab = 0;        // 512 B: {leaving, entering} base -> 16-byte entries, at strides 16 and 64 (see below)
+constexpr uint32_t kSigBad = 512;      // 4096 bits: 16-byte chunks of the span holding a byte other than ACGT
+constexpr uint32_t kSigCodes = 1024;   // one dword per 16 bases
+#ifndef GROOT_SIG_WAVES
+#define GROOT_SIG_WAVES 6
+#endif
+
+// four ASCII bases -> four 2-bit codes in bits 0..7; bad collects x ^ "ACTG"[code] (non-zero: some byte is not ACGT)
+__device__ __forceinline__ uint32_t codes_of4(uint32_t x, uint32_t &bad)
+{
+    const uint32_t y = (x >> 1) & 0x03030303u;
+    bad |= x ^ __builtin_amdgcn_perm(0x47544341u, 0x47544341u, y);
+    return (y * 0x01041040u) >> 24;
+}
+__device__ __forceinline__ uint64_t seed_of_code(unsigned c)
+{
+    return c == 0 ? GROOT_SEED_A : c == 1 ? GROOT_SEED_C : c == 2 ? GROOT_SEED_T : GROOT_SEED_G;
+}
+// append read r to the list of sketch_seed_kernel<..., LIST>: one atomic per wavefront and call site
+__device__ __forceinline__ void todo_push(const SeedArgs &a, uint32_t r)
+{
+    const uint64_t active = __ballot(1);
+    const unsigned lane = __lane_id();
+    const int leader = __ffsll((unsigned long long)active) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(a.todo_count, (uint32_t)__popcll(active));
+    base = __shfl(base, leader);
+    a.todo_list[base + __popcll(active & ((1ULL << lane) - 1ULL))] = r;
+}
+constexpr int kTextWords = kTextMax / 16;        // dwords of one packed window text row (2 bits per base)
+
+// first position of the smallest canonical ntHash among the k-mers of every window text row (ASCII, kTextMax bytes per
+// row, two rows per window): sketch_sig_kernel finds where a read lies inside a text from where its own smallest k-mer is
+__global__ __launch_bounds__(kBlock) void text_argmin_kernel(const uint8_t *__restrict__ text, const uint32_t *__restrict__ text_len, uint32_t n_rows,
+                                                              uint32_t k, uint8_t *__restrict__ pos)
+{
+    const uint32_t row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n_rows) return;
+    const uint32_t len = text_len[row >> 1];
+    const uint8_t *t = text + (size_t)row * kTextMax;
+    uint32_t best_pos = 0;
+    if (len >= k) {
+        uint64_t fh = 0, rh = 0;
+        for (uint32_t j = 0; j < k; j++) {
+            fh = rol1(fh) ^ seed_tab(t[j]);
+            rh ^= rol64(seed_tab(t[j] & 7), j);
+        }
+        uint64_t best = fh < rh ? fh : rh;
+        for (uint32_t j = 1; j + k <= len; j++) {
+            fh = rol1(fh) ^ rol64(seed_tab(t[j - 1]), k) ^ seed_tab(t[j + k - 1]);
+            rh = ror1(rh) ^ ror1(seed_tab(t[j - 1] & 7)) ^ rol64(seed_tab(t[j + k - 1] & 7), k - 1);
+            const uint64_t h = fh < rh ? fh : rh;
+            if (h < best) { best = h; best_pos = j; }
+        }
+    }
+    pos[row] = (uint8_t)best_pos;
+}
+
+template <int S, int M5>
+__global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(SeedArgs a)
+{
+    static_assert(S >= 1 && S <= 32 && M5 >= 0 && M5 < 32, "slots i < 32 with a compile-time (k * multiSeed) & 31 only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *badbits = reinterpret_cast<uint32_t *>(smem + kSigBad);
+    uint32_t *codes = reinterpret_cast<uint32_t *>(smem + kSigCodes);
+    const DeviceIndex &ix = a.ix;
+    const unsigned tid = threadIdx.x;
+    const uint32_t k = ix.k;
+    // table entries: leaving base c -> {rol(seed[c], k), ror(seed[comp c], 1)}, entering base c -> {seed[c], rol(seed[comp c], k-1)}
+    // (ntHash's forward / reverse-strand updates).  Two copies: entries 16 bytes apart for a code sitting at bits 4..5 of a
+    // register, 64 bytes apart for one at bits 6..7 -- the address is then ONE v_and of the shifted code word.
+    if (tid < 4) {
+        const uint64_t f = seed_of_code(tid), fc = seed_of_code(tid ^ 2u);
+        const uint64_t of = rol64(f, k), orv = ror1(fc), iv = f, ir = rol64(fc, k - 1);
+        const uint4 eo = make_uint4((uint32_t)of, (uint32_t)(of >> 32), (uint32_t)orv, (uint32_t)(orv >> 32));
+        const uint4 ei = make_uint4((uint32_t)iv, (uint32_t)(iv >> 32), (uint32_t)ir, (uint32_t)(ir >> 32));
+        *reinterpret_cast<uint4 *>(smem + kSigTab + 16 * tid) = eo;
+        *reinterpret_cast<uint4 *>(smem + kSigTab + 64 + 16 * tid) = ei;
+        *reinterpret_cast<uint4 *>(smem + kSigTab + 256 + 64 * tid) = eo;
+        *reinterpret_cast<uint4 *>(smem + kSigTab + 256 + 16 + 64 * tid) = ei;
+    }
+    if (tid < 128) badbits[tid] = 0;
+    // ---- stage this block's reads as 2-bit codes: one contiguous span, 16 bases per lane per load ----
+    const uint32_t r0 = blockIdx.x * kBlock;
+    const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
+    const uint64_t span0 = a.seq_off[r0], span1 = a.seq_off[r_end];
+    const uint64_t base16 = span0 & ~15ULL;
+    const uint64_t span_bytes = span1 - base16;
+    const bool in_lds = span_bytes <= a.lds_read_bytes;
+    __syncthreads();
+    if (in_lds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
+        const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
+        for (uint32_t i = tid; i < n16; i += kBlock) {
+            const uint4 v = src[i];
+            uint32_t bad = 0;
+            const uint32_t c = codes_of4(v.x, bad) | (codes_of4(v.y, bad) << 8) | (codes_of4(v.z, bad) << 16) | (codes_of4(v.w, bad) << 24);
+            codes[i] = c;
+            if (bad) atomicOr(&badbits[i >> 5], 1u << (i & 31));
+        }
+    }
+    __syncthreads();
+    const uint32_t r = r0 + tid;
+    if (r >= a.n_reads) return;
+    const uint64_t o0 = a.seq_off[r];
+    const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
+    const uint32_t q = len - k + 1;                        // kmerCount, boss.go:169
+    bool fast = in_lds && len >= k && len <= a.max_read_len && len <= kTextMax && q <= ix.max_q;   // (no window text is longer)
+    if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch, or nothing can be found
+    if (fast) {
+        const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
+        for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
+            uint32_t bits = badbits[w];
+            if (w == c0 >> 5) bits &= ~0u << (c0 & 31);
+            if (w == c1 >> 5) bits &= ~0u >> (31 - (c1 & 31));
+            if (bits) fast = false;
+        }
+    }
+    if (!fast) { todo_push(a, r); return; }
+
+    // ---- top 32 bits of the running minima (khf.go:35-55) ----
+    uint32_t m[S];
 #pragma unroll
-            for (uint32_t t = 0; t < 2; t++) {
-                const uint64_t c0 = read_chunk(p, len, t, 0, 0), c1 = read_chunk(p, len, t, 0, 8);
-                uint32_t vt = prefix_absent(tab, c0, c1, len) ? kRecNo12F : 0u;
-                if (!in_node || !prefix_ok(g8, (c0 >> 8) | (c1 << 56), m34)) vt |= kRecNo3F;    // read[1:] at (seed, OffSet)
-                if (!in_node || !prefix_ok(g8, c0, m34)) vt |= kRecNo4F;                         // read[:len-1] there
-                if (vt == (kRecNo12F | kRecNo3F | kRecNo4F)) dead |= 2u >> t;
-                verdicts |= vt << (3 * t);
-            }
-            key = (min_win << 2) | dead;
-            if (a.sort_span_bits) {
-                // windows spanning a similar number of nodes need similar numbers of DFS steps: keep them together, and
-                const uint32_t nn = min(wr.cn_end - wr.cn_off, (1u << a.sort_span_bits) - 1u);
-                // longest walks first: the slow chunks are handed out early and the short ones fill the tail of the launch
-                key |= (((1u << a.sort_span_bits) - 1u) - nn) << (32u - a.sort_span_bits);
+    for (int i = 0; i < S; i++) m[i] = ~0u;
+    const uint64_t C0 = ((uint64_t)k * GROOT_MULTI_SEED) & ~31ULL;
+    uint64_t fh = 0, rh = 0;
+    uint32_t key0 = ~0u, kj = 0;     // smallest (top 25 bits of h | k-mer index): where the read's smallest k-mer is (ties: see the text compare)
+    auto ent = [&](uint32_t byte_off) { return *reinterpret_cast<const uint4 *>(smem + kSigTab + byte_off); };
+    auto roll = [&](const uint4 eo, const uint4 ei) {
+        const uint32_t fl = (uint32_t)fh, fu = (uint32_t)(fh >> 32), rl = (uint32_t)rh, ru = (uint32_t)(rh >> 32);
+        const uint32_t nfl = __builtin_amdgcn_alignbit(fl, fu, 31) ^ eo.x ^ ei.x, nfu = __builtin_amdgcn_alignbit(fu, fl, 31) ^ eo.y ^ ei.y;   // rol 1
+        const uint32_t nrl = __builtin_amdgcn_alignbit(ru, rl, 1) ^ eo.z ^ ei.z, nru = __builtin_amdgcn_alignbit(rl, ru, 1) ^ eo.w ^ ei.w;     // ror 1
+        fh = (uint64_t)nfl | ((uint64_t)nfu << 32);
+        rh = (uint64_t)nrl | ((uint64_t)nru << 32);
+    };
+    auto slots = [&]() {
+        const uint64_t h = fh < rh ? fh : rh;              // canonical
+        m[0] = min(m[0], (uint32_t)(h >> 32));
+        key0 = min(key0, ((uint32_t)(h >> 32) & ~127u) | kj);
+        kj++;
+        const uint32_t hl = (uint32_t)h, hu = (uint32_t)(h >> 32);
+        uint64_t acc = (uint64_t)hl * (uint32_t)C0;        // h * C0 = h * c_i for the slot with (i ^ M5) == 0
+        acc += (uint64_t)(hl * (uint32_t)(C0 >> 32) + hu * (uint32_t)C0) << 32;
+#pragma unroll
+        for (int d = 0; d < 32; d++) {
+            const int i = d ^ M5;
+            if (i >= 1 && i < S) m[i] = min(m[i], (uint32_t)(acc >> 32));
+            acc += h;
+        }
+    };
+    const uint32_t P = 2u * (uint32_t)(o0 - base16);       // bit position of base 0 in `codes`
+    {   // first k-mer: bases enter, none leaves
+        uint32_t d = P >> 5, lo = codes[d];
+        for (uint32_t i = 0; i < k; i += 16) {
+            const uint32_t nx = codes[++d];
+            uint64_t t = (uint64_t)__builtin_amdgcn_alignbit(nx, lo, P & 31) << 4;
+            lo = nx;
+            const uint32_t cnt = min(16u, k - i);
+            for (uint32_t j = 0; j < cnt; j++) {
+                roll(make_uint4(0, 0, 0, 0), ent(64 + ((uint32_t)t & 0x30u)));
+                t >>= 2;
             }
         }
-        a.sort_key[r] = key;
     }
-    if (a.read_rec) {
-        uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (high ? 0x80000000u : 0u));
-        rq[1] = make_uint4(s0, s1, s2, s3);
+    slots();
+    {
+        uint32_t left = len - k;                           // k-mers still to come
+        uint32_t di = (P + 2 * k) >> 5, dn = P >> 5;
+        const uint32_t si = (P + 2 * k) & 31, sn = P & 31;
+        uint32_t li = codes[di], ln = codes[dn];
+        while (left >= 16) {
+            const uint32_t ni = codes[++di], nn = codes[++dn];
+            const uint32_t wi = __builtin_amdgcn_alignbit(ni, li, si), wo = __builtin_amdgcn_alignbit(nn, ln, sn);
+            li = ni; ln = nn;
+            uint64_t ti = (uint64_t)wi << 4, to = (uint64_t)wo << 4;     // code of the pair's first base at bits 4..5, second at 6..7
+#pragma unroll 1
+            for (int p = 0; p < 8; p++) {
+                const uint32_t a0 = (uint32_t)to & 0x30u, b0 = (uint32_t)ti & 0x30u, a1 = (uint32_t)to & 0xC0u, b1 = (uint32_t)ti & 0xC0u;
+                ti >>= 4; to >>= 4;
+                roll(ent(a0), ent(64 + b0));
+                slots();
+                roll(ent(256 + a1), ent(256 + 16 + b1));
+                slots();
+            }
+            left -= 16;
+        }
+        if (left) {
+            const uint32_t wi = __builtin_amdgcn_alignbit(codes[di + 1], li, si), wo = __builtin_amdgcn_alignbit(codes[dn + 1], ln, sn);
+            for (uint32_t j = 0; j < left; j++) {
+                roll(ent(((wo >> (2 * j)) & 3u) << 4), ent(64 + (((wi >> (2 * j)) & 3u) << 4)));
+                slots();
+            }
+        }
     }
-    if (n_hits) {
-        if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;   // this kmerCount needs a row of the call-count table
-        atomicAdd(&a.ctr->seeds, (unsigned long long)n_hits);
-        atomicMax(&a.ctr->max_seeds, n_hits);
-        if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
+
+    // ---- ContainmentIndex.Query (lshe.go:153-175), every slot must be equal ----
+    uint64_t x = GROOT_SIG_HASH_INIT;
+#pragma unroll
+    for (int i = 0; i < S; i++) x = sig_hash_step(x, m[i] >> 5);
+    x = sig_hash_fin(x);
+    const uint32_t tag = (uint32_t)(x >> 32);
+    // the read as packed codes in registers, and a comparison with len bases of a packed text row starting at base o
+    uint32_t rdw[kTextWords];
+#pragma unroll
+    for (int j = 0; j < kTextWords; j++) rdw[j] = __builtin_amdgcn_alignbit(codes[(P >> 5) + j + 1], codes[(P >> 5) + j], P & 31);
+    const uint32_t n_full = len >> 4, tail_mask = (1u << (2 * (len & 15))) - 1u;
+    auto row_differs = [&](const uint8_t *row, uint32_t o) {
+        uint32_t t[kTextWords + 1];
+        __builtin_memcpy(t, row + (o >> 2), sizeof t);     // unaligned; runs into the next row, which the masks ignore
+        uint32_t diff = 0;
+#pragma unroll
+        for (int j = 0; j < kTextWords; j++) {
+            const uint32_t mask = (uint32_t)j < n_full ? ~0u : ((uint32_t)j == n_full ? tail_mask : 0u);
+            diff |= (__builtin_amdgcn_alignbit(t[j + 1], t[j], 2 * (o & 3)) ^ rdw[j]) & mask;
+        }
+        return diff;
+    };
+    const uint32_t j0 = key0 & 127u;
+    uint32_t n_tagged = 0, only_id = kEmpty, cls = kEmpty;
+    const uint4 *sig = reinterpret_cast<const uint4 *>(ix.sig);
+    for (uint32_t slot = (uint32_t)x & ix.sig_mask;; slot = (slot + 1) & ix.sig_mask) {
+        const uint4 e = sig[slot];                         // {tag, id, cls, text_len | argmin fwd << 8 | argmin rc << 16}
+        if (e.y == kEmpty) break;
+        if (e.x != tag) continue;
+        n_tagged++;
+        only_id = e.y;
+        const uint32_t tl = e.w & 255u;
+        if (cls != kEmpty || tl < len) continue;
+        // the text's smallest k-mer (first occurrence) must be the read's: that fixes the offset, per orientation
+        const uint8_t *rows = ix.win_text + (size_t)e.y * (2 * kTextMax / 4);
+        const uint32_t of = ((e.w >> 8) & 255u) - j0, orc = ((e.w >> 16) & 255u) - j0;
+        const bool okf = of <= tl - len, okr = orc <= tl - len;
+        const uint32_t df = okf ? row_differs(rows, of) : 1u, dr = okr ? row_differs(rows + kTextMax / 4, orc) : 1u;
+        if (!df || !dr) cls = e.z;
     }
+    if (n_tagged && cls == kEmpty) { todo_push(a, r); return; }
+    uint32_t n_hits = 0, min_win = kEmpty;
+    uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;
+    auto hit = [&](uint32_t id) {
+        if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
+        if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
+        n_hits++;
+        min_win = min(min_win, id);
+    };
+    if (n_tagged == 1) hit(only_id);
+    else if (n_tagged)
+        for (uint32_t slot = (uint32_t)x & ix.sig_mask;; slot = (slot + 1) & ix.sig_mask) {
+            const uint4 e = sig[slot];
+            if (e.y == kEmpty) break;
+            if (e.x == tag && e.z == cls) hit(e.y);
+        }
+    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false);   // all bytes are ACGT
 }
 
 // groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
@@ -455,9 +764,20 @@ __global__ __launch_bounds__(kBlock) void patch_reads_kernel(const uint64_t *__r
 // the align stage.  More kmerCounts than rows: kFlagQOverflow, the align stage does nothing, the host grows the table
 // and re-runs the batch.
 __global__ void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t *q_of_row, uint32_t *n_rows, uint32_t cap, uint32_t max_q,
-                                     DeviceCounters *ctr)
+                                     DeviceCounters *ctr, unsigned long long *shards)
 {
     if (threadIdx.x || blockIdx.x) return;
+    {   // the seed kernels' sharded counters -> this batch's counter block
+        unsigned long long seeds = 0, most = 0;
+        for (uint32_t i = 0; i < kSeedShards; i++) {
+            unsigned long long *sh = shards + (size_t)i * kSeedShardStride;
+            seeds += sh[0];
+            most = sh[1] > most ? sh[1] : most;
+            sh[0] = 0; sh[1] = 0;
+        }
+        ctr->seeds += seeds;
+        if (most > ctr->max_seeds) ctr->max_seeds = (unsigned int)most;
+    }
     uint32_t need = *n_rows;
     for (uint32_t q = 0; q <= max_q; q++) {
         if (!q_seen[q]) continue;

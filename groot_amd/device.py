@@ -27,7 +27,7 @@ class Params(C.Structure):
 
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("received", "mapped", "multimapped", "alignments", "seeds", "travs",
-                                            "revcomp_panics", "short_reads")]
+                                            "revcomp_panics", "short_reads", "full_sketch_reads")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -71,6 +71,8 @@ typedef struct groot_counts {
     uint64_t travs;          /* groot_trav records of the batch                                      */
     uint64_t revcomp_panics; /* reads on which the reference panics in RevComplement (seqio.go:126)  */
     uint64_t short_reads;    /* reads shorter than k (reference panics, boss.go:164-166)             */
+    uint64_t full_sketch_reads; /* reads whose seeds the full-width sketch kernel decided: all of them, or -- when the
+                                 * signature kernel runs in front of it -- those it could not decide (diagnostic) */
 } groot_counts;
 
 /* per-stage device time of a batch, HIP events (ms); 0 if profiling off.

@@ -1,0 +1,104 @@
+"""The signature kernel in front of the full-width sketch kernel (sketch_sig_kernel: top 27 bits of every KHF slot ->
+signature table -> confirmation against the window's text; khf.go:35-55, lshe.go:153-175, graph.go:293-333): whatever mix
+of reads it is given, seeds / records / counters / call counts equal the full-width kernel's and the oracle's, and it
+hands exactly the undecidable reads to the full-width kernel."""
+import numpy as np
+import pytest
+
+from groot_amd import device, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(hip_lib):
+    assert device.device_count() > 0, "no MI355X visible: the HIP path has no CPU fallback"
+
+
+def mixed_batch(index, n=6000, seed=11):
+    """error-free 100-mers of both strands, plus: one substitution, an N, an IUPAC code (bytes > 'T' are left out: panic),
+    99 / 101 / 60-bp reads, a read that is all one base"""
+    cat, o, lens = synth.reference_sequences(index)
+    seq, off, _ = synth.reads_np(cat, o, lens, n, 100)
+    rng = np.random.default_rng(seed)
+    reads = [bytearray(seq[int(off[i]):int(off[i + 1])]) for i in range(n)]
+    kinds = rng.integers(0, 12, n)
+    for i, kind in enumerate(kinds):
+        r = reads[i]
+        if kind == 0:                                   # substitution somewhere (most lose a minimiser, a few keep all of them)
+            p = int(rng.integers(0, len(r)))
+            r[p] = b"ACGT"[(b"ACGT".index(r[p]) + 1 + int(rng.integers(0, 3))) % 4]
+        elif kind == 1 and i % 3 == 0:
+            r[int(rng.integers(0, len(r)))] = ord("N")
+        elif kind == 1 and i % 3 == 1:
+            r[int(rng.integers(0, len(r)))] = ord("R")  # IUPAC code <= 'T': hashes with seed 0, complements to 0
+        elif kind == 2 and i % 4 == 0:
+            del r[-1]                                   # 99 bp
+        elif kind == 2 and i % 4 == 1:
+            r.append(ord("A"))                          # 101 bp
+        elif kind == 2 and i % 4 == 2:
+            del r[60:]                                  # 60 bp: LSH-Forest branch
+        elif kind == 3 and i % 50 == 0:
+            r[:] = b"A" * 100
+    return O.pack_reads([bytes(r) for r in reads])
+
+
+def run(index, seq, off, monkeypatch, no_sig, threshold=0.99):
+    if no_sig:
+        monkeypatch.setenv("GROOT_NO_SIG", "1")
+    else:
+        monkeypatch.delenv("GROOT_NO_SIG", raising=False)
+    al = device.Aligner(index, threshold=threshold, max_batch_reads=max(1024, len(off) - 1), max_read_len=128)
+    al.submit(seq, off)
+    counts = al.wait()
+    out = dict(counts=counts, seeds=al.seeds().copy(), alns=al.alns().copy(), att=al.attempts().copy())
+    al.close()
+    return out
+
+
+@pytest.mark.parametrize("which", ["small", "argannot"])
+def test_mixed_reads_signature_equals_full_width_equals_oracle(small_index, argannot_index, monkeypatch, which):
+    index = small_index if which == "small" else argannot_index
+    seq, off = mixed_batch(index)
+    n = len(off) - 1
+    a = run(index, seq, off, monkeypatch, no_sig=False)
+    b = run(index, seq, off, monkeypatch, no_sig=True)
+    orc = O.Run(index, 0.99)
+    orc.batch(seq, off)
+    for got in (a, b):
+        assert np.array_equal(got["seeds"], orc.seeds().astype(device.SEED_DTYPE))
+        exp = orc.alns()
+        assert len(got["alns"]) == len(exp) and all(np.array_equal(got["alns"][f], exp[f]) for f in exp.dtype.names)
+        oatt = orc.attempts()
+        assert np.array_equal(got["att"][: oatt.shape[0]], oatt)
+        for k in ("received", "mapped", "multimapped", "alignments", "seeds", "revcomp_panics"):
+            assert got["counts"][k] == orc.counts()[k], k
+    assert b["counts"]["full_sketch_reads"] == n
+    # the signature kernel keeps the error-free 100-mers (about three quarters of this batch) and passes on the rest
+    assert 0.05 * n < a["counts"]["full_sketch_reads"] < 0.45 * n
+
+
+def test_general_lsh_threshold_goes_to_the_full_width_kernel(small_index, monkeypatch):
+    seq, off = mixed_batch(small_index, n=3000, seed=5)
+    a = run(small_index, seq, off, monkeypatch, no_sig=False, threshold=0.9)
+    b = run(small_index, seq, off, monkeypatch, no_sig=True, threshold=0.9)
+    assert a["counts"]["full_sketch_reads"] == len(off) - 1          # fewer than all slots must agree: not the signature kernel's case
+    assert np.array_equal(a["seeds"], b["seeds"]) and np.array_equal(a["att"], b["att"])
+    assert len(a["alns"]) == len(b["alns"]) and all(np.array_equal(a["alns"][f], b["alns"][f]) for f in a["alns"].dtype.names)
+    assert {k: v for k, v in a["counts"].items()} == {k: v for k, v in b["counts"].items()}
+
+
+def test_reads_with_n_next_to_clean_reads(small_index, monkeypatch):
+    """a byte other than ACGT marks its 16-byte chunk: the read and (conservatively) a neighbour sharing the chunk take the
+    full-width kernel, everything else stays with the signature kernel -- results unchanged"""
+    cat, o, lens = synth.reference_sequences(small_index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 2048, 100)
+    seq = seq.copy()
+    for r in range(0, 2048, 64):
+        seq[int(off[r]) + (r % 100)] = ord("N")
+    a = run(small_index, seq, off, monkeypatch, no_sig=False)
+    b = run(small_index, seq, off, monkeypatch, no_sig=True)
+    assert np.array_equal(a["seeds"], b["seeds"]) and np.array_equal(a["att"], b["att"])
+    assert all(np.array_equal(a["alns"][f], b["alns"][f]) for f in a["alns"].dtype.names)
+    assert 32 <= a["counts"]["full_sketch_reads"] < 300
