@@ -82,6 +82,13 @@ __device__ __forceinline__ bool prefix_absent(const uint32_t *tab, uint64_t c0, 
     return b >= 0 && !((tab[128 + (b >> 5)] >> (b & 31)) & 1u);
 }
 
+// the same with the 6-mer codes at hand (all twelve bases are ACGT); needs eff >= 12
+__device__ __forceinline__ bool prefix_absent_codes(const uint32_t *tab, uint32_t a, uint32_t b)
+{
+    if (!((tab[a >> 5] >> (a & 31)) & 1u)) return true;
+    return !((tab[128 + (b >> 5)] >> (b & 31)) & 1u);
+}
+
 // ---- 8 bases at a time (SWAR on the ASCII bytes; little endian: byte 0 = first base) ----
 constexpr uint64_t kLo7 = 0x7F7F7F7F7F7F7F7FULL, kHi1 = 0x8080808080808080ULL, kOnes = 0x0101010101010101ULL;
 
@@ -142,13 +149,32 @@ constexpr uint32_t kLdsTabCout = 4096 + 64;      // u64[8]   ror(seedTab[c], 1)
 constexpr uint32_t kLdsTabCin = 4096 + 128;      // u64[8]   rol(seedTab[c], k-1)
 constexpr uint32_t kLdsReads = 4096 + 192;       // staged read bytes (16-byte aligned)
 
+// both halves of a 32-byte record in flight together, and kept from being split into per-field loads sunk into branches
+__device__ __forceinline__ void load32(const void *p, uint4 &a, uint4 &b)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    a = q[0]; b = q[1];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
+
+// What sketch_sig_kernel fetched ahead for the window it expects to be the read's first seed: the lshe.Key record and the
+// four prefix-table words its verdicts need (one round trip together with the text rows instead of two more after them)
+struct SeedAhead {
+    uint32_t win = kEmpty;     // kEmpty: nothing fetched
+    uint4 wa = {}, wb = {};    // WinRec
+    uint32_t tf_a = 0, tf_b = 0, tr_a = 0, tr_b = 0;   // prefix-table words of code_f / code_r
+};
+
 // What every seed kernel leaves behind for one read once its seed windows are known (n_hits of them, the first four in
 // s0..s3, the smallest id in min_win): seed_count, the read record with the align stage's verdicts, its scheduling key,
 // the batch counters.
 __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
                                               const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
-                                              const uint32_t s2, const uint32_t s3, const bool high)
+                                              const uint32_t s2, const uint32_t s3, const bool high, const bool have_codes = false,
+                                              const uint32_t code_f = 0, const uint32_t code_r = 0, const SeedAhead *ahead = nullptr)
 {
+    // have_codes: the read is all ACGT and at least 12 bases long; code_f / code_r = 2-bit codes of oriented bases [0,12) of
+    // the forward read / its reverse complement (base i at bits 2i)
     const DeviceIndex &ix = a.ix;
     a.seed_count[r] = n_hits | (high ? 0x80000000u : 0u);   // bit 31: the read holds a byte > 'T'
     // scheduling key for the align stage: reads are processed in (first seed window, likely orientation) order so
@@ -162,7 +188,12 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
     if (a.sort_key) {
         uint32_t key = kEmpty;
         if (n_hits) {
-            const WinRec wr = ix.win_rec[min_win];
+            const bool pre = ahead && ahead->win == min_win;
+            WinRec wr;
+            if (pre) {
+                wr.graph = ahead->wa.x; wr.node = ahead->wa.y; wr.offset = ahead->wa.z; wr.l1_hi = ahead->wa.w;
+                wr.cn_off = ahead->wb.x; wr.cn_end = ahead->wb.y; wr.seed_s0 = ahead->wb.z; wr.seed_len = ahead->wb.w;
+            } else wr = ix.win_rec[min_win];
             const uint32_t *tab = ix.win_prefix + (size_t)min_win * kPrefixWords;
             const uint8_t *p = a.seq + o0;
             const bool in_node = wr.offset < wr.seed_len;         // else levels 3-4 are skipped (alignment.go:199-201)
@@ -172,7 +203,11 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
 #pragma unroll
             for (uint32_t t = 0; t < 2; t++) {
                 const uint64_t c0 = read_chunk(p, len, t, 0, 0), c1 = read_chunk(p, len, t, 0, 8);
-                uint32_t vt = prefix_absent(tab, c0, c1, len) ? kRecNo12F : 0u;
+                const uint32_t c12 = t ? code_r : code_f;
+                bool no12;
+                if (pre) no12 = !(((t ? ahead->tr_a : ahead->tf_a) >> (c12 & 31)) & 1u) || !(((t ? ahead->tr_b : ahead->tf_b) >> ((c12 >> 12) & 31)) & 1u);
+                else no12 = have_codes ? prefix_absent_codes(tab, c12 & 0xFFFu, c12 >> 12) : prefix_absent(tab, c0, c1, len);
+                uint32_t vt = no12 ? kRecNo12F : 0u;
                 if (!in_node || !prefix_ok(g8, (c0 >> 8) | (c1 << 56), m34)) vt |= kRecNo3F;    // read[1:] at (seed, OffSet)
                 if (!in_node || !prefix_ok(g8, c0, m34)) vt |= kRecNo4F;                         // read[:len-1] there
                 if (vt == (kRecNo12F | kRecNo3F | kRecNo4F)) dead |= 2u >> t;
@@ -195,14 +230,25 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
     }
     if (n_hits) {
         if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;   // this kmerCount needs a row of the call-count table
-        // (sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per 10 M reads; assign_q_rows_kernel folds them)
-        unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
-        atomicAdd(sh, (unsigned long long)n_hits);
-        atomicMax(sh + 1, (unsigned long long)n_hits);
         if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
     }
+    // sum and maximum of n_hits over the lanes that are here together (ballots per level: reads have one or two seeds), then
+    // one pair of atomics per wavefront, sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per
+    // 10 M reads.  assign_q_rows_kernel folds the shards into the batch's counter block.
+    uint32_t total = 0, most = 0;
+    for (uint32_t t = 1;; t++) {
+        const unsigned long long b = __ballot(n_hits >= t);
+        if (!b) break;
+        total += (uint32_t)__popcll(b);
+        most = t;
+    }
+    const unsigned long long here = __ballot(1);
+    if (total && __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) == 0) {
+        unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
+        atomicAdd(sh, (unsigned long long)total);
+        atomicMax(sh + 1, (unsigned long long)most);
+    }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // K1+K2
@@ -697,6 +743,16 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         }
         return diff;
     };
+    // 2-bit codes of the first twelve bases of both orientations, for the prefix-table verdicts
+    uint32_t code_r = 0;
+    const uint32_t code_f = rdw[0] & 0xFFFFFFu;
+    if (len >= 12) {
+        const uint32_t Q = P + 2 * (len - 12);
+        const uint32_t x = __builtin_amdgcn_alignbit(codes[(Q >> 5) + 1], codes[Q >> 5], Q & 31) & 0xFFFFFFu;   // bases len-12 .. len-1
+        const uint32_t y = __builtin_bitreverse32(x) >> 8;                                                        // last base first, bit pairs swapped
+        code_r = (((y & 0x555555u) << 1) | ((y >> 1) & 0x555555u)) ^ 0xAAAAAAu;                                   // pairs restored, complemented (code ^ 2)
+    }
+    SeedAhead ahead;
     const uint32_t j0 = key0 & 127u;
     uint32_t n_tagged = 0, only_id = kEmpty, cls = kEmpty;
     const uint4 *sig = reinterpret_cast<const uint4 *>(ix.sig);
@@ -706,6 +762,13 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         if (e.x != tag) continue;
         n_tagged++;
         only_id = e.y;
+        if (n_tagged == 1 && len >= 12 && a.sort_key) {    // most likely the read's only seed: what the verdicts will need, in flight now
+            ahead.win = e.y;
+            load32(ix.win_rec + e.y, ahead.wa, ahead.wb);
+            const uint32_t *tab = ix.win_prefix + (size_t)e.y * kPrefixWords;
+            ahead.tf_a = tab[(code_f & 0xFFFu) >> 5]; ahead.tf_b = tab[128 + (code_f >> 17)];
+            ahead.tr_a = tab[(code_r & 0xFFFu) >> 5]; ahead.tr_b = tab[128 + (code_r >> 17)];
+        }
         const uint32_t tl = e.w & 255u;
         if (cls != kEmpty || tl < len) continue;
         // the text's smallest k-mer (first occurrence) must be the read's: that fixes the offset, per orientation
@@ -731,7 +794,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (e.y == kEmpty) break;
             if (e.x == tag && e.z == cls) hit(e.y);
         }
-    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false);   // all bytes are ACGT
+    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
 }
 
 // groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
@@ -873,14 +936,6 @@ __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
 }
 // 0x80 in the low n bytes (n may exceed 8 or be <= 0)
 __device__ __forceinline__ uint64_t low_bytes(int n) { return n <= 0 ? 0 : (n >= 8 ? kHi1 : (kHi1 >> (8 * (8 - n)))); }
-
-// both halves of a 32-byte record in flight together, and kept from being split into per-field loads sunk into branches
-__device__ __forceinline__ void load32(const void *p, uint4 &a, uint4 &b)
-{
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    a = q[0]; b = q[1];
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-}
 
 // a NodeRec held in registers as dwords (16-byte loads; every access below uses a constant index)
 template <int PW> struct RecRegs {
