@@ -84,10 +84,14 @@ struct alignas(16) SigEntry {
     uint32_t tag;          // high half of the signature hash
     uint32_t id;           // window; kEmpty = free slot
     uint32_t cls;          // windows with identical 64-bit sketches share a class
-    uint32_t text_len;     // bits 0..7: bases of the window's text that were verified at open (0: the window cannot confirm a read);
-                           // bits 8..15 / 16..23: first position of the smallest canonical k-mer hash in the forward / reverse-complement row
+    uint32_t text_len;     // bits 0..9: bases of the window's text that were verified at open (0: the window cannot confirm a read);
+                           // bits 10..19 / 20..29: first position of the smallest canonical k-mer hash in the forward / reverse-complement row
 };
-constexpr uint32_t kTextMax = 128;       // bases kept per window text (window + merged neighbours), per orientation
+constexpr uint32_t kTextMax = 256;       // bases kept per window text (window + merged neighbours), per orientation
+// SigEntry::text_len fields
+__host__ __device__ inline uint32_t sig_text_pack(uint32_t len, uint32_t argmin_fwd, uint32_t argmin_rc) { return len | (argmin_fwd << 10) | (argmin_rc << 20); }
+__host__ __device__ inline uint32_t sig_text_len(uint32_t v) { return v & 1023u; }
+__host__ __device__ inline uint32_t sig_text_argmin(uint32_t v, uint32_t row) { return (v >> (10 + 10 * row)) & 1023u; }
 
 // graph + window arrays resident in HBM (replicated per GPU)
 struct DeviceIndex {
@@ -147,6 +151,7 @@ struct SeedArgs {
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
+    uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
     DeviceCounters *ctr;
 };
 

@@ -457,10 +457,12 @@ static void launch_seed(uint32_t s, uint32_t max_k, const SeedArgs &a, bool dump
 
 // sketch_sig_kernel + the list pass of sketch_seed_kernel behind it: instances for the (sketch size, k) pairs that have a
 // strength-reduced sketch_seed_kernel above
-template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
+template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((sketch_sig_kernel<S, M5>), grid, dim3(kBlock), lds, st, a);
-    hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads, st, a);
+    // (reads of up to 128 bases: half the registers and instructions in the text comparison)
+    if (max_len <= 128) hipLaunchKernelGGL((sketch_sig_kernel<S, M5, 8>), grid, dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((sketch_sig_kernel<S, M5, (int)kTextMax / 16>), grid, dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
 }
 static bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
 {
@@ -468,15 +470,15 @@ static bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
     if (max_k != 4) return false;
     return (s == 21 && (m5 == 6 || m5 == 10 || m5 == 14 || m5 == 2)) || (s == 20 && m5 == 6) || (s == 30 && m5 == 14);
 }
-static void launch_sig(uint32_t s, const SeedArgs &a, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
+static void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
 {
     const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, grid, lds, list_grid, st);
-    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, grid, lds, list_grid, st);
-    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, max_len, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, max_len, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, max_len, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, max_len, grid, lds, list_grid, st);
+    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, max_len, grid, lds, list_grid, st);
+    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, max_len, grid, lds, list_grid, st);
 }
 
 static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
@@ -578,9 +580,11 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
         // signature kernel first; what it cannot decide goes through the full-width kernel, read by read
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
+        const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;     // the LIST pass copies each read into its lane's LDS slice
+        a.list_stride_dw = (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
-        const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 64;   // (+: the kernel reads whole register rows past a read)
-        launch_sig(c->s, a, grid, lds, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
+        const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;   // (+: the kernel reads whole register rows past a read)
+        launch_sig(c->s, a, s->max_len, grid, lds, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
     } else {
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
@@ -1214,7 +1218,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
         x = sig_hash_fin(x);
         uint32_t slot = (uint32_t)x & (cap - 1);
         while (tab[slot].id != kEmpty) slot = (slot + 1) & (cap - 1);
-        tab[slot] = SigEntry{(uint32_t)(x >> 32), i, sketch_class[i], tlen[i] | ((uint32_t)argmin[2 * i] << 8) | ((uint32_t)argmin[2 * i + 1] << 16)};
+        tab[slot] = SigEntry{(uint32_t)(x >> 32), i, sketch_class[i], sig_text_pack(tlen[i], argmin[2 * i], argmin[2 * i + 1])};
     }
     HIP_TRY(c, upload(c->sig, tab.data(), tab.size()));
     HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));

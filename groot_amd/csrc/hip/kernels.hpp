@@ -375,8 +375,22 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
             rh = ror1(rh) ^ tabCout[prev & 7] ^ tabCin[end & 7];
         }
     };
-    if (in_lds) sketch(lds_reads + (o0 - base16));   // LDS address space
-    else sketch(a.seq + o0);                         // span too large for LDS: straight from HBM
+    if constexpr (LIST) {
+        if (a.list_stride_dw && len <= 4 * a.list_stride_dw - 4) {
+            // the lane's own copy of its read (odd dword stride: conflict-free): 4-byte loads in flight together instead of
+            // two dependent byte loads from HBM per k-mer
+            uint32_t *mine = reinterpret_cast<uint32_t *>(lds_reads) + (size_t)tid * a.list_stride_dw;
+            for (uint32_t i = 0; i < len; i += 4) {
+                uint32_t v;
+                __builtin_memcpy(&v, a.seq + o0 + i, 4);     // (reads up to 3 bytes past the read: the batch buffer is padded)
+                mine[i >> 2] = v;
+            }
+            sketch(reinterpret_cast<const unsigned char *>(mine));
+        } else sketch(a.seq + o0);
+    } else {
+        if (in_lds) sketch(lds_reads + (o0 - base16));   // LDS address space
+        else sketch(a.seq + o0);                         // span too large for LDS: straight from HBM
+    }
     if (DUMP) {
 #pragma unroll
         for (int i = 0; i < s_; i++) a.sketch_out[(size_t)r * s_ + i] = m[i];
@@ -554,7 +568,6 @@ __device__ __forceinline__ void todo_push(const SeedArgs &a, uint32_t r)
     base = __shfl(base, leader);
     a.todo_list[base + __popcll(active & ((1ULL << lane) - 1ULL))] = r;
 }
-constexpr int kTextWords = kTextMax / 16;        // dwords of one packed window text row (2 bits per base)
 
 // first position of the smallest canonical ntHash among the k-mers of every window text row (ASCII, kTextMax bytes per
 // row, two rows per window): sketch_sig_kernel finds where a read lies inside a text from where its own smallest k-mer is
@@ -583,10 +596,13 @@ __global__ __launch_bounds__(kBlock) void text_argmin_kernel(const uint8_t *__re
     pos[row] = (uint8_t)best_pos;
 }
 
-template <int S, int M5>
+// TW: dwords of a packed read the text comparison handles (reads of up to 16 * TW bases; longer ones take the full-width kernel)
+template <int S, int M5, int TW>
 __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(SeedArgs a)
 {
     static_assert(S >= 1 && S <= 32 && M5 >= 0 && M5 < 32, "slots i < 32 with a compile-time (k * multiSeed) & 31 only");
+    static_assert(TW >= 1 && 16 * TW <= (int)kTextMax, "a read cannot be longer than a window text");
+    constexpr int kTextWords = TW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ __attribute__((aligned(512))) unsigned char tab[512];
     uint32_t *badbits = reinterpret_cast<uint32_t *>(smem + kSigBad);
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     const uint64_t o0 = a.seq_off[r];
     const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
     const uint32_t q = len - k + 1;                        // kmerCount, boss.go:169
-    bool fast = in_lds && len >= k && len <= a.max_read_len && len <= kTextMax && q <= ix.max_q;   // (no window text is longer)
+    bool fast = in_lds && len >= k && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
     if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch, or nothing can be found
     if (fast) {
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     for (int i = 0; i < S; i++) m[i] = ~0u;
     const uint64_t C0 = ((uint64_t)k * GROOT_MULTI_SEED) & ~31ULL;
     uint64_t fh = 0, rh = 0;
-    uint32_t key0 = ~0u, kj = 0;     // smallest (top 25 bits of h | k-mer index): where the read's smallest k-mer is (ties: see the text compare)
+    uint32_t key0 = ~0u, kj = 0;     // smallest (top 24 bits of h | k-mer index): where the read's smallest k-mer is (ties: see the text compare)
     auto ent = [&](uint32_t byte_off) { return *reinterpret_cast<const uint4 *>(tab + byte_off); };
     auto roll = [&](const uint4 eo, const uint4 ei) {
         const uint32_t fl = (uint32_t)fh, fu = (uint32_t)(fh >> 32), rl = (uint32_t)rh, ru = (uint32_t)(rh >> 32);
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     auto slots = [&]() {
         const uint64_t h = fh < rh ? fh : rh;              // canonical
         m[0] = min(m[0], (uint32_t)(h >> 32));
-        key0 = min(key0, ((uint32_t)(h >> 32) & ~127u) | kj);
+        key0 = min(key0, ((uint32_t)(h >> 32) & ~255u) | kj);
         kj++;
         const uint32_t hl = (uint32_t)h, hu = (uint32_t)(h >> 32);
         uint64_t acc = (uint64_t)hl * (uint32_t)C0;        // h * C0 = h * c_i for the slot with (i ^ M5) == 0
@@ -753,11 +769,11 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         code_r = (((y & 0x555555u) << 1) | ((y >> 1) & 0x555555u)) ^ 0xAAAAAAu;                                   // pairs restored, complemented (code ^ 2)
     }
     SeedAhead ahead;
-    const uint32_t j0 = key0 & 127u;
+    const uint32_t j0 = key0 & 255u;
     uint32_t n_tagged = 0, only_id = kEmpty, cls = kEmpty;
     const uint4 *sig = reinterpret_cast<const uint4 *>(ix.sig);
     for (uint32_t slot = (uint32_t)x & ix.sig_mask;; slot = (slot + 1) & ix.sig_mask) {
-        const uint4 e = sig[slot];                         // {tag, id, cls, text_len | argmin fwd << 8 | argmin rc << 16}
+        const uint4 e = sig[slot];                         // {tag, id, cls, sig_text_pack(text_len, argmin fwd, argmin rc)}
         if (e.y == kEmpty) break;
         if (e.x != tag) continue;
         n_tagged++;
@@ -769,11 +785,11 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             ahead.tf_a = tab[(code_f & 0xFFFu) >> 5]; ahead.tf_b = tab[128 + (code_f >> 17)];
             ahead.tr_a = tab[(code_r & 0xFFFu) >> 5]; ahead.tr_b = tab[128 + (code_r >> 17)];
         }
-        const uint32_t tl = e.w & 255u;
+        const uint32_t tl = sig_text_len(e.w);
         if (cls != kEmpty || tl < len) continue;
         // the text's smallest k-mer (first occurrence) must be the read's: that fixes the offset, per orientation
         const uint8_t *rows = ix.win_text + (size_t)e.y * (2 * kTextMax / 4);
-        const uint32_t of = ((e.w >> 8) & 255u) - j0, orc = ((e.w >> 16) & 255u) - j0;
+        const uint32_t of = sig_text_argmin(e.w, 0) - j0, orc = sig_text_argmin(e.w, 1) - j0;
         const bool okf = of <= tl - len, okr = orc <= tl - len;
         const uint32_t df = okf ? row_differs(rows, of) : 1u, dr = okr ? row_differs(rows + kTextMax / 4, orc) : 1u;
         if (!df || !dr) cls = e.z;

@@ -102,3 +102,44 @@ def test_reads_with_n_next_to_clean_reads(small_index, monkeypatch):
     assert np.array_equal(a["seeds"], b["seeds"]) and np.array_equal(a["att"], b["att"])
     assert all(np.array_equal(a["alns"][f], b["alns"][f]) for f in a["alns"].dtype.names)
     assert 32 <= a["counts"]["full_sketch_reads"] < 300
+
+
+@pytest.mark.parametrize("k,s,w", [(31, 21, 200), (41, 21, 150), (51, 30, 120), (21, 21, 60), (31, 20, 100), (31, 21, 256)])
+def test_every_compiled_instance_and_long_windows(msa_dir, monkeypatch, k, s, w):
+    """the (sketch size, k) pairs with a signature kernel, window sizes on both sides of 128 bases (two text widths)"""
+    from groot_amd import host
+
+    monkeypatch.delenv("GROOT_NO_SIG", raising=False)
+    index = host.Index.from_msa_files(host.msa_files(msa_dir)[:8], host.index_params(k=k, s=s, w=w))
+    cat, o, lens = synth.reference_sequences(index)
+    rng = np.random.default_rng(k + s + w)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    reads = []
+    for i in range(3000):
+        sq = int(rng.integers(0, len(lens)))
+        L = min(w, int(lens[sq]))
+        st = int(rng.integers(0, lens[sq] - L + 1))
+        r = bytearray(cat[int(o[sq]) + st:int(o[sq]) + st + L].tobytes())
+        if i % 7 == 0:
+            p = int(rng.integers(0, L))
+            r[p] = ord("A") if r[p] != ord("A") else ord("C")
+        r = bytes(r)
+        reads.append(r.translate(comp)[::-1] if rng.integers(0, 2) else r)
+    seq, off = O.pack_reads(reads)
+    al = device.Aligner(index, max_batch_reads=4096, max_read_len=max(256, w))
+    al.submit(seq, off)
+    counts = al.wait()
+    orc = O.Run(index, 0.99)
+    orc.batch(seq, off)
+    assert np.array_equal(al.seeds(), orc.seeds().astype(device.SEED_DTYPE))
+    got, exp = al.alns(), orc.alns()
+    assert len(got) == len(exp) and all(np.array_equal(got[f], exp[f]) for f in exp.dtype.names)
+    oatt = orc.attempts()
+    assert np.array_equal(al.attempts()[: oatt.shape[0]], oatt)
+    for f in ("received", "mapped", "multimapped", "alignments", "seeds"):
+        assert counts[f] == orc.counts()[f], f
+    if w <= 200:    # (256-base windows leave no room for the merged neighbours in a 256-base text: only reads at offset 0 stay)
+        assert counts["full_sketch_reads"] < 0.4 * counts["received"]  # the signature kernel decided the error-free reads
+    else:
+        assert counts["full_sketch_reads"] < counts["received"]
+    al.close()
