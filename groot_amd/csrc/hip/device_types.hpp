@@ -132,6 +132,12 @@ struct DeviceIndex {
     const SigEntry *sig;
     uint32_t sig_mask;
     const uint8_t *win_text;
+    // what the seed stage's epilogue works out for a read that IS bases [o, o + WindowSize) of a text row (every such read is
+    // the same string): verdict bits (kRecNo* >> 24, both orientations) | dead-orientation class << 6, as the full-width kernel
+    // produced them for exactly that string when the ctx was opened -- [(window * 2 + row) * sig_verdict_stride + o]; null = none
+    const uint8_t *sig_verdict;
+    uint32_t sig_verdict_stride;
+    const uint8_t *win_nodes;       // [n_windows] min(255, contained nodes of the window): the span class of the scheduling key
 };
 
 struct SeedArgs {

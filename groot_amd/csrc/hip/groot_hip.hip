@@ -132,7 +132,7 @@ struct groot_ctx {
     DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
     DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature table + window texts (absent: that kernel is not used)
-    DevBuf<uint8_t> win_text;
+    DevBuf<uint8_t> win_text, sig_verdict, win_nodes;
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
 
@@ -1113,6 +1113,45 @@ static int sketch_uniform(groot_ctx *c, const uint8_t *seqs, uint32_t n, uint32_
     return GROOT_OK;
 }
 
+// the full-width seed stage (lookups, verdicts, scheduling class) over n sequences of `len` bases: per read the record's
+// cnt_flags word and the scheduling key without span bits (first seed window << 2 | dead-orientation class)
+static int seed_uniform(groot_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t len, uint32_t *cnt_flags, uint32_t *keys)
+{
+    DevBuf<uint64_t> off;
+    DevBuf<uint8_t> seq;
+    DevBuf<DeviceCounters> ctr;
+    DevBuf<uint32_t> cnt, win, key;
+    DevBuf<ReadRec> rec;
+    const uint64_t total = (uint64_t)n * len;
+    HIP_TRY(c, off.alloc((size_t)n + 1));
+    HIP_TRY(c, seq.alloc(total + 64));
+    HIP_TRY(c, ctr.alloc(1));
+    HIP_TRY(c, cnt.alloc(n));
+    HIP_TRY(c, win.alloc((size_t)c->seed_slots * n));
+    HIP_TRY(c, key.alloc(n));
+    HIP_TRY(c, rec.alloc(n));
+    HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    const dim3 grid((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->stream, off.p, n, len);
+    SeedArgs a{};
+    a.ix = c->dix;
+    a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, c->prm.max_read_len);
+    a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * len + 32, kMaxLdsReadBytes);
+    a.seed_slots = c->seed_slots; a.seed_count = cnt.p; a.seed_win = win.p;
+    a.sort_key = key.p; a.sort_span_bits = 0; a.read_rec = rec.p;
+    a.ctr = ctr.p; a.shards = c->seed_shards.p;
+    launch_seed(c->s, c->max_k, a, false, grid, kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<ReadRec> h(n);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), rec.p, (size_t)n * sizeof(ReadRec), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(keys, key.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));   // (nobody folds them here)
+    for (uint32_t i = 0; i < n; i++) cnt_flags[i] = h[i].cnt_flags;
+    return GROOT_OK;
+}
+
 static int build_signature_index(groot_ctx *c, const groot_index_view *v, const std::vector<uint32_t> &sketch_class)
 {
     const uint32_t n = v->n_windows, s = v->sketch_size, w = v->window_size, k = v->kmer_size;
@@ -1186,7 +1225,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
         }
         if (int rc = flush()) return rc;
         for (uint32_t i = 0; i < n; i++)
-            if (!tlen[i]) { c->sig_disabled++; memset(&text[(size_t)i * 2 * kTextMax], 0, 2 * kTextMax); }
+            if (!tlen[i]) memset(&text[(size_t)i * 2 * kTextMax], 0, 2 * kTextMax);
     }
     // 3. where the smallest k-mer of every text row is (first occurrence), and the rows at 2 bits per base
     std::vector<uint8_t> argmin((size_t)n * 2, 0);
@@ -1208,7 +1247,46 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
             uint8_t *dst = &packed[((size_t)i * 2 + row) * (kTextMax / 4)];
             for (uint32_t j = 0; j < tlen[i]; j++) dst[j >> 2] |= (uint8_t)(((src[j] >> 1) & 3u) << (2 * (j & 3)));
         }
-    // 4. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
+    // 4. what the full-width seed stage's epilogue says about every WindowSize-mer of the texts (the reads the signature kernel
+    //    confirms ARE these strings): verdict bits and dead-orientation class, one byte each.  A text whose own bases do not
+    //    come back with a seed is dropped.
+    const uint32_t vstride = kTextMax - w + 1;
+    std::vector<uint8_t> verdict((size_t)n * 2 * vstride + 16, 0);
+    {
+        const uint32_t chunk = 1u << 20;
+        std::vector<uint8_t> seqs;
+        std::vector<uint32_t> owner, flags, keys;
+        std::vector<size_t> where;
+        auto flush = [&]() -> int {
+            if (owner.empty()) return GROOT_OK;
+            flags.resize(owner.size()); keys.resize(owner.size());
+            if (int rc = seed_uniform(c, seqs.data(), (uint32_t)owner.size(), w, flags.data(), keys.data())) return rc;
+            for (size_t j = 0; j < owner.size(); j++) {
+                if (!(flags[j] & kRecCountMask) || keys[j] == kEmpty) { tlen[owner[j]] = 0; continue; }
+                verdict[where[j]] = (uint8_t)(((flags[j] >> 24) & 0x3Fu) | ((keys[j] & 3u) << 6));
+            }
+            seqs.clear(); owner.clear(); where.clear();
+            return GROOT_OK;
+        };
+        for (uint32_t i = 0; i < n; i++) {
+            if (!tlen[i]) continue;
+            for (uint32_t row = 0; row < 2; row++)
+                for (uint32_t o = 0; o + w <= tlen[i]; o++) {
+                    const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax + o];
+                    seqs.insert(seqs.end(), src, src + w);
+                    owner.push_back(i);
+                    where.push_back(((size_t)i * 2 + row) * vstride + o);
+                }
+            if (owner.size() >= chunk)
+                if (int rc = flush()) return rc;
+        }
+        if (int rc = flush()) return rc;
+    }
+    c->sig_disabled = 0;
+    for (uint32_t i = 0; i < n; i++) c->sig_disabled += tlen[i] == 0;
+    std::vector<uint8_t> nodes(n);
+    for (uint32_t i = 0; i < n; i++) nodes[i] = (uint8_t)std::min<uint32_t>(255, v->win_cn_off[i + 1] - v->win_cn_off[i]);
+    // 5. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
     uint32_t cap = 16;
     while (cap < 2 * (uint64_t)n) cap <<= 1;
     std::vector<SigEntry> tab(cap, SigEntry{0, kEmpty, 0, 0});
@@ -1222,6 +1300,11 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     }
     HIP_TRY(c, upload(c->sig, tab.data(), tab.size()));
     HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));
+    HIP_TRY(c, upload(c->sig_verdict, verdict.data(), verdict.size()));
+    HIP_TRY(c, upload(c->win_nodes, nodes.data(), nodes.size(), 4));
+    c->dix.sig_verdict = getenv("GROOT_NO_SIG_VERDICTS") ? nullptr : c->sig_verdict.p;
+    c->dix.sig_verdict_stride = vstride;
+    c->dix.win_nodes = c->win_nodes.p;
     c->dix.sig = c->sig.p;
     c->dix.sig_mask = cap - 1;
     c->dix.win_text = c->win_text.p;

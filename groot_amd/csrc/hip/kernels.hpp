@@ -165,6 +165,32 @@ struct SeedAhead {
     uint32_t tf_a = 0, tf_b = 0, tr_a = 0, tr_b = 0;   // prefix-table words of code_f / code_r
 };
 
+// per-read bookkeeping every seed kernel ends with
+__device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t q, const uint32_t n_hits)
+{
+    const DeviceIndex &ix = a.ix;
+    if (n_hits) {
+        if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;   // this kmerCount needs a row of the call-count table
+        if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
+    }
+    // sum and maximum of n_hits over the lanes that are here together (ballots per level: reads have one or two seeds), then
+    // one pair of atomics per wavefront, sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per
+    // 10 M reads.  assign_q_rows_kernel folds the shards into the batch's counter block.
+    uint32_t total = 0, most = 0;
+    for (uint32_t t = 1;; t++) {
+        const unsigned long long b = __ballot(n_hits >= t);
+        if (!b) break;
+        total += (uint32_t)__popcll(b);
+        most = t;
+    }
+    const unsigned long long here = __ballot(1);
+    if (total && __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) == 0) {
+        unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
+        atomicAdd(sh, (unsigned long long)total);
+        atomicMax(sh + 1, (unsigned long long)most);
+    }
+}
+
 // What every seed kernel leaves behind for one read once its seed windows are known (n_hits of them, the first four in
 // s0..s3, the smallest id in min_win): seed_count, the read record with the align stage's verdicts, its scheduling key,
 // the batch counters.
@@ -228,26 +254,26 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
         rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (high ? 0x80000000u : 0u));
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
-    if (n_hits) {
-        if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;   // this kmerCount needs a row of the call-count table
-        if (n_hits > a.seed_slots) atomicOr(&a.ctr->flags, kFlagSeedOverflow);
+    seed_counters(a, q, n_hits);
+}
+
+// the same for a read known to be bases [o, o + WindowSize) of a window text row: its verdicts come from the table made at open
+__device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
+                                                    const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
+                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes)
+{
+    a.seed_count[r] = n_hits;
+    if (a.sort_key) {
+        uint32_t key = (min_win << 2) | (vbyte >> 6);
+        if (a.sort_span_bits) key |= (((1u << a.sort_span_bits) - 1u) - min(nodes, (1u << a.sort_span_bits) - 1u)) << (32u - a.sort_span_bits);
+        a.sort_key[r] = key;
     }
-    // sum and maximum of n_hits over the lanes that are here together (ballots per level: reads have one or two seeds), then
-    // one pair of atomics per wavefront, sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per
-    // 10 M reads.  assign_q_rows_kernel folds the shards into the batch's counter block.
-    uint32_t total = 0, most = 0;
-    for (uint32_t t = 1;; t++) {
-        const unsigned long long b = __ballot(n_hits >= t);
-        if (!b) break;
-        total += (uint32_t)__popcll(b);
-        most = t;
+    if (a.read_rec) {
+        uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u));
+        rq[1] = make_uint4(s0, s1, s2, s3);
     }
-    const unsigned long long here = __ballot(1);
-    if (total && __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) == 0) {
-        unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
-        atomicAdd(sh, (unsigned long long)total);
-        atomicMax(sh + 1, (unsigned long long)most);
-    }
+    seed_counters(a, q, n_hits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -769,6 +795,9 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         code_r = (((y & 0x555555u) << 1) | ((y >> 1) & 0x555555u)) ^ 0xAAAAAAu;                                   // pairs restored, complemented (code ^ 2)
     }
     SeedAhead ahead;
+    const bool use_table = ix.sig_verdict && len == ix.w && a.sort_key;   // the epilogue's answers for window-sized text reads exist already
+    uint32_t vbyte = 0, nodes_ahead = 0, first_id = kEmpty;
+    bool have_vbyte = false;
     const uint32_t j0 = key0 & 255u;
     uint32_t n_tagged = 0, only_id = kEmpty, cls = kEmpty;
     const uint4 *sig = reinterpret_cast<const uint4 *>(ix.sig);
@@ -778,7 +807,9 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         if (e.x != tag) continue;
         n_tagged++;
         only_id = e.y;
-        if (n_tagged == 1 && len >= 12 && a.sort_key) {    // most likely the read's only seed: what the verdicts will need, in flight now
+        if (n_tagged == 1) first_id = e.y;
+        if (n_tagged == 1 && use_table) nodes_ahead = ix.win_nodes[e.y];
+        else if (n_tagged == 1 && len >= 12 && a.sort_key) {    // most likely the read's only seed: what the verdicts will need, in flight now
             ahead.win = e.y;
             load32(ix.win_rec + e.y, ahead.wa, ahead.wb);
             const uint32_t *tab = ix.win_prefix + (size_t)e.y * kPrefixWords;
@@ -791,8 +822,18 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         const uint8_t *rows = ix.win_text + (size_t)e.y * (2 * kTextMax / 4);
         const uint32_t of = sig_text_argmin(e.w, 0) - j0, orc = sig_text_argmin(e.w, 1) - j0;
         const bool okf = of <= tl - len, okr = orc <= tl - len;
+        uint32_t vf = 0, vr = 0;
+        if (use_table) {
+            const uint8_t *vt = ix.sig_verdict + (size_t)e.y * 2 * ix.sig_verdict_stride;
+            if (okf) vf = vt[of];
+            if (okr) vr = vt[ix.sig_verdict_stride + orc];
+        }
         const uint32_t df = okf ? row_differs(rows, of) : 1u, dr = okr ? row_differs(rows + kTextMax / 4, orc) : 1u;
-        if (!df || !dr) cls = e.z;
+        if (!df || !dr) {
+            cls = e.z;
+            have_vbyte = use_table;
+            vbyte = !df ? vf : vr;
+        }
     }
     if (n_tagged && cls == kEmpty) { todo_push(a, r); return; }
     uint32_t n_hits = 0, min_win = kEmpty;
@@ -810,7 +851,8 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (e.y == kEmpty) break;
             if (e.x == tag && e.z == cls) hit(e.y);
         }
-    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
+    if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win]);
+    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
 }
 
 // groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
