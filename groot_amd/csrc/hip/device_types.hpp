@@ -41,7 +41,7 @@ struct DeviceCounters {
 template <int PW> struct alignas(16) NodeRec {
     uint32_t seq_off;          // into DeviceIndex::bases
     uint32_t seq_len;
-    uint32_t deg;              // out-degree; > 4: edges[0] is the offset into DeviceIndex::edges, child_first unused
+    uint32_t deg;              // bits 0..30 out-degree (> 4: edges[0] is the offset into DeviceIndex::edges, child_first unused); bit 31: the node holds an 'N'
     uint8_t child_first[4];    // first base of each embedded neighbour
     uint64_t first8;           // first 8 bases of the node (bytes past seq_len are don't-care)
     uint32_t edges[4];         // OutEdges order (global node indices)

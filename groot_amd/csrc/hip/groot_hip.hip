@@ -384,7 +384,9 @@ template <int PW> void build_node_records(const groot_index_view *v, std::vector
         r.seq_off = v->node_seq_off[n];
         r.seq_len = v->node_seq_off[n + 1] - v->node_seq_off[n];
         const uint32_t e0 = v->node_edge_off[n], deg = v->node_edge_off[n + 1] - e0;
-        r.deg = deg;
+        bool wild = false;
+        for (uint32_t i = 0; i < r.seq_len; i++) wild |= v->bases[r.seq_off + i] == 'N';
+        r.deg = deg | (wild ? 0x80000000u : 0u);        // bit 31: the node holds an 'N' (the wildcard of alignment.go:212-222)
         if (deg <= 4) {
             for (uint32_t e = 0; e < deg; e++) {
                 const uint32_t c = v->edges[e0 + e];
