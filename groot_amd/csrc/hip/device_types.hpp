@@ -170,7 +170,7 @@ struct AlignArgs {
     const uint32_t *seed_count;
     const uint32_t *seed_win;
     const uint32_t *perm;        // [n_reads] processing order (reads sorted by sort_key) or null
-    const ReadRec *read_rec;     // [n_reads]
+    const ReadRec *read_rec;     // [n_reads], by read
     uint32_t no_align, update_weights;
     const void *node_rec;        // NodeRec<pw>[n_nodes]
     uint32_t *attempts;          // [rows][n_windows], row = ix.q_row[kmerCount]

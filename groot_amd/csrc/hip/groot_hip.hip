@@ -153,7 +153,7 @@ struct groot_ctx {
     DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, todo_list, todo_count;
     DevBuf<unsigned long long> seed_shards;
     DevBuf<char> sort_tmp;
-    DevBuf<ReadRec> read_rec, read_rec_sorted;
+    DevBuf<ReadRec> read_rec;
     DevBuf<uint64_t> sketches;
     uint32_t ovf_cap = 0;
     DevBuf<groot_trav> trav_first, ovf_trav;
@@ -606,8 +606,6 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     }
     HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p,
                                          s->n_reads, 0, end_bit, c->stream));
-    hipLaunchKernelGGL(gather_recs_kernel, grid, dim3(kBlock), 0, c->stream, c->perm.p, c->read_rec.p, c->read_rec_sorted.p, s->n_reads);
-    HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
 
@@ -623,7 +621,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.seed_count = c->seed_count.p;
     a.seed_win = c->seed_win.p;
     a.perm = c->perm.p;
-    a.read_rec = c->read_rec_sorted.p;   // in perm order (gather_recs_kernel)
+    a.read_rec = c->read_rec.p;
     a.no_align = c->prm.no_exact_align;
     a.update_weights = update_weights ? 1 : 0;
     a.attempts = c->attempts_ptr;
@@ -1523,7 +1521,6 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->seed_count.alloc(R));
     HIP_TRY(c, c->sort_key.alloc(R));
     HIP_TRY(c, c->read_rec.alloc(R));
-    HIP_TRY(c, c->read_rec_sorted.alloc(R));
     HIP_TRY(c, c->sort_key_out.alloc(R));
     HIP_TRY(c, c->perm.alloc(R));
     {

@@ -926,19 +926,6 @@ __global__ __launch_bounds__(kBlock) void uniform_offsets_kernel(uint64_t *__res
     if (i <= n) off[i] = (uint64_t)i * len;
 }
 
-// read records in processing order: the align stage then fetches slot-consecutive (coalesced) records instead of
-// chasing perm[slot] -> read_rec[read]
-__global__ __launch_bounds__(kBlock) void gather_recs_kernel(const uint32_t *__restrict__ perm, const ReadRec *__restrict__ in,
-                                                             ReadRec *__restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint4 *src = reinterpret_cast<const uint4 *>(in + perm[i]);
-    uint4 *dst = reinterpret_cast<uint4 *>(out + i);
-    const uint4 x = src[0], y = src[1];
-    dst[0] = x; dst[1] = y;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K3
 // ---------------------------------------------------------------------------------------------
@@ -1251,8 +1238,8 @@ __global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignA
             if (!have_read) {
                 GROOT_EV(3);
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
-                uint4 ra, rb;                                     // one 32-byte record per read, records in slot order
-                load32(a.read_rec + slot, ra, rb);
+                uint4 ra, rb;                                     // one 32-byte record per read
+                load32(a.read_rec + r, ra, rb);                  // (gathering the records into processing order first costs more than this dependent trip)
                 const uint32_t sc = ra.w;
                 cnt = min(sc & kRecCountMask, a.seed_slots);   // overflow already flagged; batch is re-run
                 cls = a.perm ? (sc >> 24) & 0x3Fu : 0x80u;     // bit 7: no verdicts without the seed stage's sort keys
