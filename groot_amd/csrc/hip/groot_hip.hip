@@ -1539,7 +1539,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    uint32_t per_cu = GROOT_ALIGN_WAVES;
+    uint32_t per_cu = c->pw > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALIGN_WAVES;
     if (const char *e = getenv("GROOT_ALIGN_GRID_PER_CU")) per_cu = std::max(1, std::min(16, atoi(e)));   // experiments (tools/overlap_probe.py)
     c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, (uint32_t)std::max(n_cu, 1) * per_cu * kBlock);
     c->stk_depth = c->prm.max_read_len;

@@ -1022,8 +1022,11 @@ template <int PW> struct RecRegs {
 #ifndef GROOT_ALIGN_WAVES
 #define GROOT_ALIGN_WAVES 4   // 4 waves/SIMD = at most 128 VGPRs (5 or 6 spill and are slower; 3 hide too little latency)
 #endif
+#ifndef GROOT_ALIGN_WAVES_WIDE
+#define GROOT_ALIGN_WAVES_WIDE 3   // 704-bit path sets: at 4 waves (128 VGPRs) the kernel spills 260 bytes per lane and is 40 % slower (tools/wide_probe.py)
+#endif
 template <int PW, bool LDSR>
-__global__ __launch_bounds__(kBlock, GROOT_ALIGN_WAVES) void align_kernel(AlignArgs a)
+__global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALIGN_WAVES) void align_kernel(AlignArgs a)
 {
     using Rec = NodeRec<PW>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_reads[];
