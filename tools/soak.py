@@ -17,6 +17,7 @@ def main():
     import bench
     from groot_amd import synth
     from oracle import oracle_py as O
+    import test_gpu_parity as T
     from test_gpu_parity import assert_same, run_both
 
     index, _ = bench.load_index()
@@ -43,10 +44,13 @@ def main():
             reads.append(r.translate(comp)[::-1] if rng.integers(0, 2) else r)
         seq, off = O.pack_reads(reads)
         for t in (0.99, 0.95):
-            al, counts, run = run_both(index, seq, off, threshold=t)
-            assert_same(al, counts, run, index)
-            al.close()
-            print(f"seed {seed} t={t}: {counts['mapped']} mapped, {counts['alignments']} alignments, identical", flush=True)
+            for keep in (True, False):      # full-width sketch kernel alone / signature kernel in front of it
+                T.KEEP_SKETCHES = keep
+                al, counts, run = run_both(index, seq, off, threshold=t)
+                assert_same(al, counts, run, index)
+                al.close()
+                print(f"seed {seed} t={t} {'full-width' if keep else 'signature'}: {counts['mapped']} mapped, {counts['alignments']} alignments, "
+                      f"{counts['full_sketch_reads']} through the full-width kernel, identical", flush=True)
 
 
 if __name__ == "__main__":
