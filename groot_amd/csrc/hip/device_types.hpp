@@ -32,6 +32,8 @@ struct DeviceCounters {
     unsigned int q_rows;        // rows of the call-count table in use after this batch (may exceed its capacity: then kFlagQOverflow)
     unsigned int mask_words;    // 64-bit words of the compact path sets of this batch (mask_compact_kernel)
     unsigned int todo_reads;    // reads sketch_sig_kernel handed to the full-width kernel (0 when that kernel ran alone)
+    unsigned int seeded_reads;  // reads with at least one seed: the align stage's share of the processing order (they sort first)
+    unsigned int pad3;
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };
@@ -154,6 +156,7 @@ struct SeedArgs {
     uint32_t sort_span_bits;     // top bits of sort_key that hold min(contained nodes of the window, 2^bits-1); 0 = none
     ReadRec *read_rec;           // [n_reads]
     uint32_t *q_seen;            // [max_q + 1] set for every kmerCount of a seeded read that has no row yet; or null
+    uint32_t *trav_cnt;          // [n_reads] traversal counts of the align stage: zeroed here for reads without seeds (it skips them); or null
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]

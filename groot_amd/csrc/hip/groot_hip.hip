@@ -568,6 +568,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     a.sort_key = c->sort_key.p;
     a.read_rec = c->read_rec.p;
     a.q_seen = c->q_seen.p;
+    a.trav_cnt = c->trav_cnt.p;
     a.shards = c->seed_shards.p;
     a.ctr = s->d_ctr.p;
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely

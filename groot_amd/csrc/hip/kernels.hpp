@@ -171,7 +171,7 @@ struct SeedAhead {
 };
 
 // per-read bookkeeping every seed kernel ends with
-__device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t q, const uint32_t n_hits)
+__device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t r, const uint32_t q, const uint32_t n_hits)
 {
     const DeviceIndex &ix = a.ix;
     if (n_hits) {
@@ -181,11 +181,13 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
     // sum and maximum of n_hits over the lanes that are here together (ballots per level: reads have one or two seeds), then
     // one pair of atomics per wavefront, sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per
     // 10 M reads.  assign_q_rows_kernel folds the shards into the batch's counter block.
-    uint32_t total = 0, most = 0;
+    if (!n_hits && a.trav_cnt) a.trav_cnt[r] = 0;          // the align stage only walks the reads with seeds
+    uint32_t total = 0, most = 0, seeded = 0;
     for (uint32_t t = 1;; t++) {
         const unsigned long long b = __ballot(n_hits >= t);
         if (!b) break;
         total += (uint32_t)__popcll(b);
+        if (t == 1) seeded = total;
         most = t;
     }
     const unsigned long long here = __ballot(1);
@@ -193,6 +195,7 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
         unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
         atomicAdd(sh, (unsigned long long)total);
         atomicMax(sh + 1, (unsigned long long)most);
+        atomicAdd(sh + 2, (unsigned long long)seeded);
     }
 }
 
@@ -259,7 +262,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
         rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (high ? 0x80000000u : 0u));
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
-    seed_counters(a, q, n_hits);
+    seed_counters(a, r, q, n_hits);
 }
 
 // the same for a read known to be bases [o, o + WindowSize) of a window text row: its verdicts come from the table made at open
@@ -278,7 +281,7 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
         rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u));
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
-    seed_counters(a, q, n_hits);
+    seed_counters(a, r, q, n_hits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         a.seed_count[r] = 0;
         if (a.read_rec) { uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r); rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, 0); }
         if (a.sort_key) a.sort_key[r] = kEmpty;
+        if (a.trav_cnt) a.trav_cnt[r] = 0;
         return;
     }
     if (len > a.max_read_len) {
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         a.seed_count[r] = 0;
         if (a.read_rec) { uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r); rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, 0); }
         if (a.sort_key) a.sort_key[r] = kEmpty;
+        if (a.trav_cnt) a.trav_cnt[r] = 0;
         return;
     }
     // ---- KHF sketch (khf.go:35-55): per slot i, min over k-mers of MultiHash_i(canonical ntHash) ----
@@ -896,14 +901,16 @@ __global__ void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t
 {
     if (threadIdx.x || blockIdx.x) return;
     {   // the seed kernels' sharded counters -> this batch's counter block
-        unsigned long long seeds = 0, most = 0;
+        unsigned long long seeds = 0, most = 0, seeded = 0;
         for (uint32_t i = 0; i < kSeedShards; i++) {
             unsigned long long *sh = shards + (size_t)i * kSeedShardStride;
             seeds += sh[0];
             most = sh[1] > most ? sh[1] : most;
-            sh[0] = 0; sh[1] = 0;
+            seeded += sh[2];
+            sh[0] = 0; sh[1] = 0; sh[2] = 0;
         }
         ctr->seeds += seeds;
+        ctr->seeded_reads += (unsigned int)seeded;
         if (most > ctr->max_seeds) ctr->max_seeds = (unsigned int)most;
     }
     uint32_t need = *n_rows;
@@ -1057,8 +1064,12 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
     // round of them can take a quarter of the launch): cursor 0 hands those out one round at a time; once it has run past
     // them, cursor 1 hands out the rest kWaveChunk slots at a time.  (Only atomics touch the cursors: an atomic LOAD at
     // agent scope in this loop halves the kernel's speed.)
-    const uint32_t n_rounds = (a.n_reads + 63u) >> 6;
-    const uint32_t head_rounds = GROOT_SMALL_CHUNK_SHARE(n_rounds);
+    // reads without seeds sort last and have nothing to do here (the seed stage zeroed their traversal counts)
+    const uint32_t n_todo = a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads)) : a.n_reads;   // (scalar: it bounds every refill)
+    const uint32_t n_rounds = (n_todo + 63u) >> 6;
+    // (odd on purpose: with an even count the two-round chunks behind the head start at multiples of 128 slots and the kernel is
+    // 6 % slower -- measured both ways, cause not established)
+    const uint32_t head_rounds = GROOT_SMALL_CHUNK_SHARE(n_rounds) | 1u;
     uint32_t chunk_len = 0;                                // slots in the current chunk (wave-uniform)
     bool head_done = head_rounds == 0;                     // wave-uniform
     auto take_chunk = [&]() -> uint32_t {
@@ -1208,7 +1219,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 wc_round0 = wc_iter;
 #endif
                 const uint64_t base = (uint64_t)chunk_j * 64u;
-                if (base >= a.n_reads) {                       // this wave's share is used up
+                if (base >= n_todo) {                          // this wave's share is used up
                     if (phase == PH_WAIT) phase = PH_DONE;
                 } else {
                     const uint32_t room = chunk_len - chunk_pos;
@@ -1216,7 +1227,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
                         const uint64_t sl = base + chunk_pos + rank;
                         if (rank < room) {
-                            if (sl < a.n_reads) { slot = (uint32_t)sl; phase = PH_FETCH; GROOT_EV(20); }
+                            if (sl < n_todo) { slot = (uint32_t)sl; phase = PH_FETCH; GROOT_EV(20); }
                             else phase = PH_DONE;
                         }
                     }
