@@ -32,7 +32,7 @@ def main():
     out = {}
     for n_ctx in (1, 2):
         per = R // n_ctx
-        als = [device.Aligner(index, device=0, max_batch_reads=per, max_read_len=256, max_batch_bases=R * L + 64) for _ in range(n_ctx)]
+        als = [device.Aligner(index, device=0, max_batch_reads=per, max_read_len=256, max_batch_bases=R * L + 64, results_on_device=True) for _ in range(n_ctx)]
         res = [None] * n_ctx
         def work(i, steps, delay):
             time.sleep(delay)
