@@ -594,7 +594,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     }
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
-    hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(1), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
+    hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(64), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
                        c->max_q, s->d_ctr.p, c->seed_shards.p);
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low

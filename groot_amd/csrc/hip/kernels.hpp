@@ -896,34 +896,53 @@ __global__ __launch_bounds__(kBlock) void patch_reads_kernel(const uint64_t *__r
 // graphminion.go:60-67): rows are handed out in ascending kmerCount order within a batch, after the seed stage and before
 // the align stage.  More kmerCounts than rows: kFlagQOverflow, the align stage does nothing, the host grows the table
 // and re-runs the batch.
-__global__ void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t *q_of_row, uint32_t *n_rows, uint32_t cap, uint32_t max_q,
-                                     DeviceCounters *ctr, unsigned long long *shards)
+__global__ __launch_bounds__(64) void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t *q_of_row, uint32_t *n_rows, uint32_t cap,
+                                                            uint32_t max_q, DeviceCounters *ctr, unsigned long long *shards)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    {   // the seed kernels' sharded counters -> this batch's counter block
+    // one wavefront: lane i folds shard i of the seed kernels' counters, then the kmerCounts are taken 64 at a time
+    if (blockIdx.x) return;
+    const uint32_t lane = threadIdx.x;
+    {
         unsigned long long seeds = 0, most = 0, seeded = 0;
-        for (uint32_t i = 0; i < kSeedShards; i++) {
+        for (uint32_t i = lane; i < kSeedShards; i += 64) {
             unsigned long long *sh = shards + (size_t)i * kSeedShardStride;
             seeds += sh[0];
             most = sh[1] > most ? sh[1] : most;
             seeded += sh[2];
             sh[0] = 0; sh[1] = 0; sh[2] = 0;
         }
-        ctr->seeds += seeds;
-        ctr->seeded_reads += (unsigned int)seeded;
-        if (most > ctr->max_seeds) ctr->max_seeds = (unsigned int)most;
+        for (int o = 32; o; o >>= 1) {
+            seeds += __shfl_xor(seeds, o);
+            seeded += __shfl_xor(seeded, o);
+            const unsigned long long other = __shfl_xor(most, o);
+            most = other > most ? other : most;
+        }
+        if (!lane) {
+            ctr->seeds += seeds;
+            ctr->seeded_reads += (unsigned int)seeded;
+            if (most > ctr->max_seeds) ctr->max_seeds = (unsigned int)most;
+        }
     }
-    uint32_t need = *n_rows;
-    for (uint32_t q = 0; q <= max_q; q++) {
-        if (!q_seen[q]) continue;
-        q_seen[q] = 0;
-        if (q_row[q] != kEmpty) continue;
-        if (need < cap) { q_row[q] = need; q_of_row[need] = q; }
-        need++;
+    uint32_t need = *n_rows;                               // (every lane reads the same value; lane 0 writes it back at the end)
+    for (uint32_t q0 = 0; q0 <= max_q; q0 += 64) {
+        const uint32_t q = q0 + lane;
+        bool wants = false;
+        if (q <= max_q && q_seen[q]) {
+            q_seen[q] = 0;
+            wants = q_row[q] == kEmpty;
+        }
+        const unsigned long long b = __ballot(wants);       // rows are handed out in ascending kmerCount order
+        if (wants) {
+            const uint32_t row = need + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (row < cap) { q_row[q] = row; q_of_row[row] = q; }
+        }
+        need += (uint32_t)__popcll(b);
     }
-    if (need > cap) atomicOr(&ctr->flags, kFlagQOverflow);
-    *n_rows = min(need, cap);
-    ctr->q_rows = need;
+    if (!lane) {
+        if (need > cap) atomicOr(&ctr->flags, kFlagQOverflow);
+        *n_rows = min(need, cap);
+        ctr->q_rows = need;
+    }
 }
 
 // offsets of a batch whose reads all have the same length (then no length array travels): off[i] = i * len, i in [0, n]
