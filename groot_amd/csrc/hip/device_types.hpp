@@ -191,6 +191,7 @@ struct AlignArgs {
     uint64_t *stk_mask;          // [(d*n_threads + t)*pw + word]
     uint32_t n_threads, stk_depth;
     uint32_t lds_stride_dw;      // dwords of LDS per lane for the staged read (odd), 0 = reads stay in global memory
+    uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;
 };
 

@@ -73,6 +73,7 @@ struct Slot {
     uint64_t ticket = 0;
     uint32_t n_reads = 0, first_read_id = 0, max_len = 0;
     uint32_t uniform_len = 0;              // IN_PACKED16: every read has this length (0 = lengths differ): no length array on the wire
+    bool mixed_len = false;                // the reads are known to differ in length (the align stage then refills its wavefronts earlier)
     uint64_t n_bases = 0, n_exc = 0;
     enum Input { IN_ASCII, IN_PACKED, IN_PACKED16, IN_DEVICE } input = IN_ASCII;
     const uint8_t *ext_seq = nullptr;      // IN_DEVICE
@@ -645,6 +646,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         const uint32_t stride = (2 + 4 * ((s->max_len + 27) / 16)) | 1u;
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
+    a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
     launch_align(c->pw, a, dim3(blocks), c->stream);
@@ -1603,13 +1605,14 @@ static int take_slot(groot_ctx *c, uint32_t n_reads, Slot **out)
 }
 
 // offsets must start at 0 and not decrease; *max_len = the longest read (branch-free pass so that it vectorises: 10 M reads per batch)
-static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads, uint32_t *max_len)
+static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads, uint32_t *max_len, uint32_t *min_len = nullptr)
 {
     if (seq_off[0] != 0) return fail(c, GROOT_E_INVALID, "seq_off[0] must be 0");
-    uint64_t longest = 0, bad = 0;
+    uint64_t longest = 0, shortest = ~0ULL, bad = 0;
     for (uint32_t i = 0; i < n_reads; i++) {
         bad |= (uint64_t)(seq_off[i + 1] < seq_off[i]);
         longest = std::max(longest, seq_off[i + 1] - seq_off[i]);
+        shortest = std::min(shortest, seq_off[i + 1] - seq_off[i]);
     }
     if (bad) {
         uint32_t i = 0;
@@ -1619,6 +1622,7 @@ static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads
     if (seq_off[n_reads] > c->prm.max_batch_bases)
         return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)seq_off[n_reads], (unsigned long long)c->prm.max_batch_bases);
     *max_len = (uint32_t)std::min<uint64_t>(longest, 0xFFFFFFFFu);
+    if (min_len) *min_len = (uint32_t)std::min<uint64_t>(shortest, 0xFFFFFFFFu);
     return GROOT_OK;
 }
 
@@ -1646,12 +1650,13 @@ int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
 {
     if (!c) return GROOT_E_INVALID;
     if (n_reads && (!seq_concat || !seq_off)) return fail(c, GROOT_E_INVALID, "null read buffers");
-    uint32_t max_len = 0;
-    if (n_reads) { if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc; }
+    uint32_t max_len = 0, min_len = 0;
+    if (n_reads) { if (int rc = check_offsets(c, seq_off, n_reads, &max_len, &min_len)) return rc; }
     Slot *s = nullptr;
     if (int rc = take_slot(c, n_reads, &s)) return rc;
     if (int rc = ensure_slot(c, s, Slot::IN_ASCII, 0)) return rc;
     s->input = Slot::IN_ASCII; s->n_reads = n_reads; s->first_read_id = first_read_id;
+    s->mixed_len = min_len != max_len;
     s->n_bases = n_reads ? seq_off[n_reads] : 0; s->n_exc = 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     if (n_reads) {   // the caller's memory is not referenced after this call returns
@@ -1667,15 +1672,16 @@ int groot_hip_submit_packed(groot_ctx *c, const uint8_t *packed, const uint64_t 
     if (!c) return GROOT_E_INVALID;
     if (n_reads && (!packed || !seq_off)) return fail(c, GROOT_E_INVALID, "null read buffers");
     if (n_exc && (!exc_pos || !exc_byte)) return fail(c, GROOT_E_INVALID, "null exception list");
-    uint32_t max_len = 0;
+    uint32_t max_len = 0, min_len = 0;
     if (n_reads) {
-        if (int rc = check_offsets(c, seq_off, n_reads, &max_len)) return rc;
+        if (int rc = check_offsets(c, seq_off, n_reads, &max_len, &min_len)) return rc;
         if (int rc = check_exceptions(c, exc_pos, n_exc, seq_off[n_reads])) return rc;
     }
     Slot *s = nullptr;
     if (int rc = take_slot(c, n_reads, &s)) return rc;
     if (int rc = ensure_slot(c, s, Slot::IN_PACKED, n_exc)) return rc;
     s->input = Slot::IN_PACKED; s->n_reads = n_reads; s->first_read_id = first_read_id;
+    s->mixed_len = min_len != max_len;
     s->n_bases = n_reads ? seq_off[n_reads] : 0; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     if (n_reads) {
@@ -1705,6 +1711,7 @@ int groot_hip_submit_packed16(groot_ctx *c, const uint8_t *packed, const uint16_
     s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     s->uniform_len = n_reads && min_len == max_len ? max_len : 0;
+    s->mixed_len = n_reads && min_len != max_len;
     if (n_reads) {
         par_copy(s->h_bases.p, packed, (size_t)((total + 3) / 4));
         if (!s->uniform_len) par_copy(s->h_len.p, seq_len, (size_t)n_reads * sizeof(uint16_t));
@@ -1752,6 +1759,7 @@ int groot_hip_submit_acquired(groot_ctx *c, uint64_t ticket, uint32_t n_reads, u
     s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     s->uniform_len = n_reads && min_len == max_len ? max_len : 0;
+    s->mixed_len = n_reads && min_len != max_len;
     s->state = Slot::FREE;           // enqueue re-labels it
     return enqueue(c, s);
 }
@@ -1768,6 +1776,7 @@ int groot_hip_submit_device(groot_ctx *c, const void *d_seq, const void *d_seq_o
     s->input = Slot::IN_DEVICE; s->n_reads = n_reads; s->first_read_id = first_read_id; s->n_bases = 0; s->n_exc = 0;
     s->ext_seq = (const uint8_t *)d_seq; s->ext_off = (const uint64_t *)d_seq_off;
     s->max_len = max_len ? std::min(max_len, c->prm.max_read_len) : c->prm.max_read_len;
+    s->mixed_len = false;                  // (unknown: the offsets are on the device)
     return enqueue(c, s);
 }
 

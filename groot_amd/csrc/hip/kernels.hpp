@@ -367,12 +367,18 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         if (a.trav_cnt) a.trav_cnt[r] = 0;
         return;
     }
+    const uint32_t nk = len - k + 1;
+    if (!DUMP && a.ix.max_q && (nk > ix.max_q || ix.q_min_eq[nk] > (uint32_t)s_)) {
+        // more k-mers than Containment > t allows at any number of equal slots (reads well beyond the window size): the
+        // query cannot return a window, whatever the sketch is -- no hashing
+        seed_epilogue(a, r, o0, len, nk, 0, kEmpty, kEmpty, kEmpty, kEmpty, kEmpty, false);
+        return;
+    }
     // ---- KHF sketch (khf.go:35-55): per slot i, min over k-mers of MultiHash_i(canonical ntHash) ----
     uint64_t m[SM];
 #pragma unroll
     for (int i = 0; i < s_; i++) m[i] = ~0ULL;
     const uint64_t M = (uint64_t)k * GROOT_MULTI_SEED;
-    const uint32_t nk = len - k + 1;
     unsigned high = 0;                       // any byte > 'T': RevComplement would panic (seqio.go:126)
     auto sketch = [&](const unsigned char *rd) {
         uint64_t fh = 0, rh = 0;
@@ -685,8 +691,13 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     const uint64_t o0 = a.seq_off[r];
     const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
     const uint32_t q = len - k + 1;                        // kmerCount, boss.go:169
+    if (len >= k && len <= a.max_read_len && (q > ix.max_q || ix.q_min_eq[q] > (uint32_t)S)) {
+        // Containment > t is out of reach for this many k-mers: no seed, and nothing to hash
+        seed_epilogue(a, r, o0, len, q, 0, kEmpty, kEmpty, kEmpty, kEmpty, kEmpty, false);
+        return;
+    }
     bool fast = in_lds && len >= k && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
-    if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch, or nothing can be found
+    if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch
     if (fast) {
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
         for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
@@ -1229,7 +1240,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             // orientation class), so lanes that start together do near-identical work and share phases.
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
-            if (cw >= kRefill || (cw && !(bf | bs | bd))) {
+            if (cw >= (int)a.refill || (cw && !(bf | bs | bd))) {
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
                 if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
