@@ -101,6 +101,7 @@ struct DeviceIndex {
     const uint32_t *edges;          // only for nodes with more than 4 OutEdges (NodeRec embeds the rest)
     const uint8_t *bases;
     const uint32_t *win_graph, *cn_node;
+    const uint32_t *graph_win_end;  // [n_graphs] one past the last window of the graph (windows are numbered graph by graph); null if they are not
     const WinRec *win_rec;          // [n_windows]
     const uint64_t *win_sketch;     // [n_windows*s]
     // per window: which read prefixes (6-mer codes of oriented bases [0,6) and [6,12), 2 bits per base A=0 C=1 T=2 G=3)

@@ -121,6 +121,7 @@ struct groot_ctx {
     bool profiling = false;
 
     // index in HBM
+    DevBuf<uint32_t> graph_win_end;
     DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
         band_keys, band_ids;
     DevBuf<ExactEntry> band_hash;
@@ -1383,6 +1384,18 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
+    {   // windows are numbered graph by graph (canonical seed order): the last window of every graph
+        std::vector<uint32_t> end(v->n_graphs, 0);
+        bool grouped = true;
+        for (uint32_t w = 0; w < v->n_windows; w++) {
+            if (w && v->win_graph[w] < v->win_graph[w - 1]) grouped = false;
+            end[v->win_graph[w]] = w + 1;
+        }
+        if (grouped && v->n_graphs) {
+            HIP_TRY(c, upload(c->graph_win_end, end.data(), end.size()));
+            c->dix.graph_win_end = c->graph_win_end.p;
+        }
+    }
     {
         std::vector<uint8_t> gw(v->n_graphs, 1);
         for (uint32_t g = 0; g < v->n_graphs; g++) gw[g] = (uint8_t)std::max<uint32_t>(1, (v->graph_path_off[g + 1] - v->graph_path_off[g] + 63) / 64);

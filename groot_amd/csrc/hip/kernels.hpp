@@ -1553,7 +1553,12 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             if (backtrack) {
                 GROOT_EV(16);
                 if (sp == 0) {                                 // performAlignment is over
-                    if (emitted) { done_graph = g; phase = PH_FETCH; }   // alignment found for (read, graph)
+                    if (emitted) {                             // alignment found for (read, graph)
+                        done_graph = g; phase = PH_FETCH;
+                        // graphminion.go:96-98 passes over the graph's other seeds: they are the windows up to the graph's last one
+                        // (a read below the window size can bring a hundred of them: one FETCH step instead of one each)
+                        if (ix.graph_win_end) last = (long long)ix.graph_win_end[g] - 1;
+                    }
                     else phase = PH_SCAN;
                 } else {                                       // resume at the newest pending neighbour
                     GROOT_EV(17);
