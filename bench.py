@@ -119,7 +119,7 @@ def cpu_baseline(index_path, seconds):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def host_fed(index, d_seq, R, steps, depth=3):
+def host_fed(index, d_seq, R, steps, depth=4):
     """submit -> collect through pinned host memory, `depth` batches in flight in one ctx.  The packed batch is written
     into each slot's pinned staging once (a FASTQ parser's job in the CLI); the timed loop is acquire -> submit_acquired ->
     collect -> release, i.e. H2D of 27 B/read, the kernels, D2H of the traversal records."""
@@ -157,14 +157,14 @@ def host_fed(index, d_seq, R, steps, depth=3):
         al.submit_acquired(b["ticket"], R, len(exc_pos))
         if al.in_flight()[0] == depth:
             r = al.collect(copy=False)
-            trav_bytes += r["n_travs"] * 20 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4
+            trav_bytes += r["n_travs"] * 12 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
             for k, v in r["ms"].items():
                 stage[k] = stage.get(k, 0.0) + v
             al.release(r["ticket"])
             done += 1
     while done < steps:
         r = al.collect(copy=False)
-        trav_bytes += r["n_travs"] * 20 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4
+        trav_bytes += r["n_travs"] * 12 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
         for k, v in r["ms"].items():
             stage[k] = stage.get(k, 0.0) + v
         al.release(r["ticket"])
@@ -175,7 +175,7 @@ def host_fed(index, d_seq, R, steps, depth=3):
            "d2h_bytes_per_read": trav_bytes / (steps * R),
            "stage_ms_per_batch": {k: v / steps for k, v in stage.items()},
            "what": "one ctx, one index replica: pinned staging -> H2D (2-bit bases + u16 lengths) -> kernels -> D2H of the traversal "
-                   "records into pinned host memory; first submit -> last collect"}
+                   "records (12 bytes each, expanded to groot_trav by collect) into pinned host memory; first submit -> last collect"}
     # the plain-ASCII entry point with pageable caller memory (what a cgo caller handing over Go slices gets)
     off = np.arange(R + 1, dtype=np.uint64) * READ_LEN
     n_ascii = max(3, steps // 4)

@@ -78,6 +78,14 @@ constexpr uint32_t kRecCountMask = 0x00FFFFFFu;
 constexpr uint32_t kRecNo12F = 1u << 24, kRecNo3F = 1u << 25, kRecNo4F = 1u << 26;   // R = F << 3
 constexpr uint32_t kPrefixWords = 256;   // words per window in DeviceIndex::win_prefix
 
+// a traversal record on its way to the host: what cannot be derived there (graph = graph of the node, ord = position among
+// the read's records, read id = first_read_id + position in the batch)
+struct groot_ctrav {
+    uint32_t node, offset;
+    uint32_t read_flags;       // position of the read in the batch (24 bits) | GROOT_TRAV_* flags << 24
+};
+static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
+
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
 

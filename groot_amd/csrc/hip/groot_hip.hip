@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <deque>
 #include <memory>
 #include <numeric>
@@ -94,7 +95,9 @@ struct Slot {
     DevBuf<uint64_t> d_mask;
     DevBuf<DeviceCounters> d_ctr;
     PinBuf<DeviceCounters> h_ctr;
-    PinBuf<groot_trav> h_trav;
+    PinBuf<groot_trav> h_trav;                     // what collect hands out (expanded on the host from h_ctrav when the records travel packed)
+    DevBuf<groot_ctrav> d_ctrav;                   // 12-byte records for the copy-out
+    PinBuf<groot_ctrav> h_ctrav;
     PinBuf<uint64_t> h_mask;                       // COMPACT path sets: ceil(paths(graph) / 64) words per traversal
     PinBuf<uint32_t> h_ckpt;                       // offset into h_mask of every 256th traversal
     DevBuf<uint64_t> d_cmask;                      // the compact copy the copy-out takes (host-result mode)
@@ -145,6 +148,8 @@ struct groot_ctx {
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
     double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
     double words_per_trav = 0;             // compact path-set words per traversal, likewise (0 = not seen yet: path_words)
+    bool packed_travs = false;             // the copy-out sends 12-byte records (batches of at most 2^24 reads), collect expands them
+    std::vector<uint32_t> h_node_graph;    // graph of every node (the expansion)
     DevBuf<uint8_t> graph_words;           // ceil(paths / 64) per graph
     std::vector<uint8_t> h_graph_words;
     Slot *work_owner = nullptr;            // whose seeds / sketches the shared work buffers hold
@@ -522,6 +527,10 @@ static int alloc_trav(groot_ctx *c, Slot *s, uint32_t cap)
         HIP_TRY(c, s->d_mwords.alloc(cap));
         HIP_TRY(c, s->d_moff.alloc(cap));
         HIP_TRY(c, s->d_ckpt.alloc((size_t)cap / 256 + 2));
+        if (c->packed_travs) {
+            HIP_TRY(c, s->d_ctrav.alloc((size_t)cap + 2));
+            HIP_TRY(c, s->h_ctrav.alloc((size_t)cap + 2));
+        }
     }
     return GROOT_OK;
 }
@@ -688,6 +697,7 @@ static int launch_order_stage(groot_ctx *c, Slot *s)
         HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
         hipLaunchKernelGGL(mask_compact_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_mask.p, c->pw_view, s->d_ctr.p, s->trav_cap,
                            c->graph_words.p, (uint32_t)c->h_graph_words.size(), s->d_moff.p, s->d_cmask.p, s->d_ckpt.p);
+        if (c->packed_travs) hipLaunchKernelGGL(trav_pack_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_ctr.p, s->trav_cap, s->first_read_id, s->d_ctrav.p);
         HIP_TRY(c, hipGetLastError());
     }
     return GROOT_OK;
@@ -857,7 +867,8 @@ static int enqueue(groot_ctx *c, Slot *s)
         s->copied = (uint32_t)std::min<uint64_t>(predicted, s->trav_cap);
         const double wpt = c->words_per_trav > 0 ? c->words_per_trav : (double)c->pw_view;
         s->copied_words = std::min<uint64_t>((uint64_t)((double)s->copied * wpt * margin) + 1024, (uint64_t)s->trav_cap * c->pw_view);
-        HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->copied * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
+        if (c->packed_travs) HIP_TRY(c, hipMemcpyAsync(s->h_ctrav.p, s->d_ctrav.p, (size_t)s->copied * sizeof(groot_ctrav), hipMemcpyDeviceToHost, c->d2h_stream));
+        else HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->copied * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_cmask.p, (size_t)s->copied_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(c, hipMemcpyAsync(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->copied / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h_stream));
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h, c->d2h_stream));
@@ -867,6 +878,43 @@ static int enqueue(groot_ctx *c, Slot *s)
     s->state = Slot::IN_FLIGHT;
     c->inflight.push_back(s);
     return GROOT_OK;
+}
+
+// 12-byte records (read position | flags, node, offset) -> groot_trav: the graph is the node's, ord counts the records of a read
+static void expand_travs(const groot_ctx *c, Slot *s)
+{
+    const size_t n = s->n_trav;
+    const groot_ctrav *in = s->h_ctrav.p;
+    groot_trav *out = s->h_trav.p;
+    const uint32_t first = s->first_read_id;
+    const uint32_t *node_graph = c->h_node_graph.data();
+    auto span = [=](size_t lo, size_t hi) {
+        if (lo >= hi) return;
+        uint32_t ord = 0, prev = ~0u;
+        if (lo) {                                          // records of the same read before this span
+            prev = in[lo - 1].read_flags & 0x00FFFFFFu;
+            if ((in[lo].read_flags & 0x00FFFFFFu) == prev) {
+                size_t j = lo;
+                while (j > 0 && (in[j - 1].read_flags & 0x00FFFFFFu) == prev) j--;
+                ord = (uint32_t)(lo - j) - 1;              // ord of the record at lo - 1
+            }
+        }
+        for (size_t i = lo; i < hi; i++) {
+            const uint32_t pos = in[i].read_flags & 0x00FFFFFFu;
+            ord = pos == prev ? ord + 1 : 0;
+            prev = pos;
+            groot_trav t;
+            t.read_id = first + pos; t.graph_id = node_graph[in[i].node]; t.node = in[i].node; t.offset = in[i].offset;
+            t.ord = (uint16_t)ord; t.flags = (uint8_t)(in[i].read_flags >> 24); t.reserved = 0;
+            out[i] = t;
+        }
+    };
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / (1u << 18));   // (memory bound: 2-3 ms per 10 M records)
+    if (nt <= 1) { span(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(span, std::min(n, t * per), std::min(n, (t + 1) * per));
+    for (auto &x : th) x.join();
 }
 
 // The counters of slot s have arrived: grow-and-redo on overflow, then start the copy-out of its traversal records.
@@ -966,12 +1014,14 @@ static int finish_counters(groot_ctx *c, Slot *s)
         c->words_per_trav = (double)s->n_mask_words / (double)s->n_trav;
         const uint32_t have = redone ? 0 : std::min(s->copied, s->n_trav);      // a redo re-made the records: fetch them all
         if (have < s->n_trav) {
-            HIP_TRY(c, hipMemcpy(s->h_trav.p + have, s->d_trav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_trav), hipMemcpyDeviceToHost));
+            if (c->packed_travs) HIP_TRY(c, hipMemcpy(s->h_ctrav.p + have, s->d_ctrav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_ctrav), hipMemcpyDeviceToHost));
+            else HIP_TRY(c, hipMemcpy(s->h_trav.p + have, s->d_trav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_trav), hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->n_trav / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
         }
         const uint64_t have_w = redone ? 0 : std::min<uint64_t>(s->copied_words, s->n_mask_words);
         if (have_w < s->n_mask_words)
             HIP_TRY(c, hipMemcpy(s->h_mask.p + have_w, s->d_cmask.p + have_w, (size_t)(s->n_mask_words - have_w) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (c->packed_travs) expand_travs(c, s);
         s->host_results = true;
     }
     s->state = Slot::D2H_ISSUED;
@@ -1384,6 +1434,10 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
+    c->h_node_graph.resize(v->n_nodes);
+    for (uint32_t g = 0; g < v->n_graphs; g++)
+        for (uint32_t nd = v->graph_node_off[g]; nd < v->graph_node_off[g + 1]; nd++) c->h_node_graph[nd] = g;
+    c->packed_travs = !c->prm.results_on_device && c->prm.max_batch_reads <= (1u << 24) && !getenv("GROOT_WIDE_COPYOUT");
     {   // windows are numbered graph by graph (canonical seed order): the last window of every graph
         std::vector<uint32_t> end(v->n_graphs, 0);
         bool grouped = true;

@@ -1631,6 +1631,16 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
     }
 }
 
+// ordered traversal records -> the 12-byte form the copy-out sends (20 B -> 12 B per record over PCIe)
+__global__ __launch_bounds__(kBlock) void trav_pack_kernel(const groot_trav *__restrict__ in, const DeviceCounters *__restrict__ ctr, uint32_t cap,
+                                                           uint32_t first_read_id, groot_ctrav *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap || i >= ctr->n_trav) return;
+    const groot_trav t = in[i];
+    out[i] = groot_ctrav{t.node, t.offset, ((t.read_id - first_read_id) & 0x00FFFFFFu) | ((uint32_t)t.flags << 24)};
+}
+
 // dst += src over n uint32 (call-count tables of ctxs that share a device, groot_hip_attempts_allreduce)
 __global__ __launch_bounds__(kBlock) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
 {
