@@ -559,14 +559,17 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
 // set is decided without ever forming the 64-bit minima:
 //  * MultiHash mixes with t ^= t >> 27, which leaves the top 27 bits of t alone, and truncation is monotone, so
 //    top27(min_j mix(t_j)) = min_j top27(t_j) = (min_j hi32(h_j * c_i)) >> 5: a running 32-bit minimum of the raw product's
-//    high word gives the top 27 bits of every slot EXACTLY -- two instructions per (k-mer, slot) (64-bit add, v_min_u32)
-//    instead of seven (add, shift, 2 xor, 64-bit compare, 2 selects);
+//    high word gives the top 27 bits of every slot EXACTLY -- a 64-bit add and half a v_min3_u32 per (k-mer, slot) (the
+//    compiler pairs two k-mers) instead of seven instructions (add, shift, 2 xor, 64-bit compare, 2 selects);
 //  * a window can only equal the read's sketch if its signature (those 27 bits of all S slots) does: the signature table
 //    holds every window; no entry -> no seed, rigorously;
 //  * an entry is confirmed by TEXT: the window's sketch is the sketch of every WindowSize-mer of the bases it was merged
 //    from (graph.go:293-333; re-sketched and compared with Key.Sketch when the ctx is opened), so a read that equals one
-//    of them, or its reverse complement (canonical k-mer hashes), has exactly that sketch.  Its seeds are then all windows
-//    of the same sketch class, in table order = ascending window id, as the exact table would have returned them;
+//    of them, or its reverse complement (canonical k-mer hashes), has exactly that sketch.  Where in the text to compare is
+//    known from the read's smallest k-mer (its position in each text row is in the table entry).  Its seeds are then all
+//    windows of the same sketch class, in table order = ascending window id, as the exact table would have returned them;
+//  * for a confirmed window-sized read the epilogue's verdicts come from DeviceIndex::sig_verdict -- the full-width seed
+//    stage was run on every WindowSize-mer of every text at open;
 //  * everything else -- a signature found but no text equal (reads with errors that keep all minimisers, windows merged
 //    from another path), bytes other than ACGT (their 2-bit codes say nothing), other lengths / thresholds (LSH-Forest
 //    branch), spans too long for the LDS -- goes onto a list and through sketch_seed_kernel<..., LIST> unchanged.

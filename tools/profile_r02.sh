@@ -15,7 +15,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -o c -- python bench.py $ARGS > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -o c -- python bench.py $ARGS > gpurun_out/prof_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $P/tcc -o c -- python bench.py $ARGS > gpurun_out/prof_tcc.log 2>&1
-READS=10000000 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $P/hf -o t -- python tools/host_fed_probe.py 12 3 > gpurun_out/prof_hf.log 2>&1
+READS=10000000 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $P/hf -o t -- python tools/host_fed_probe.py 12 4 > gpurun_out/prof_hf.log 2>&1
 python - <<'PY'
 import csv, glob, json, collections, os
 P = "/tmp/prof"
@@ -32,7 +32,7 @@ def stats(pattern, dest, note):
             w.writerow([r["Name"].split("(")[0][:90]] + [r[k] for k in list(r.keys())[1:]])
         w.writerow(["# " + note, "", sum(int(r["TotalDurationNs"]) for r in rows)])
 stats(P + "/trace/**/*kernel_stats.csv", "profiles/r02_kernel_stats.csv", "total of all kernels in the process (incl. torch input generation)")
-stats(P + "/hf/**/*kernel_stats.csv", "profiles/r02_host_fed_kernel_stats.csv", "host-fed leg (tools/host_fed_probe.py 12 3): total of all kernels in the process")
+stats(P + "/hf/**/*kernel_stats.csv", "profiles/r02_host_fed_kernel_stats.csv", "host-fed leg (tools/host_fed_probe.py 12 4): total of all kernels in the process")
 for f in glob.glob(P + "/hf/**/*memory_copy_stats.csv", recursive=True):
     os.replace(f, "profiles/r02_host_fed_memory_copy_stats.csv")
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
