@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <memory>
@@ -1136,55 +1137,30 @@ void groot_hip_close(groot_ctx *ctx)
 // ---------------------------------------------------------------------------------------------
 // sketch_sig_kernel's side of the index: window texts, proven against Key.Sketch, and the signature table
 // ---------------------------------------------------------------------------------------------
-// KHF sketches of n sequences of `len` bases each (concatenated), through the full-width kernel
-static int sketch_uniform(groot_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t len, uint64_t *out)
+// n WindowSize-mers of window texts (concatenated; owner[j] = their window) through the full-width kernel twice on one upload:
+// sketches (compared with Key.Sketch on the device: differs[j]) and the whole seed stage (per read the record's cnt_flags word and the scheduling key without
+// span bits: first seed window << 2 | dead-orientation class)
+static int text_pass(groot_ctx *c, const uint8_t *seqs, const uint32_t *owner, uint32_t n, uint32_t len, uint8_t *differs, uint32_t *cnt_flags,
+                     uint32_t *keys)
 {
-    DevBuf<uint64_t> sk, off;
-    DevBuf<uint8_t> seq;
+    DevBuf<uint64_t> off, sk;
+    DevBuf<uint8_t> seq, bad;
     DevBuf<DeviceCounters> ctr;
-    DevBuf<uint32_t> cnt;
-    const uint64_t total = (uint64_t)n * len;
-    HIP_TRY(c, sk.alloc((size_t)n * c->s));
-    HIP_TRY(c, off.alloc((size_t)n + 1));
-    HIP_TRY(c, seq.alloc(total + 64));
-    HIP_TRY(c, ctr.alloc(1));
-    HIP_TRY(c, cnt.alloc(n));
-    HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->stream));
-    const dim3 grid((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->stream, off.p, n, len);
-    SeedArgs a{};
-    a.ix = c->dix;
-    a.ix.max_q = 0;   // no lookup: every read gets min_eq = S+1
-    a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, c->prm.max_read_len);
-    a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * len + 32, kMaxLdsReadBytes);
-    a.seed_slots = 0; a.seed_count = cnt.p; a.seed_win = nullptr;
-    a.sketch_out = sk.p; a.ctr = ctr.p; a.shards = c->seed_shards.p;
-    launch_seed(c->s, c->max_k, a, true, grid, kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(out, sk.p, (size_t)n * c->s * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return GROOT_OK;
-}
-
-// the full-width seed stage (lookups, verdicts, scheduling class) over n sequences of `len` bases: per read the record's
-// cnt_flags word and the scheduling key without span bits (first seed window << 2 | dead-orientation class)
-static int seed_uniform(groot_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t len, uint32_t *cnt_flags, uint32_t *keys)
-{
-    DevBuf<uint64_t> off;
-    DevBuf<uint8_t> seq;
-    DevBuf<DeviceCounters> ctr;
-    DevBuf<uint32_t> cnt, win, key;
+    DevBuf<uint32_t> cnt, win, key, own;
     DevBuf<ReadRec> rec;
     const uint64_t total = (uint64_t)n * len;
     HIP_TRY(c, off.alloc((size_t)n + 1));
+    HIP_TRY(c, sk.alloc((size_t)n * c->s));
     HIP_TRY(c, seq.alloc(total + 64));
+    HIP_TRY(c, bad.alloc(n));
     HIP_TRY(c, ctr.alloc(1));
     HIP_TRY(c, cnt.alloc(n));
+    HIP_TRY(c, own.alloc(n));
     HIP_TRY(c, win.alloc((size_t)c->seed_slots * n));
     HIP_TRY(c, key.alloc(n));
     HIP_TRY(c, rec.alloc(n));
     HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(own.p, owner, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->stream));
     const dim3 grid((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->stream, off.p, n, len);
@@ -1193,13 +1169,19 @@ static int seed_uniform(groot_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t 
     a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, c->prm.max_read_len);
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * len + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = cnt.p; a.seed_win = win.p;
-    a.sort_key = key.p; a.sort_span_bits = 0; a.read_rec = rec.p;
     a.ctr = ctr.p; a.shards = c->seed_shards.p;
-    launch_seed(c->s, c->max_k, a, false, grid, kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
+    const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
+    SeedArgs d = a;                                         // sketches only: no lookup
+    d.ix.max_q = 0; d.sketch_out = sk.p;
+    launch_seed(c->s, c->max_k, d, true, grid, lds, c->stream);
+    hipLaunchKernelGGL(sketch_equal_kernel, grid, dim3(kBlock), 0, c->stream, sk.p, own.p, c->win_sketch.p, c->s, n, bad.p);
+    a.sort_key = key.p; a.sort_span_bits = 0; a.read_rec = rec.p;
+    launch_seed(c->s, c->max_k, a, false, grid, lds, c->stream);
     HIP_TRY(c, hipGetLastError());
     std::vector<ReadRec> h(n);
     HIP_TRY(c, hipMemcpyAsync(h.data(), rec.p, (size_t)n * sizeof(ReadRec), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(keys, key.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(differs, bad.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));   // (nobody folds them here)
     for (uint32_t i = 0; i < n; i++) cnt_flags[i] = h[i].cnt_flags;
@@ -1210,6 +1192,14 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
 {
     const uint32_t n = v->n_windows, s = v->sketch_size, w = v->window_size, k = v->kmer_size;
     if (getenv("GROOT_NO_SIG") || !sig_supported(s, v->max_k, k) || w > kTextMax || w < k || !n) return GROOT_OK;
+    const bool open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!open_stats) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[groot open]   sig: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     // 1. the bases every window was sketched from: WindowSize + MergeSpan of them along its first Ref path, starting at
     //    (Key.Node, Key.OffSet) -- WindowGraph walks a path through the graph's nodes in order (graph.go:243-262) and merges
     //    consecutive windows of equal sketch into the first one (:293-333).  Texts stop at a base other than ACGT.
@@ -1250,20 +1240,27 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
             });
         for (auto &x : th) x.join();
     }
-    // 2. proof: every WindowSize-mer of both rows must reproduce Key.Sketch through the full-width kernel; a window
-    //    whose text does not is left without one (its reads take the full-width kernel)
+    lap("texts");
+    // 2. proof and verdicts, one pass: every WindowSize-mer of both rows must reproduce Key.Sketch through the full-width kernel
+    //    (a window whose text does not is left without one: its reads take the full-width kernel), and what the full-width
+    //    seed stage's epilogue says about the same strings (the reads the signature kernel confirms ARE these strings) --
+    //    verdict bits and dead-orientation class, one byte each.  A text whose own bases do not come back with a seed is dropped.
+    const uint32_t vstride = kTextMax - w + 1;
+    std::vector<uint8_t> verdict((size_t)n * 2 * vstride + 16, 0);
     {
         const uint32_t chunk = 1u << 20;
-        std::vector<uint8_t> seqs;
-        std::vector<uint32_t> owner;
-        std::vector<uint64_t> sk;
+        std::vector<uint8_t> seqs, differs;
+        std::vector<uint32_t> owner, flags, keys;
+        std::vector<size_t> where;
         auto flush = [&]() -> int {
             if (owner.empty()) return GROOT_OK;
-            sk.resize(owner.size() * (size_t)s);
-            if (int rc = sketch_uniform(c, seqs.data(), (uint32_t)owner.size(), w, sk.data())) return rc;
-            for (size_t j = 0; j < owner.size(); j++)
-                if (memcmp(&sk[j * s], v->win_sketch + (size_t)owner[j] * s, (size_t)s * 8)) tlen[owner[j]] = 0;
-            seqs.clear(); owner.clear();
+            flags.resize(owner.size()); keys.resize(owner.size()); differs.resize(owner.size());
+            if (int rc = text_pass(c, seqs.data(), owner.data(), (uint32_t)owner.size(), w, differs.data(), flags.data(), keys.data())) return rc;
+            for (size_t j = 0; j < owner.size(); j++) {
+                if (differs[j] || !(flags[j] & kRecCountMask) || keys[j] == kEmpty) { tlen[owner[j]] = 0; continue; }
+                verdict[where[j]] = (uint8_t)(((flags[j] >> 24) & 0x3Fu) | ((keys[j] & 3u) << 6));
+            }
+            seqs.clear(); owner.clear(); where.clear();
             return GROOT_OK;
         };
         for (uint32_t i = 0; i < n; i++) {
@@ -1273,6 +1270,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
                     const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax + o];
                     seqs.insert(seqs.end(), src, src + w);
                     owner.push_back(i);
+                    where.push_back(((size_t)i * 2 + row) * vstride + o);
                 }
             if (owner.size() >= chunk)
                 if (int rc = flush()) return rc;
@@ -1281,6 +1279,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
         for (uint32_t i = 0; i < n; i++)
             if (!tlen[i]) memset(&text[(size_t)i * 2 * kTextMax], 0, 2 * kTextMax);
     }
+    lap("proof + verdicts");
     // 3. where the smallest k-mer of every text row is (first occurrence), and the rows at 2 bits per base
     std::vector<uint8_t> argmin((size_t)n * 2, 0);
     {
@@ -1301,46 +1300,12 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
             uint8_t *dst = &packed[((size_t)i * 2 + row) * (kTextMax / 4)];
             for (uint32_t j = 0; j < tlen[i]; j++) dst[j >> 2] |= (uint8_t)(((src[j] >> 1) & 3u) << (2 * (j & 3)));
         }
-    // 4. what the full-width seed stage's epilogue says about every WindowSize-mer of the texts (the reads the signature kernel
-    //    confirms ARE these strings): verdict bits and dead-orientation class, one byte each.  A text whose own bases do not
-    //    come back with a seed is dropped.
-    const uint32_t vstride = kTextMax - w + 1;
-    std::vector<uint8_t> verdict((size_t)n * 2 * vstride + 16, 0);
-    {
-        const uint32_t chunk = 1u << 20;
-        std::vector<uint8_t> seqs;
-        std::vector<uint32_t> owner, flags, keys;
-        std::vector<size_t> where;
-        auto flush = [&]() -> int {
-            if (owner.empty()) return GROOT_OK;
-            flags.resize(owner.size()); keys.resize(owner.size());
-            if (int rc = seed_uniform(c, seqs.data(), (uint32_t)owner.size(), w, flags.data(), keys.data())) return rc;
-            for (size_t j = 0; j < owner.size(); j++) {
-                if (!(flags[j] & kRecCountMask) || keys[j] == kEmpty) { tlen[owner[j]] = 0; continue; }
-                verdict[where[j]] = (uint8_t)(((flags[j] >> 24) & 0x3Fu) | ((keys[j] & 3u) << 6));
-            }
-            seqs.clear(); owner.clear(); where.clear();
-            return GROOT_OK;
-        };
-        for (uint32_t i = 0; i < n; i++) {
-            if (!tlen[i]) continue;
-            for (uint32_t row = 0; row < 2; row++)
-                for (uint32_t o = 0; o + w <= tlen[i]; o++) {
-                    const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax + o];
-                    seqs.insert(seqs.end(), src, src + w);
-                    owner.push_back(i);
-                    where.push_back(((size_t)i * 2 + row) * vstride + o);
-                }
-            if (owner.size() >= chunk)
-                if (int rc = flush()) return rc;
-        }
-        if (int rc = flush()) return rc;
-    }
     c->sig_disabled = 0;
     for (uint32_t i = 0; i < n; i++) c->sig_disabled += tlen[i] == 0;
     std::vector<uint8_t> nodes(n);
     for (uint32_t i = 0; i < n; i++) nodes[i] = (uint8_t)std::min<uint32_t>(255, v->win_cn_off[i + 1] - v->win_cn_off[i]);
-    // 5. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
+    lap("argmin + packing");
+    // 4. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
     uint32_t cap = 16;
     while (cap < 2 * (uint64_t)n) cap <<= 1;
     std::vector<SigEntry> tab(cap, SigEntry{0, kEmpty, 0, 0});
@@ -1359,6 +1324,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     c->dix.sig_verdict = getenv("GROOT_NO_SIG_VERDICTS") ? nullptr : c->sig_verdict.p;
     c->dix.sig_verdict_stride = vstride;
     c->dix.win_nodes = c->win_nodes.p;
+    lap("tables + uploads");
     c->dix.sig = c->sig.p;
     c->dix.sig_mask = cap - 1;
     c->dix.win_text = c->win_text.p;
@@ -1410,6 +1376,16 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         c->slots.push_back(std::move(s));
     }
 
+    const bool open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
+    auto t_open = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!open_stats) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[groot open] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_open).count());
+        t_open = now;
+    };
+    lap("device + streams");
     // ---- graphs + windows -> HBM ----
     HIP_TRY(c, upload(c->edges, v->edges, v->n_edges));
     HIP_TRY(c, upload(c->bases, v->bases, v->n_bases, 64));   // kernels read 8-byte windows up to 24 bytes past a node start
@@ -1433,6 +1409,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         for (auto &x : th) x.join();
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
+    lap("node records + prefix tables");
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));
     c->h_node_graph.resize(v->n_nodes);
     for (uint32_t g = 0; g < v->n_graphs; g++)
@@ -1470,6 +1447,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, upload(c->cn_node, v->cn_node, v->n_cn));
     HIP_TRY(c, upload(c->win_sketch, v->win_sketch, (size_t)v->n_windows * v->sketch_size, 2));
 
+    lap("window arrays");
     // ---- lookup structures (the reference bootstraps its LSH forests at load too, lshe.go:95-147) ----
     const uint32_t n = v->n_windows, s = v->sketch_size;
     std::vector<uint32_t> sketch_class(n);   // smallest window id with the same 64-bit sketch
@@ -1491,10 +1469,22 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->exact, tab.data(), tab.size()));
         c->dix.exact_mask = cap - 1;
     }
+    lap("exact table");
     {   // LSH forest band tables: per band the low-32 hash values of its max_k slots, sorted
         const uint32_t mk = v->max_k, lmax = c->l_max;
-        std::vector<uint32_t> keys((size_t)lmax * n * mk), ids((size_t)lmax * n), order(n);
-        for (uint32_t b = 0; b < lmax; b++) {
+        std::vector<uint32_t> keys((size_t)lmax * n * mk), ids((size_t)lmax * n);
+        // hash tables over the distinct K-prefixes of every band: the query finds the first matching row with one or two
+        // probes instead of a binary search of ~log2(n) dependent loads
+        uint32_t bits = 4;
+        while ((1ull << bits) < 2 * (uint64_t)n) bits++;
+        c->band_hash_bits = bits;
+        const uint32_t cap = 1u << bits;
+        std::vector<ExactEntry> tab((size_t)lmax * mk * cap, ExactEntry{0, kEmpty});
+        std::vector<uint8_t> sig((size_t)lmax * n * 32, 0);
+        std::vector<uint32_t> run((size_t)lmax * mk * n, 0);
+        const uint32_t sl = std::min<uint32_t>(s, 32);
+        auto band = [&](uint32_t b) {                            // the bands are independent: one thread each
+            std::vector<uint32_t> order(n);
             std::iota(order.begin(), order.end(), 0u);
             const uint64_t *sk = v->win_sketch;
             std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
@@ -1509,17 +1499,6 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                 for (uint32_t j = 0; j < mk; j++)
                     keys[((size_t)b * n + e) * mk + j] = (uint32_t)sk[(size_t)order[e] * s + b * mk + j];
             }
-        }
-        HIP_TRY(c, upload(c->band_keys, keys.data(), keys.size()));
-        HIP_TRY(c, upload(c->band_ids, ids.data(), ids.size()));
-        // hash tables over the distinct K-prefixes of every band: the query finds the first matching row with one or two
-        // probes instead of a binary search of ~log2(n) dependent loads
-        uint32_t bits = 4;
-        while ((1ull << bits) < 2 * (uint64_t)n) bits++;
-        c->band_hash_bits = bits;
-        const uint32_t cap = 1u << bits;
-        std::vector<ExactEntry> tab((size_t)lmax * mk * cap, ExactEntry{0, kEmpty});
-        for (uint32_t b = 0; b < lmax; b++)
             for (uint32_t K = 1; K <= mk; K++) {
                 ExactEntry *t = tab.data() + (((size_t)b * mk + (K - 1)) << bits);
                 for (uint32_t e = 0; e < n; e++) {
@@ -1532,18 +1511,11 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                     t[slot] = ExactEntry{(uint32_t)(h >> 32), e};
                 }
             }
-        HIP_TRY(c, upload(c->band_hash, tab.data(), tab.size()));
-        std::vector<uint8_t> sig((size_t)lmax * n * 32, 0);
-        const uint32_t sl = std::min<uint32_t>(s, 32);
-        for (uint32_t b = 0; b < lmax; b++)
             for (uint32_t e = 0; e < n; e++) {
                 const uint64_t *ws = v->win_sketch + (size_t)ids[(size_t)b * n + e] * s;
                 uint8_t *row = &sig[((size_t)b * n + e) * 32];
                 for (uint32_t i = 0; i < sl; i++) row[i] = (uint8_t)sig8(ws[i]);
             }
-        HIP_TRY(c, upload(c->band_sig, sig.data(), sig.size(), 32));
-        std::vector<uint32_t> run((size_t)lmax * mk * n, 0);
-        for (uint32_t b = 0; b < lmax; b++)
             for (uint32_t K = 1; K <= mk; K++) {
                 uint32_t *rn = run.data() + ((size_t)b * mk + (K - 1)) * n;
                 for (uint32_t e = n; e-- > 0;) {             // backwards: length of the run of equal K-prefixes starting at e
@@ -1551,8 +1523,22 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                     rn[e] = (e + 1 < n && std::equal(ke, ke + K, ke + mk)) ? rn[e + 1] + 1 : 1;
                 }
             }
+        };
+        {
+            std::atomic<uint32_t> next{0};
+            std::vector<std::thread> th;
+            const uint32_t workers = std::min<uint32_t>(lmax, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+            for (uint32_t t = 0; t < workers; t++)
+                th.emplace_back([&]() { for (uint32_t b; (b = next.fetch_add(1)) < lmax;) band(b); });
+            for (auto &x : th) x.join();
+        }
+        HIP_TRY(c, upload(c->band_keys, keys.data(), keys.size()));
+        HIP_TRY(c, upload(c->band_ids, ids.data(), ids.size()));
+        HIP_TRY(c, upload(c->band_hash, tab.data(), tab.size()));
+        HIP_TRY(c, upload(c->band_sig, sig.data(), sig.size(), 32));
         HIP_TRY(c, upload(c->band_run, run.data(), run.size()));
     }
+    lap("LSH forest tables");
     {   // per kmerCount: (K, L) of the partitions (all have Upper = NumWindowKmers) and min #equal slots
         std::vector<uint8_t> qk(c->max_q + 1, 0), ql(c->max_q + 1, 0);
         std::vector<uint16_t> qm(c->max_q + 1, (uint16_t)(s + 1));
@@ -1586,6 +1572,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     x.max_k = v->max_k; x.l_max = c->l_max; x.q_k = c->q_k.p; x.q_l = c->q_l.p; x.q_min_eq = c->q_min_eq.p; x.max_q = c->max_q;
     x.q_row = c->q_row.p;
 
+    lap("per-kmerCount tables");
     // ---- shared work buffers (inputs / outputs are per pipeline slot, allocated at their first use) ----
     const uint32_t R = c->prm.max_batch_reads;
     HIP_TRY(c, c->seed_count.alloc(R));
@@ -1620,7 +1607,9 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->seed_shards.alloc((size_t)kSeedShards * kSeedShardStride));
     HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));
     HIP_TRY(c, hipDeviceSynchronize());
+    lap("work buffers");
     if (int rc = build_signature_index(c, v, sketch_class)) return rc;
+    lap("signature index");
     return GROOT_OK;
 }
 

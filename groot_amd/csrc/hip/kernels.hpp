@@ -614,6 +614,18 @@ __device__ __forceinline__ void todo_push(const SeedArgs &a, uint32_t r)
     a.todo_list[base + __popcll(active & ((1ULL << lane) - 1ULL))] = r;
 }
 
+// does sketch j (s words) equal the sketch of window owner[j]?  (the proof of the window texts, groot_hip_open)
+__global__ __launch_bounds__(kBlock) void sketch_equal_kernel(const uint64_t *__restrict__ sk, const uint32_t *__restrict__ owner,
+                                                              const uint64_t *__restrict__ win_sketch, uint32_t s, uint32_t n, uint8_t *__restrict__ differs)
+{
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t *a = sk + (size_t)j * s, *b = win_sketch + (size_t)owner[j] * s;
+    uint64_t d = 0;
+    for (uint32_t i = 0; i < s; i++) d |= a[i] ^ b[i];
+    differs[j] = d != 0;
+}
+
 // first position of the smallest canonical ntHash among the k-mers of every window text row (ASCII, kTextMax bytes per
 // row, two rows per window): sketch_sig_kernel finds where a read lies inside a text from where its own smallest k-mer is
 __global__ __launch_bounds__(kBlock) void text_argmin_kernel(const uint8_t *__restrict__ text, const uint32_t *__restrict__ text_len, uint32_t n_rows,
