@@ -76,6 +76,8 @@ struct Slot {
     uint32_t n_reads = 0, first_read_id = 0, max_len = 0;
     uint32_t uniform_len = 0;              // IN_PACKED16: every read has this length (0 = lengths differ): no length array on the wire
     bool mixed_len = false;                // the reads are known to differ in length (the align stage then refills its wavefronts earlier)
+    bool sig_used = false;                 // the signature kernel ran in front of the full-width kernel for this batch
+    bool one_len = false;                  // the reads are known to have max_len bases each, or the caller said so (submit_device with max_len)
     uint64_t n_bases = 0, n_exc = 0;
     enum Input { IN_ASCII, IN_PACKED, IN_PACKED16, IN_DEVICE } input = IN_ASCII;
     const uint8_t *ext_seq = nullptr;      // IN_DEVICE
@@ -139,6 +141,7 @@ struct groot_ctx {
     DevBuf<ExactEntry> exact;
     DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature table + window texts (absent: that kernel is not used)
     DevBuf<uint8_t> win_text, sig_verdict, win_nodes;
+    std::vector<uint16_t> h_q_min_eq;      // host copy of DeviceIndex::q_min_eq: which seed kernel a batch of one read length gets
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
 
@@ -591,7 +594,15 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
-    if (c->dix.sig && !c->prm.keep_sketches) {
+    // a batch of one read length that is not on the exact-table branch (lower thresholds, reads shorter than the windows) would
+    // send every read through the list: the full-width kernel alone is 25-30 % faster then (tools/threshold_probe.py)
+    bool sig_useful = true;
+    if (s->one_len && s->max_len >= c->k) {
+        const uint32_t q = s->max_len - c->k + 1;
+        sig_useful = q < c->h_q_min_eq.size() && c->h_q_min_eq[q] == c->s;
+    }
+    s->sig_used = c->dix.sig && !c->prm.keep_sketches && sig_useful;
+    if (s->sig_used) {
         // signature kernel first; what it cannot decide goes through the full-width kernel, read by read
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
@@ -977,7 +988,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
     o.received = s->n_reads;              // boss.go:194 receivedReads++ for every read
     o.mapped = h.mapped; o.multimapped = h.multimapped; o.alignments = h.alignments; o.seeds = h.seeds;
     o.travs = s->n_trav; o.revcomp_panics = h.revcomp_panics; o.short_reads = h.short_reads;
-    o.full_sketch_reads = c->dix.sig && !c->prm.keep_sketches ? h.todo_reads : s->n_reads;
+    o.full_sketch_reads = s->sig_used ? h.todo_reads : s->n_reads;
     if (s->status == GROOT_OK) {
         char buf[256];
         if (h.flags & kFlagLongRead) { s->status = GROOT_E_NOSPACE; snprintf(buf, sizeof buf, "a read is longer than max_read_len=%u", c->prm.max_read_len); s->status_msg = buf; }
@@ -1551,6 +1562,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->q_k, qk.data(), qk.size()));
         HIP_TRY(c, upload(c->q_l, ql.data(), ql.size()));
         HIP_TRY(c, upload(c->q_min_eq, qm.data(), qm.size()));
+        c->h_q_min_eq = qm;
     }
     {   // call-count table: rows appear as kmerCounts do
         std::vector<uint32_t> none(c->max_q + 2, kEmpty);
@@ -1712,7 +1724,7 @@ int groot_hip_submit(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     if (int rc = take_slot(c, n_reads, &s)) return rc;
     if (int rc = ensure_slot(c, s, Slot::IN_ASCII, 0)) return rc;
     s->input = Slot::IN_ASCII; s->n_reads = n_reads; s->first_read_id = first_read_id;
-    s->mixed_len = min_len != max_len;
+    s->mixed_len = min_len != max_len; s->one_len = n_reads && min_len == max_len;
     s->n_bases = n_reads ? seq_off[n_reads] : 0; s->n_exc = 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     if (n_reads) {   // the caller's memory is not referenced after this call returns
@@ -1737,7 +1749,7 @@ int groot_hip_submit_packed(groot_ctx *c, const uint8_t *packed, const uint64_t 
     if (int rc = take_slot(c, n_reads, &s)) return rc;
     if (int rc = ensure_slot(c, s, Slot::IN_PACKED, n_exc)) return rc;
     s->input = Slot::IN_PACKED; s->n_reads = n_reads; s->first_read_id = first_read_id;
-    s->mixed_len = min_len != max_len;
+    s->mixed_len = min_len != max_len; s->one_len = n_reads && min_len == max_len;
     s->n_bases = n_reads ? seq_off[n_reads] : 0; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     if (n_reads) {
@@ -1767,7 +1779,7 @@ int groot_hip_submit_packed16(groot_ctx *c, const uint8_t *packed, const uint16_
     s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     s->uniform_len = n_reads && min_len == max_len ? max_len : 0;
-    s->mixed_len = n_reads && min_len != max_len;
+    s->mixed_len = n_reads && min_len != max_len; s->one_len = n_reads && min_len == max_len;
     if (n_reads) {
         par_copy(s->h_bases.p, packed, (size_t)((total + 3) / 4));
         if (!s->uniform_len) par_copy(s->h_len.p, seq_len, (size_t)n_reads * sizeof(uint16_t));
@@ -1815,7 +1827,7 @@ int groot_hip_submit_acquired(groot_ctx *c, uint64_t ticket, uint32_t n_reads, u
     s->n_bases = total; s->n_exc = n_reads ? n_exc : 0;
     s->max_len = std::min(max_len, c->prm.max_read_len);
     s->uniform_len = n_reads && min_len == max_len ? max_len : 0;
-    s->mixed_len = n_reads && min_len != max_len;
+    s->mixed_len = n_reads && min_len != max_len; s->one_len = n_reads && min_len == max_len;
     s->state = Slot::FREE;           // enqueue re-labels it
     return enqueue(c, s);
 }
@@ -1833,6 +1845,7 @@ int groot_hip_submit_device(groot_ctx *c, const void *d_seq, const void *d_seq_o
     s->ext_seq = (const uint8_t *)d_seq; s->ext_off = (const uint64_t *)d_seq_off;
     s->max_len = max_len ? std::min(max_len, c->prm.max_read_len) : c->prm.max_read_len;
     s->mixed_len = false;                  // (unknown: the offsets are on the device)
+    s->one_len = max_len != 0;             // (the caller's word: the longest read, taken as THE read length when choosing kernels)
     return enqueue(c, s);
 }
 
