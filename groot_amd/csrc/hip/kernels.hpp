@@ -510,15 +510,19 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
             const uint32_t e_end = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
             for (uint32_t e = lo; e < e_end; e++) {
                 // slots whose signature bytes agree (pad bytes are zero on both sides): an upper bound of the equal slots
+                // (this filter is most of the branch's time -- runs of ~40 rows per band: only the dwords that hold slots, and the
+                // cheap zero-byte test, which may also flag a byte of value 1 above an equal one: an upper bound still)
                 const uint4 sa = sigs[2 * (size_t)e], sb = sigs[2 * (size_t)e + 1];
                 const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+                const int nd = (sl_ + 3) >> 2;
                 uint32_t same = 0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
+                    if (i >= nd) break;
                     const uint32_t x = ws8[i] ^ rs[i];
-                    same += __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));
+                    same += __popc((x - 0x01010101u) & ~x & 0x80808080u);
                 }
-                if (same - (32u - (uint32_t)sl_) + (uint32_t)(s_ - sl_) < min_eq) continue;
+                if (same - (4u * (uint32_t)nd - (uint32_t)sl_) + (uint32_t)(s_ - sl_) < min_eq) continue;
                 const uint32_t id = ids[e];
                 const uint64_t *ws = ix.win_sketch + (size_t)id * s_;
                 uint32_t eq = 0;
