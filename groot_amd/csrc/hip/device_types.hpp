@@ -3,6 +3,8 @@
 
 #include <cstdint>
 
+#include <hip/hip_runtime.h>
+
 #include "groot_hip.h"
 
 namespace groot {
@@ -21,6 +23,7 @@ enum : uint32_t {
     kFlagQOverflow = 64u,     // more distinct kmerCounts among the seeded reads than the call-count table has rows
 };
 
+constexpr uint32_t kIncrCap = 8;      // AlignArgs::incr_win slots per read
 constexpr uint32_t kSeedShards = 64, kSeedShardStride = 16;   // seed-stage counters: one 128-byte line per shard
 constexpr uint32_t kOvfShards = 256;  // overflow traversal lists, picked by workgroup id: spreads the atomics
 
@@ -32,7 +35,7 @@ struct DeviceCounters {
     unsigned int q_rows;        // rows of the call-count table in use after this batch (may exceed its capacity: then kFlagQOverflow)
     unsigned int mask_words;    // 64-bit words of the compact path sets of this batch (mask_compact_kernel)
     unsigned int todo_reads;    // reads sketch_sig_kernel handed to the full-width kernel (0 when that kernel ran alone)
-    unsigned int seeded_reads;  // reads with at least one seed: the align stage's share of the processing order (they sort first)
+    unsigned int seeded_reads;  // reads with at least one seed whose alignment is not tabulated: the align stage's share of the processing order (they sort first)
     unsigned int pad3;
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
@@ -85,6 +88,18 @@ struct groot_ctrav {
     uint32_t read_flags;       // position of the read in the batch (24 bits) | GROOT_TRAV_* flags << 24
 };
 static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
+
+// Outcome table entry (DeviceIndex::out_tab), as dwords: what graphMinion + AlignRead (graphminion.go:46-102, alignment.go:13-159)
+// produce for a read that IS bases [o, o + WindowSize) of a window text row -- every such read is the same string with the same seed
+// windows, so the outcome is a function of (window, row, o) and the ctx works it out once, at open, by running the align stage itself
+// on the string.  One entry per traversal record:
+//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | sam.Records of the whole read << 16
+//   [4],[5] windows whose IncrementSubPath the read triggers (kEmpty = none; a string's calls are spread over its entries)
+//   [6..] path set, pw 64-bit words (lo, hi)
+constexpr uint32_t kOutHdrDw = 6;
+constexpr uint32_t kOutTab = 0x80000000u;                  // sig_info: the string's outcome is tabulated
+constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 27;
+__host__ __device__ inline uint32_t out_stride_q(uint32_t pw) { return (kOutHdrDw * 4 + 8 * pw + 15) / 16; }
 
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
@@ -146,8 +161,14 @@ struct DeviceIndex {
     // what the seed stage's epilogue works out for a read that IS bases [o, o + WindowSize) of a text row (every such read is
     // the same string): verdict bits (kRecNo* >> 24, both orientations) | dead-orientation class << 6, as the full-width kernel
     // produced them for exactly that string when the ctx was opened -- [(window * 2 + row) * sig_verdict_stride + o]; null = none
-    const uint8_t *sig_verdict;
+    // One u32 per such string since round 3.  Bit 31 clear: bits 0..7 = that verdict byte.  Bit 31 set: the whole outcome of the
+    // graphMinion loop for the string is tabulated (kOutTab): bits 27..30 = traversals - 1, bits 0..26 = index of its first OutEntry.
+    const uint32_t *sig_info;
     uint32_t sig_verdict_stride;
+    // AlignRead outcomes of window-text strings (groot_hip_open ran the align stage on every one of them): out_stride_q 16-byte
+    // words per entry, entries of a string back to back in `ord` order
+    const uint4 *out_tab;
+    uint32_t out_stride_q;
     const uint8_t *win_nodes;       // [n_windows] min(255, contained nodes of the window): the span class of the scheduling key
 };
 
@@ -167,6 +188,7 @@ struct SeedArgs {
     uint32_t *q_seen;            // [max_q + 1] set for every kmerCount of a seeded read that has no row yet; or null
     uint32_t *trav_cnt;          // [n_reads] traversal counts of the align stage: zeroed here for reads without seeds (it skips them); or null
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
+    uint32_t *tab_idx;           // [n_reads] first OutEntry of reads whose outcome is tabulated (preset to kEmpty per batch); or null: no table
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
@@ -200,6 +222,9 @@ struct AlignArgs {
     uint64_t *stk_mask;          // [(d*n_threads + t)*pw + word]
     uint32_t n_threads, stk_depth;
     uint32_t lds_stride_dw;      // dwords of LDS per lane for the staged read (odd), 0 = reads stay in global memory
+    // groot_hip_open's capture pass for the outcome table: per read the windows whose IncrementSubPath was called, in call order
+    // ([n_reads][kIncrCap], count in incr_cnt[r] bits 0..30, bit 31 = the read touched more than one graph); null otherwise
+    uint32_t *incr_cnt, *incr_win;
     uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;
 };

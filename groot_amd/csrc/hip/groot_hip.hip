@@ -140,7 +140,13 @@ struct groot_ctx {
     DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
     DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature table + window texts (absent: that kernel is not used)
-    DevBuf<uint8_t> win_text, sig_verdict, win_nodes;
+    DevBuf<uint8_t> win_text, win_nodes;
+    DevBuf<uint32_t> sig_info;             // per window-text string: verdict byte, or where its tabulated outcome is (DeviceIndex::sig_info)
+    DevBuf<uint4> out_tab;                 // AlignRead outcomes of the window-text strings (DeviceIndex::out_tab)
+    uint64_t out_strings = 0, out_tabulated = 0, out_entries = 0;   // strings that confirm reads / of them tabulated / table entries
+    double out_build_ms = 0;
+    bool tab_capture = false;              // the capture pass of groot_hip_open is running (align stage records the IncrementSubPath windows)
+    DevBuf<uint32_t> tab_idx, incr_cnt, incr_win;
     std::vector<uint16_t> h_q_min_eq;      // host copy of DeviceIndex::q_min_eq: which seed kernel a batch of one read length gets
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
@@ -586,6 +592,10 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     a.trav_cnt = c->trav_cnt.p;
     a.shards = c->seed_shards.p;
     a.ctr = s->d_ctr.p;
+    if (c->dix.out_tab) {                                   // reads the signature kernel finds in the outcome table say so here
+        a.tab_idx = c->tab_idx.p;
+        HIP_TRY(c, hipMemsetAsync(c->tab_idx.p, 0xFF, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
+    }
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
     // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
     unsigned win_bits = 3;                                  // 2 class bits + one bit above the largest window id
@@ -668,6 +678,10 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         const uint32_t stride = (2 + 4 * ((s->max_len + 27) / 16)) | 1u;
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
+    if (c->tab_capture) {
+        a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p;
+        HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
+    }
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
@@ -677,7 +691,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
 }
 
 // traversal records -> (read, ord) order: exclusive scan of the per-read counts, then two scatters into the slot's output
-static int launch_order_stage(groot_ctx *c, Slot *s)
+static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     const uint32_t n = s->n_reads;
     size_t tmp_bytes = 0;
@@ -688,9 +702,15 @@ static int launch_order_stage(groot_ctx *c, Slot *s)
     }
     HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
     hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, s->d_ctr.p);
-    hipLaunchKernelGGL(order_first_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->trav_first.p,
+    OrderTabArgs ot{};
+    if (c->dix.out_tab) {
+        ot.tab_idx = c->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
+        ot.update_weights = update_weights ? 1 : 0; ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
+        ot.q_tab = c->dix.w - c->k + 1; ot.n_windows = c->n_windows;
+    }
+    hipLaunchKernelGGL(order_first_kernel, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, 2048u)), dim3(kBlock), 0, c->stream, c->trav_first.p,
                        c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw,
-                       c->pw_view, s->d_ctr.p);
+                       c->pw_view, s->d_ctr.p, ot);
     hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->stream,
                        c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, s->first_read_id, s->d_trav.p,
                        s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
@@ -724,7 +744,7 @@ static int run_batch_async(groot_ctx *c, Slot *s, bool update_weights)
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[3], c->stream));
     if (int rc = launch_align_stage(c, s, update_weights)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[4], c->stream));
-    if (int rc = launch_order_stage(c, s)) return rc;
+    if (int rc = launch_order_stage(c, s, update_weights)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[5], c->stream));
     c->work_owner = s;
     c->work_ticket = s->ticket;
@@ -1199,6 +1219,141 @@ static int text_pass(groot_ctx *c, const uint8_t *seqs, const uint32_t *owner, u
     return GROOT_OK;
 }
 
+static int enqueue(groot_ctx *c, Slot *s);
+static int collect_impl(groot_ctx *c, Slot **out);
+static int take_slot(groot_ctx *c, uint32_t n_reads, Slot **out);
+
+// Outcome table (DeviceIndex::out_tab, device_types.hpp OutEntry).  A read the signature kernel confirms by text IS bases
+// [o, o + WindowSize) of a window text row, and every such read brings the same seed windows (the row's sketch class): what the
+// graphMinion loop does with it -- which windows get IncrementSubPath, which traversals AlignRead reports, in which order
+// (graphminion.go:46-102, alignment.go:13-159) -- is a function of the string.  So the strings go through this ctx's own pipeline
+// once, as ordinary batches (signature kernel -> sort -> align_kernel -> ordering), the align stage additionally noting the windows
+// it counted, and every string with 1..16 traversals gets its records stored.  At run time such reads never reach the align stage.
+static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, const std::vector<uint32_t> &tlen, std::vector<uint32_t> &info,
+                               uint32_t w, uint32_t vstride)
+{
+    const uint32_t n = c->n_windows, pw = c->pw_view;
+    const uint32_t sq = out_stride_q(pw);
+    const uint32_t chunk = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(c->prm.max_batch_reads, 1u << 20), c->prm.max_batch_bases / w);
+    if (!chunk) return GROOT_OK;
+    HIP_TRY(c, c->incr_cnt.alloc(chunk));
+    HIP_TRY(c, c->incr_win.alloc((size_t)chunk * kIncrCap));
+    DevBuf<uint8_t> d_seq;
+    DevBuf<uint64_t> d_off;
+    HIP_TRY(c, d_seq.alloc((size_t)chunk * w + 64));
+    HIP_TRY(c, d_off.alloc((size_t)chunk + 1));
+    std::vector<uint32_t> tab;                              // entries, sq * 4 dwords each
+    std::vector<uint8_t> seqs;
+    std::vector<uint64_t> offs;
+    std::vector<size_t> where;
+    std::vector<groot_trav> travs;
+    std::vector<uint64_t> masks;
+    std::vector<uint32_t> icnt, iwin;
+    c->out_strings = c->out_tabulated = c->out_entries = 0;
+    int rc_all = GROOT_OK;
+    auto flush = [&]() -> int {
+        const uint32_t m = (uint32_t)where.size();
+        if (!m) return GROOT_OK;
+        Slot *s = nullptr;
+        if (int rc = take_slot(c, m, &s)) return rc;
+        if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;      // (resident input: no ASCII staging is allocated for this)
+        HIP_TRY(c, hipMemcpy(d_seq.p, seqs.data(), seqs.size(), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_off.p, offs.data(), ((size_t)m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        s->input = Slot::IN_DEVICE; s->n_reads = m; s->first_read_id = 0; s->mixed_len = false; s->one_len = true;
+        s->n_bases = 0; s->n_exc = 0; s->max_len = w; s->uniform_len = 0;
+        s->ext_seq = d_seq.p; s->ext_off = d_off.p;
+        if (int rc = enqueue(c, s)) return rc;
+        Slot *done = nullptr;
+        if (int rc = collect_impl(c, &done)) return rc;
+        const bool ok = done->status == GROOT_OK;
+        const uint32_t nt = done->n_trav;
+        travs.resize(nt); masks.resize((size_t)nt * pw); icnt.resize(m); iwin.resize((size_t)m * kIncrCap);
+        if (ok) {
+            if (nt) {
+                HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            }
+            HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * kIncrCap * 4, hipMemcpyDeviceToHost));
+        }
+        release_slot(c, done);
+        c->out_strings += m;
+        if (ok) {
+            size_t t0 = 0;
+            for (uint32_t j = 0; j < m; j++) {              // records come in (read, ord) order
+                size_t t1 = t0;
+                while (t1 < nt && travs[t1].read_id == j) t1++;
+                const uint32_t cnt = (uint32_t)(t1 - t0), ni = icnt[j] & 0x7FFFFFFFu;
+                uint64_t recs = 0;
+                for (size_t t = t0; t < t1; t++)
+                    for (uint32_t x = 0; x < pw; x++) recs += (uint64_t)__builtin_popcountll(masks[t * pw + x]);
+                const size_t first = tab.size() / (sq * 4);
+                if (cnt >= 1 && cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(kIncrCap, 2 * cnt) && recs <= 0xFFFFu && first + cnt < (1u << kOutIdxBits)) {
+                    for (uint32_t e = 0; e < cnt; e++) {
+                        const groot_trav &t = travs[t0 + e];
+                        const size_t b = tab.size();
+                        tab.resize(b + sq * 4, 0);
+                        tab[b] = t.node; tab[b + 1] = t.offset; tab[b + 2] = t.graph_id;
+                        tab[b + 3] = (uint32_t)t.flags | (e == 0 && (icnt[j] >> 31) ? 0x100u : 0u) | (e == 0 ? (uint32_t)recs << 16 : 0u);
+                        tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * kIncrCap + 2 * e] : kEmpty;
+                        tab[b + 5] = 2 * e + 1 < ni ? iwin[(size_t)j * kIncrCap + 2 * e + 1] : kEmpty;
+                        for (uint32_t x = 0; x < pw; x++) {
+                            tab[b + kOutHdrDw + 2 * x] = (uint32_t)masks[(t0 + e) * pw + x];
+                            tab[b + kOutHdrDw + 2 * x + 1] = (uint32_t)(masks[(t0 + e) * pw + x] >> 32);
+                        }
+                    }
+                    info[where[j]] = kOutTab | ((cnt - 1) << kOutIdxBits) | (uint32_t)first;
+                    c->out_tabulated++;
+                }
+                t0 = t1;
+            }
+        }
+        seqs.clear(); where.clear(); offs.assign(1, 0);
+        return GROOT_OK;
+    };
+    offs.assign(1, 0);
+    c->tab_capture = true;
+    for (uint32_t i = 0; i < n && !rc_all; i++) {
+        if (!tlen[i]) continue;
+        for (uint32_t row = 0; row < 2 && !rc_all; row++)
+            for (uint32_t o = 0; o + w <= tlen[i] && !rc_all; o++) {
+                const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax + o];
+                seqs.insert(seqs.end(), src, src + w);
+                offs.push_back(offs.back() + w);
+                where.push_back(((size_t)i * 2 + row) * vstride + o);
+                if (where.size() >= chunk) rc_all = flush();
+            }
+    }
+    if (!rc_all) rc_all = flush();
+    c->tab_capture = false;
+    c->incr_cnt.release(); c->incr_win.release();
+    // the capture batches counted IncrementSubPath calls and claimed rows of the call-count table: back to the state of a fresh ctx
+    {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> none(c->max_q + 2, kEmpty);
+        HIP_TRY(c, hipMemcpy(c->q_row.p, none.data(), none.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemset(c->q_seen.p, 0, (size_t)(c->max_q + 2) * 4));
+        HIP_TRY(c, hipMemset(c->q_nrows.p, 0, 4));
+        if (c->att_cap) HIP_TRY(c, hipMemset(c->attempts_ptr, 0, (size_t)c->att_cap * c->n_windows * sizeof(uint32_t)));
+        c->work_owner = nullptr;
+        c->trav_per_read = 1.25; c->words_per_trav = 0;
+    }
+    if (rc_all) return rc_all;
+    c->out_entries = tab.size() / (sq * 4);
+    if (!c->out_entries) return GROOT_OK;
+    tab.resize(tab.size() + 16, 0);
+    HIP_TRY(c, c->out_tab.alloc(c->out_entries * sq + 4));
+    HIP_TRY(c, hipMemcpy(c->out_tab.p, tab.data(), (c->out_entries * sq + 4) * sizeof(uint4), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->sig_info.p, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, c->tab_idx.alloc(c->prm.max_batch_reads));
+    c->dix.out_tab = c->out_tab.p;
+    c->dix.out_stride_q = sq;
+    if (getenv("GROOT_OPEN_STATS"))
+        fprintf(stderr, "[groot open]   outcome table: %llu of %llu window-text strings tabulated, %llu entries of %u bytes\n", (unsigned long long)c->out_tabulated,
+                (unsigned long long)c->out_strings, (unsigned long long)c->out_entries, sq * 16);
+    return GROOT_OK;
+}
+
 static int build_signature_index(groot_ctx *c, const groot_index_view *v, const std::vector<uint32_t> &sketch_class)
 {
     const uint32_t n = v->n_windows, s = v->sketch_size, w = v->window_size, k = v->kmer_size;
@@ -1257,7 +1412,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     //    seed stage's epilogue says about the same strings (the reads the signature kernel confirms ARE these strings) --
     //    verdict bits and dead-orientation class, one byte each.  A text whose own bases do not come back with a seed is dropped.
     const uint32_t vstride = kTextMax - w + 1;
-    std::vector<uint8_t> verdict((size_t)n * 2 * vstride + 16, 0);
+    std::vector<uint32_t> verdict((size_t)n * 2 * vstride + 16, 0);   // DeviceIndex::sig_info (verdict bytes first, tabulated outcomes in step 5)
     {
         const uint32_t chunk = 1u << 20;
         std::vector<uint8_t> seqs, differs;
@@ -1269,7 +1424,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
             if (int rc = text_pass(c, seqs.data(), owner.data(), (uint32_t)owner.size(), w, differs.data(), flags.data(), keys.data())) return rc;
             for (size_t j = 0; j < owner.size(); j++) {
                 if (differs[j] || !(flags[j] & kRecCountMask) || keys[j] == kEmpty) { tlen[owner[j]] = 0; continue; }
-                verdict[where[j]] = (uint8_t)(((flags[j] >> 24) & 0x3Fu) | ((keys[j] & 3u) << 6));
+                verdict[where[j]] = ((flags[j] >> 24) & 0x3Fu) | ((keys[j] & 3u) << 6);
             }
             seqs.clear(); owner.clear(); where.clear();
             return GROOT_OK;
@@ -1330,15 +1485,22 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     }
     HIP_TRY(c, upload(c->sig, tab.data(), tab.size()));
     HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));
-    HIP_TRY(c, upload(c->sig_verdict, verdict.data(), verdict.size()));
+    HIP_TRY(c, upload(c->sig_info, verdict.data(), verdict.size()));
     HIP_TRY(c, upload(c->win_nodes, nodes.data(), nodes.size(), 4));
-    c->dix.sig_verdict = getenv("GROOT_NO_SIG_VERDICTS") ? nullptr : c->sig_verdict.p;
+    c->dix.sig_info = getenv("GROOT_NO_SIG_VERDICTS") ? nullptr : c->sig_info.p;
     c->dix.sig_verdict_stride = vstride;
     c->dix.win_nodes = c->win_nodes.p;
     lap("tables + uploads");
     c->dix.sig = c->sig.p;
     c->dix.sig_mask = cap - 1;
     c->dix.win_text = c->win_text.p;
+    // 5. outcome table: the align stage itself, once, on every string that confirms reads
+    if (c->dix.sig_info && !getenv("GROOT_NO_OUTCOME_TABLE") && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (int rc = build_outcome_table(c, text, tlen, verdict, w, vstride)) return rc;
+        c->out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lap("outcome table");
+    }
     return GROOT_OK;
 }
 

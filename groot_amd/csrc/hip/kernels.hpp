@@ -171,7 +171,7 @@ struct SeedAhead {
 };
 
 // per-read bookkeeping every seed kernel ends with
-__device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t r, const uint32_t q, const uint32_t n_hits)
+__device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t r, const uint32_t q, const uint32_t n_hits, const bool tabulated = false)
 {
     const DeviceIndex &ix = a.ix;
     if (n_hits) {
@@ -182,14 +182,14 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
     // one pair of atomics per wavefront, sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per
     // 10 M reads.  assign_q_rows_kernel folds the shards into the batch's counter block.
     if (!n_hits && a.trav_cnt) a.trav_cnt[r] = 0;          // the align stage only walks the reads with seeds
-    uint32_t total = 0, most = 0, seeded = 0;
+    uint32_t total = 0, most = 0;
     for (uint32_t t = 1;; t++) {
         const unsigned long long b = __ballot(n_hits >= t);
         if (!b) break;
         total += (uint32_t)__popcll(b);
-        if (t == 1) seeded = total;
         most = t;
     }
+    const uint32_t seeded = (uint32_t)__popcll(__ballot(n_hits && !tabulated));   // ... and whose outcome is not tabulated
     const unsigned long long here = __ballot(1);
     if (total && __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) == 0) {
         unsigned long long *sh = a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride;
@@ -282,6 +282,17 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);
+}
+
+// the same for a read whose whole graphMinion outcome is tabulated (info = its DeviceIndex::sig_info word): nothing is left for the
+// align stage -- no read record, no place in the processing order; order_first_kernel writes its records from the table
+__device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint32_t r, const uint32_t q, const uint32_t n_hits, const uint32_t info)
+{
+    a.seed_count[r] = n_hits;
+    a.sort_key[r] = kEmpty;
+    a.tab_idx[r] = info & ((1u << kOutIdxBits) - 1u);
+    a.trav_cnt[r] = ((info >> kOutIdxBits) & (kOutMaxTrav - 1u)) + 1u;
+    seed_counters(a, r, q, n_hits, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         code_r = (((y & 0x555555u) << 1) | ((y >> 1) & 0x555555u)) ^ 0xAAAAAAu;                                   // pairs restored, complemented (code ^ 2)
     }
     SeedAhead ahead;
-    const bool use_table = ix.sig_verdict && len == ix.w && a.sort_key;   // the epilogue's answers for window-sized text reads exist already
+    const bool use_table = ix.sig_info && len == ix.w && a.sort_key;   // the epilogue's answers for window-sized text reads exist already
     uint32_t vbyte = 0, nodes_ahead = 0, first_id = kEmpty;
     bool have_vbyte = false;
     const uint32_t j0 = key0 & 255u;
@@ -864,7 +875,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         const bool okf = of <= tl - len, okr = orc <= tl - len;
         uint32_t vf = 0, vr = 0;
         if (use_table) {
-            const uint8_t *vt = ix.sig_verdict + (size_t)e.y * 2 * ix.sig_verdict_stride;
+            const uint32_t *vt = ix.sig_info + (size_t)e.y * 2 * ix.sig_verdict_stride;
             if (okf) vf = vt[of];
             if (okr) vr = vt[ix.sig_verdict_stride + orc];
         }
@@ -891,7 +902,8 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (e.y == kEmpty) break;
             if (e.x == tag && e.z == cls) hit(e.y);
         }
-    if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win]);
+    if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte);
+    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win]);
     else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
 }
 
@@ -1360,6 +1372,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 a.trav_cnt[r] = ord;
                 mapped++;                                     // boss.go:195-200
                 if (n_graphs > 1) multimapped++;
+                if (a.incr_cnt && n_graphs > 1) a.incr_cnt[r] |= 0x80000000u;   // (capture pass of groot_hip_open; the lane owns the read)
                 have_read = false;
                 phase = PH_WAIT;
                 continue;
@@ -1385,6 +1398,11 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                         pending = false;
                     }
                 }
+            }
+            if (a.incr_cnt) {              // capture pass: which windows had IncrementSubPath called, in call order
+                const uint32_t n = a.incr_cnt[r];
+                a.incr_cnt[r] = n + 1;
+                if (n < kIncrCap) a.incr_win[(size_t)r * kIncrCap + n] = w;
             }
             if (a.no_align) continue;                         // :70-72
             seed = wa.y; off0 = wa.z;
@@ -1673,16 +1691,71 @@ __global__ void order_total_kernel(const uint32_t *off, const uint32_t *cnt, uin
     if (n) ctr->n_trav = off[n - 1] + cnt[n - 1];
 }
 
+// tab_idx[r] != kEmpty: the read's records come from the outcome table (DeviceIndex::out_tab) instead of the align stage -- cnt[r]
+// entries from tab_idx[r] on --, and this kernel does what the align stage does for the others: the IncrementSubPath call counts
+// (graphminion.go:60-67) and the read / alignment counters (boss.go:195-200).
+struct OrderTabArgs {
+    const uint32_t *tab_idx;     // [n] or null
+    const uint4 *out_tab;
+    uint32_t stride_q, first_read_id;
+    uint32_t update_weights;
+    uint32_t *attempts;          // [rows][n_windows]
+    const uint32_t *q_row;
+    uint32_t q_tab, n_windows;   // kmerCount of the tabulated reads (WindowSize - k + 1)
+};
 __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *first, const uint64_t *mask_first, const uint32_t *off,
                                                            const uint32_t *cnt, uint32_t n, groot_trav *out, uint64_t *mask_out,
-                                                           uint32_t cap, uint32_t pw_in, uint32_t pw_out, DeviceCounters *ctr)
+                                                           uint32_t cap, uint32_t pw_in, uint32_t pw_out, DeviceCounters *ctr, OrderTabArgs t)
 {
-    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n || cnt[r] == 0) return;
-    const uint32_t i = off[r];
-    if (i >= cap) { atomicOr(&ctr->flags, kFlagTravOverflow); return; }
-    out[i] = first[r];
-    for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = mask_first[(size_t)r * pw_in + w];
+    __shared__ unsigned long long red[4];
+    unsigned long long alns = 0, mapped = 0, multimapped = 0;
+    // (a pass whose seed stage ran out of slots / table rows is repeated as a whole: nothing may be counted in it)
+    const bool live = !(ctr->flags & (kFlagSeedOverflow | kFlagQOverflow));
+    // (grid-stride: the three counter atomics per workgroup below share one line, ~7 ns each -- a few thousand workgroups, not 40 000)
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+    const uint32_t ti = t.tab_idx ? t.tab_idx[r] : kEmpty;
+    if (ti != kEmpty && live) {
+        const uint32_t nt = cnt[r], i = off[r];
+        const bool fits = i < cap && nt <= cap - i;
+        if (!fits) atomicOr(&ctr->flags, kFlagTravOverflow);
+        const uint32_t row = t.update_weights ? t.q_row[t.q_tab] : 0u;
+        for (uint32_t j = 0; j < nt; j++) {
+            const uint4 *e = t.out_tab + (size_t)(ti + j) * t.stride_q;
+            const uint4 h = e[0];                          // node, offset, graph, flags | multimapped << 8 | records << 16
+            const uint4 x = e[1];                          // two call-count windows, first path word
+            if (t.update_weights) {
+                if (x.x != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.x], 1u);
+                if (x.y != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.y], 1u);
+            }
+            if (j == 0) { alns += h.w >> 16; mapped++; multimapped += (h.w >> 8) & 1u; }
+            if (!fits) continue;
+            groot_trav tr;
+            tr.read_id = t.first_read_id + r; tr.graph_id = h.z; tr.node = h.x; tr.offset = h.y;
+            tr.ord = (uint16_t)j; tr.flags = (uint8_t)h.w; tr.reserved = 0;
+            out[i + j] = tr;
+            const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
+            for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)(i + j) * pw_out + w] = (uint64_t)ew[2 * w] | ((uint64_t)ew[2 * w + 1] << 32);
+        }
+    } else if (ti == kEmpty && cnt[r] != 0) {
+        const uint32_t i = off[r];
+        if (i >= cap) atomicOr(&ctr->flags, kFlagTravOverflow);
+        else {
+            out[i] = first[r];
+            for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = mask_first[(size_t)r * pw_in + w];
+        }
+    }
+    }
+    if (!t.tab_idx) return;                                // (uniform)
+    alns = block_sum(alns, red);
+    mapped = block_sum(mapped, red);
+    multimapped = block_sum(multimapped, red);
+    if (threadIdx.x == 0) {
+        if (alns) atomicAdd(&ctr->alignments, alns);
+        if (t.update_weights) {
+            if (mapped) atomicAdd(&ctr->mapped, mapped);
+            if (multimapped) atomicAdd(&ctr->multimapped, multimapped);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void order_ovf_kernel(const groot_trav *ovf, const uint64_t *ovf_mask, const uint32_t *ovf_cnt,
