@@ -362,10 +362,21 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     k_ms, a_ms, s_ms, g_ms = [], [], [], []
-    for _ in range(args.steps):
-        counts = step()
-        ms = al.stage_ms()
-        k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"]); g_ms.append(ms["schedule"])
+    # the ctx is a pipeline (submit / collect-the-oldest): the next step is enqueued while the GPU works on this one, so
+    # the host's launch latency is not part of a step; every step is waited for and its counters are read
+    pending = 0
+    for i in range(args.steps + 1):
+        if i < args.steps:
+            al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), R, first_read_id=0, max_len=READ_LEN)
+            pending += 1
+        if pending == 2 or (i == args.steps and pending):
+            counts = al.wait()
+            pending -= 1
+            ms = al.stage_ms()
+            k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"]); g_ms.append(ms["schedule"])
+    while pending:
+        counts = al.wait()
+        pending -= 1
     if dist is not None:
         dist.all_reduce(d_att)  # per-(kmerCount, window) IncrementSubPath counts: the only exchange
     torch.cuda.synchronize()

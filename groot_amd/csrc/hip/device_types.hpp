@@ -98,8 +98,16 @@ static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
 //   [6..] path set, pw 64-bit words (lo, hi)
 constexpr uint32_t kOutHdrDw = 6;
 constexpr uint32_t kOutTab = 0x80000000u;                  // sig_info: the string's outcome is tabulated
-constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 27;
-__host__ __device__ inline uint32_t out_stride_q(uint32_t pw) { return (kOutHdrDw * 4 + 8 * pw + 15) / 16; }
+constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 26, kOutTravShift = 27;
+constexpr uint32_t kOutAllSeeds = 1u << 26;                // sig_info: ... and IncrementSubPath is called exactly once for each of the read's seed windows
+constexpr uint32_t kTabCounted = 0x80000000u;              // SeedArgs::tab_idx: the seed stage has counted the read's IncrementSubPath calls
+// (entries are padded to a power of two of at least 64 bytes: a gather touches one 64-byte sector, never two)
+__host__ __device__ inline uint32_t out_stride_q(uint32_t pw)
+{
+    uint32_t q = 4;
+    while (q * 16 < kOutHdrDw * 4 + 8 * pw) q <<= 1;
+    return q;
+}
 
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
@@ -162,7 +170,7 @@ struct DeviceIndex {
     // the same string): verdict bits (kRecNo* >> 24, both orientations) | dead-orientation class << 6, as the full-width kernel
     // produced them for exactly that string when the ctx was opened -- [(window * 2 + row) * sig_verdict_stride + o]; null = none
     // One u32 per such string since round 3.  Bit 31 clear: bits 0..7 = that verdict byte.  Bit 31 set: the whole outcome of the
-    // graphMinion loop for the string is tabulated (kOutTab): bits 27..30 = traversals - 1, bits 0..26 = index of its first OutEntry.
+    // graphMinion loop for the string is tabulated (kOutTab): bits 27..30 = traversals - 1, bit 26 = kOutAllSeeds, bits 0..25 = index of its first OutEntry.
     const uint32_t *sig_info;
     uint32_t sig_verdict_stride;
     // AlignRead outcomes of window-text strings (groot_hip_open ran the align stage on every one of them): out_stride_q 16-byte
@@ -188,7 +196,8 @@ struct SeedArgs {
     uint32_t *q_seen;            // [max_q + 1] set for every kmerCount of a seeded read that has no row yet; or null
     uint32_t *trav_cnt;          // [n_reads] traversal counts of the align stage: zeroed here for reads without seeds (it skips them); or null
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
-    uint32_t *tab_idx;           // [n_reads] first OutEntry of reads whose outcome is tabulated (preset to kEmpty per batch); or null: no table
+    uint32_t *tab_idx;           // [n_reads] first OutEntry (| kTabCounted) of reads whose outcome is tabulated, kEmpty for the others; or null: no table
+    uint32_t *tab_hist;          // [n_windows] IncrementSubPath calls of tabulated reads counted by the seed stage in this batch; or null
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
@@ -225,6 +234,7 @@ struct AlignArgs {
     // groot_hip_open's capture pass for the outcome table: per read the windows whose IncrementSubPath was called, in call order
     // ([n_reads][kIncrCap], count in incr_cnt[r] bits 0..30, bit 31 = the read touched more than one graph); null otherwise
     uint32_t *incr_cnt, *incr_win;
+    uint32_t round_lanes;        // lanes a wavefront fills per round; 0 = 64, fewer when the batch leaves the align stage little to do (see the kernel)
     uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;
 };

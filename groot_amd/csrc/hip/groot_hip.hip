@@ -146,7 +146,7 @@ struct groot_ctx {
     uint64_t out_strings = 0, out_tabulated = 0, out_entries = 0;   // strings that confirm reads / of them tabulated / table entries
     double out_build_ms = 0;
     bool tab_capture = false;              // the capture pass of groot_hip_open is running (align stage records the IncrementSubPath windows)
-    DevBuf<uint32_t> tab_idx, incr_cnt, incr_win;
+    DevBuf<uint32_t> tab_idx, tab_hist, incr_cnt, incr_win;
     std::vector<uint16_t> h_q_min_eq;      // host copy of DeviceIndex::q_min_eq: which seed kernel a batch of one read length gets
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
@@ -156,6 +156,7 @@ struct groot_ctx {
     std::deque<Slot *> inflight;           // submission order: IN_FLIGHT / D2H_ISSUED
     uint64_t next_ticket = 1;
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
+    double dfs_frac = 1.0;                 // share of the latest finished batch's reads that needed the align stage's graph walk (the rest: no seeds / tabulated outcomes)
     double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
     double words_per_trav = 0;             // compact path-set words per traversal, likewise (0 = not seen yet: path_words)
     bool packed_travs = false;             // the copy-out sends 12-byte records (batches of at most 2^24 reads), collect expands them
@@ -167,7 +168,7 @@ struct groot_ctx {
 
     // shared work buffers (compute stream only)
     uint32_t seed_slots = 0;
-    DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, todo_list, todo_count;
+    DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, perm_count, todo_list, todo_count;
     DevBuf<unsigned long long> seed_shards;
     DevBuf<char> sort_tmp;
     DevBuf<ReadRec> read_rec;
@@ -569,10 +570,14 @@ static int grow_attempts(groot_ctx *c, uint32_t rows)
     return GROOT_OK;
 }
 
+struct HasKey {     // reads the seed stage left for the align stage's graph walk carry a scheduling key
+    const uint32_t *key;
+    __host__ __device__ bool operator()(uint32_t r) const { return key[r] != kEmpty; }
+};
 #ifndef GROOT_SPAN_BITS
 #define GROOT_SPAN_BITS 6
 #endif
-static int launch_seed_stage(groot_ctx *c, Slot *s)
+static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     SeedArgs a{};
     a.ix = c->dix;
@@ -594,7 +599,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     a.ctr = s->d_ctr.p;
     if (c->dix.out_tab) {                                   // reads the signature kernel finds in the outcome table say so here
         a.tab_idx = c->tab_idx.p;
-        HIP_TRY(c, hipMemsetAsync(c->tab_idx.p, 0xFF, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
+        a.tab_hist = getenv("GROOT_EXP_NOHIST") ? nullptr : c->tab_hist.p;
     }
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
     // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
@@ -629,6 +634,27 @@ static int launch_seed_stage(groot_ctx *c, Slot *s)
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(64), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
                        c->max_q, s->d_ctr.p, c->seed_shards.p);
+    if (a.tab_hist) {
+        hipLaunchKernelGGL(fold_tab_hist_kernel, dim3(std::min<uint32_t>((c->n_windows + kBlock - 1) / kBlock, 1024u)), dim3(kBlock), 0, c->stream, c->tab_hist.p,
+                           c->attempts_ptr, c->q_row.p, c->dix.w - c->k + 1, c->n_windows, s->d_ctr.p, update_weights ? 1u : 0u);
+        HIP_TRY(c, hipGetLastError());
+    }
+    static const double list_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
+    if (c->dfs_frac < list_below) {
+        // Few reads need the graph walk (the latest batch says so; most are answered from the outcome table or have no seeds): sorting
+        // ten million keys to order a few of them costs more than their order saves.  The processing order is then simply the reads
+        // with a key, ascending -- one stream compaction (0.05 instead of 0.45 ms per 10 M reads).  Processing order only.
+        size_t tb = 0;
+        HasKey pred{c->sort_key.p};
+        rocprim::counting_iterator<uint32_t> ids(0u);
+        HIP_TRY(c, rocprim::select(nullptr, tb, ids, c->perm.p, c->perm_count.p, (size_t)s->n_reads, pred, c->stream));
+        if (tb > c->sort_tmp.n) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, c->sort_tmp.alloc(tb + tb / 4));
+        }
+        HIP_TRY(c, rocprim::select(c->sort_tmp.p, tb, ids, c->perm.p, c->perm_count.p, (size_t)s->n_reads, pred, c->stream));
+        return GROOT_OK;
+    }
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
@@ -682,6 +708,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p;
         HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
     }
+    if (const char *e = getenv("GROOT_ROUND_LANES")) a.round_lanes = (uint32_t)std::max(8, std::min(64, atoi(e)));   // experiments
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
@@ -705,7 +732,9 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
     OrderTabArgs ot{};
     if (c->dix.out_tab) {
         ot.tab_idx = c->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
-        ot.update_weights = update_weights ? 1 : 0; ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
+        ot.update_weights = update_weights ? 1 : 0;
+        if (getenv("GROOT_EXP_NOATOM")) ot.update_weights <<= 1;   // experiments: everything but the call-count atomics
+        ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
         ot.q_tab = c->dix.w - c->k + 1; ot.n_windows = c->n_windows;
     }
     hipLaunchKernelGGL(order_first_kernel, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, 2048u)), dim3(kBlock), 0, c->stream, c->trav_first.p,
@@ -740,7 +769,7 @@ static int run_batch_async(groot_ctx *c, Slot *s, bool update_weights)
 {
     HIP_TRY(c, hipMemsetAsync(s->d_ctr.p, 0, sizeof(DeviceCounters), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[1], c->stream));
-    if (int rc = launch_seed_stage(c, s)) return rc;
+    if (int rc = launch_seed_stage(c, s, update_weights)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[3], c->stream));
     if (int rc = launch_align_stage(c, s, update_weights)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[4], c->stream));
@@ -1041,6 +1070,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
 #endif
     // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
     if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
+    if (s->n_reads && !c->tab_capture) c->dfs_frac = (double)h.seeded_reads / (double)s->n_reads;
     s->n_mask_words = s->n_trav ? h.mask_words : 0;
     if (!c->prm.results_on_device && s->n_trav) {
         c->words_per_trav = (double)s->n_mask_words / (double)s->n_trav;
@@ -1248,7 +1278,7 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
     std::vector<size_t> where;
     std::vector<groot_trav> travs;
     std::vector<uint64_t> masks;
-    std::vector<uint32_t> icnt, iwin;
+    std::vector<uint32_t> icnt, iwin, nseeds, seedw;
     c->out_strings = c->out_tabulated = c->out_entries = 0;
     int rc_all = GROOT_OK;
     auto flush = [&]() -> int {
@@ -1273,6 +1303,9 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
                 HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
                 HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
             }
+            nseeds.resize(m); seedw.resize((size_t)4 * m);
+            HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, std::min<uint32_t>(4, c->seed_slots), hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * kIncrCap * 4, hipMemcpyDeviceToHost));
         }
@@ -1302,7 +1335,15 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
                             tab[b + kOutHdrDw + 2 * x + 1] = (uint32_t)(masks[(t0 + e) * pw + x] >> 32);
                         }
                     }
-                    info[where[j]] = kOutTab | ((cnt - 1) << kOutIdxBits) | (uint32_t)first;
+                    // are the IncrementSubPath calls exactly the string's seed windows, once each?  (then the seed stage counts them)
+                    bool all_seeds = ni == (nseeds[j] & 0x7FFFFFFFu) && ni <= 4 && ni <= c->seed_slots;
+                    if (all_seeds) {
+                        uint32_t a4[4], b4[4];
+                        for (uint32_t x = 0; x < ni; x++) { a4[x] = iwin[(size_t)j * kIncrCap + x]; b4[x] = seedw[(size_t)x * m + j]; }
+                        std::sort(a4, a4 + ni); std::sort(b4, b4 + ni);
+                        all_seeds = std::equal(a4, a4 + ni, b4) && std::adjacent_find(a4, a4 + ni) == a4 + ni;
+                    }
+                    info[where[j]] = kOutTab | ((cnt - 1) << kOutTravShift) | (all_seeds ? kOutAllSeeds : 0u) | (uint32_t)first;
                     c->out_tabulated++;
                 }
                 t0 = t1;
@@ -1336,7 +1377,7 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
         HIP_TRY(c, hipMemset(c->q_nrows.p, 0, 4));
         if (c->att_cap) HIP_TRY(c, hipMemset(c->attempts_ptr, 0, (size_t)c->att_cap * c->n_windows * sizeof(uint32_t)));
         c->work_owner = nullptr;
-        c->trav_per_read = 1.25; c->words_per_trav = 0;
+        c->trav_per_read = 1.25; c->words_per_trav = 0; c->dfs_frac = 1.0;
     }
     if (rc_all) return rc_all;
     c->out_entries = tab.size() / (sq * 4);
@@ -1346,6 +1387,8 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
     HIP_TRY(c, hipMemcpy(c->out_tab.p, tab.data(), (c->out_entries * sq + 4) * sizeof(uint4), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->sig_info.p, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, c->tab_idx.alloc(c->prm.max_batch_reads));
+    HIP_TRY(c, c->tab_hist.alloc(c->n_windows));
+    HIP_TRY(c, hipMemset(c->tab_hist.p, 0, (size_t)c->n_windows * sizeof(uint32_t)));
     c->dix.out_tab = c->out_tab.p;
     c->dix.out_stride_q = sq;
     if (getenv("GROOT_OPEN_STATS"))
@@ -1754,6 +1797,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->read_rec.alloc(R));
     HIP_TRY(c, c->sort_key_out.alloc(R));
     HIP_TRY(c, c->perm.alloc(R));
+    HIP_TRY(c, c->perm_count.alloc(4));
     {
         std::vector<uint32_t> iota(R);
         std::iota(iota.begin(), iota.end(), 0u);

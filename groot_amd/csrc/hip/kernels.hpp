@@ -182,6 +182,7 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
     // one pair of atomics per wavefront, sharded: one counter line for all wavefronts costs ~7 ns per atomic, 2.3 ms per
     // 10 M reads.  assign_q_rows_kernel folds the shards into the batch's counter block.
     if (!n_hits && a.trav_cnt) a.trav_cnt[r] = 0;          // the align stage only walks the reads with seeds
+    if (a.tab_idx && !tabulated) a.tab_idx[r] = kEmpty;    // its records will not come from the outcome table
     uint32_t total = 0, most = 0;
     for (uint32_t t = 1;; t++) {
         const unsigned long long b = __ballot(n_hits >= t);
@@ -286,12 +287,25 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
 
 // the same for a read whose whole graphMinion outcome is tabulated (info = its DeviceIndex::sig_info word): nothing is left for the
 // align stage -- no read record, no place in the processing order; order_first_kernel writes its records from the table
-__device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint32_t r, const uint32_t q, const uint32_t n_hits, const uint32_t info)
+__device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint32_t r, const uint32_t q, const uint32_t n_hits, const uint32_t info,
+                                                  const uint32_t s0, const uint32_t s1, const uint32_t s2, const uint32_t s3)
 {
     a.seed_count[r] = n_hits;
     a.sort_key[r] = kEmpty;
-    a.tab_idx[r] = info & ((1u << kOutIdxBits) - 1u);
-    a.trav_cnt[r] = ((info >> kOutIdxBits) & (kOutMaxTrav - 1u)) + 1u;
+    // IncrementSubPath is called once for every seed window of most reads (graphminion.go:60-67; the exceptions: a second seed
+    // of a graph that already has its alignment).  Those calls are counted right here, into the batch's own histogram over the
+    // windows (fire-and-forget atomics behind the hashing of the other wavefronts; fold_tab_hist_kernel adds the histogram to the
+    // call-count table once the batch is known to stand); order_first_kernel takes the others from the table entry.
+    uint32_t counted = 0;
+    if ((info & kOutAllSeeds) && a.tab_hist && n_hits <= 4u) {
+        atomicAdd(&a.tab_hist[s0], 1u);
+        if (n_hits > 1u) atomicAdd(&a.tab_hist[s1], 1u);
+        if (n_hits > 2u) atomicAdd(&a.tab_hist[s2], 1u);
+        if (n_hits > 3u) atomicAdd(&a.tab_hist[s3], 1u);
+        counted = kTabCounted;
+    }
+    a.tab_idx[r] = (info & ((1u << kOutIdxBits) - 1u)) | counted;
+    a.trav_cnt[r] = ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
     seed_counters(a, r, q, n_hits, true);
 }
 
@@ -368,6 +382,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         if (a.read_rec) { uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r); rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, 0); }
         if (a.sort_key) a.sort_key[r] = kEmpty;
         if (a.trav_cnt) a.trav_cnt[r] = 0;
+        if (a.tab_idx) a.tab_idx[r] = kEmpty;
         return;
     }
     if (len > a.max_read_len) {
@@ -376,6 +391,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         if (a.read_rec) { uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r); rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, 0); }
         if (a.sort_key) a.sort_key[r] = kEmpty;
         if (a.trav_cnt) a.trav_cnt[r] = 0;
+        if (a.tab_idx) a.tab_idx[r] = kEmpty;
         return;
     }
     const uint32_t nk = len - k + 1;
@@ -902,7 +918,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (e.y == kEmpty) break;
             if (e.x == tag && e.z == cls) hit(e.y);
         }
-    if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte);
+    if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte, s0, s1, s2, s3);
     else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win]);
     else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
 }
@@ -1127,7 +1143,14 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
     // agent scope in this loop halves the kernel's speed.)
     // reads without seeds sort last and have nothing to do here (the seed stage zeroed their traversal counts)
     const uint32_t n_todo = a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads)) : a.n_reads;   // (scalar: it bounds every refill)
-    const uint32_t n_rounds = (n_todo + 63u) >> 6;
+    // Lanes per round.  A round lasts as long as its slowest read, so when there are fewer reads than 64 per resident wavefront
+    // (most of the batch was answered from the outcome table: what is left are the hard reads) the rounds are made smaller
+    // and spread over all wavefronts: the launch then ends with the slowest read instead of the slowest sum of rounds.
+    uint32_t U = 64;
+    if (a.round_lanes) U = a.round_lanes;
+    else
+        while (U > 8u && n_todo < U * (gridDim.x * (uint32_t)(kBlock / 64))) U >>= 1;
+    const uint32_t n_rounds = (n_todo + U - 1u) / U;
     // (odd on purpose: with an even count the two-round chunks behind the head start at multiples of 128 slots and the kernel is
     // 6 % slower -- measured both ways, cause not established)
     const uint32_t head_rounds = GROOT_SMALL_CHUNK_SHARE(n_rounds) | 1u;
@@ -1145,8 +1168,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             c |= u << 28;
         }
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-        chunk_len = (c >> 28) * 64u;
-        if (chunk_len > 64u) head_done = true;
+        chunk_len = (c >> 28) * U;
+        if (chunk_len > U) head_done = true;
         return c & 0x0FFFFFFFu;
     };
     uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor: first round of the chunk, slots used
@@ -1271,7 +1294,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             // orientation class), so lanes that start together do near-identical work and share phases.
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
-            if (cw >= (int)a.refill || (cw && !(bf | bs | bd))) {
+            if (cw >= (int)((64u - U) + a.refill * U / 64u) || (cw && !(bf | bs | bd))) {
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
                 if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
@@ -1279,7 +1302,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
 #elif defined(GROOT_WORK_COUNTERS)
                 wc_round0 = wc_iter;
 #endif
-                const uint64_t base = (uint64_t)chunk_j * 64u;
+                const uint64_t base = (uint64_t)chunk_j * U;
                 if (base >= n_todo) {                          // this wave's share is used up
                     if (phase == PH_WAIT) phase = PH_DONE;
                 } else {
@@ -1684,6 +1707,21 @@ __global__ __launch_bounds__(kBlock) void add_u32_kernel(uint32_t *__restrict__ 
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] += src[i];
 }
 
+// the seed stage's histogram of IncrementSubPath calls of tabulated reads (SeedArgs::tab_hist) -> the row of their kmerCount in the
+// call-count table; after assign_q_rows_kernel, when the row exists and the batch's overflow flags are known.  Zeroes the histogram.
+__global__ __launch_bounds__(kBlock) void fold_tab_hist_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ attempts, const uint32_t *__restrict__ q_row,
+                                                               uint32_t q_tab, uint32_t n_windows, const DeviceCounters *ctr, uint32_t update_weights)
+{
+    const bool live = update_weights && !(ctr->flags & (kFlagSeedOverflow | kFlagQOverflow));
+    const uint32_t row = live ? q_row[q_tab] : kEmpty;
+    for (uint32_t w = blockIdx.x * kBlock + threadIdx.x; w < n_windows; w += gridDim.x * kBlock) {
+        const uint32_t v = hist[w];
+        if (!v) continue;
+        hist[w] = 0;
+        if (row != kEmpty) attempts[(size_t)row * n_windows + w] += v;
+    }
+}
+
 // ---- ordering: (read, ord) order without a sort -------------------------------------------------
 // off = exclusive scan of trav_cnt (rocprim); record (r, ord) lands at off[r] + ord.
 __global__ void order_total_kernel(const uint32_t *off, const uint32_t *cnt, uint32_t n, DeviceCounters *ctr)
@@ -1713,7 +1751,9 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
     const bool live = !(ctr->flags & (kFlagSeedOverflow | kFlagQOverflow));
     // (grid-stride: the three counter atomics per workgroup below share one line, ~7 ns each -- a few thousand workgroups, not 40 000)
     for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
-    const uint32_t ti = t.tab_idx ? t.tab_idx[r] : kEmpty;
+    const uint32_t tw = t.tab_idx ? t.tab_idx[r] : kEmpty;
+    const uint32_t ti = tw == kEmpty ? kEmpty : tw & ~kTabCounted;
+    const bool count_here = (t.update_weights & 1u) && !(tw & kTabCounted);   // (else the seed stage counted the read's calls)
     if (ti != kEmpty && live) {
         const uint32_t nt = cnt[r], i = off[r];
         const bool fits = i < cap && nt <= cap - i;
@@ -1723,7 +1763,7 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             const uint4 *e = t.out_tab + (size_t)(ti + j) * t.stride_q;
             const uint4 h = e[0];                          // node, offset, graph, flags | multimapped << 8 | records << 16
             const uint4 x = e[1];                          // two call-count windows, first path word
-            if (t.update_weights) {
+            if (count_here) {
                 if (x.x != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.x], 1u);
                 if (x.y != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.y], 1u);
             }
@@ -1733,8 +1773,15 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             tr.read_id = t.first_read_id + r; tr.graph_id = h.z; tr.node = h.x; tr.offset = h.y;
             tr.ord = (uint16_t)j; tr.flags = (uint8_t)h.w; tr.reserved = 0;
             out[i + j] = tr;
-            const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
-            for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)(i + j) * pw_out + w] = (uint64_t)ew[2 * w] | ((uint64_t)ew[2 * w + 1] << 32);
+            uint64_t *mo = mask_out + (size_t)(i + j) * pw_out;
+            mo[0] = (uint64_t)x.z | ((uint64_t)x.w << 32);
+            if (pw_out > 1) {
+                const uint4 y = e[2];
+                mo[1] = (uint64_t)y.x | ((uint64_t)y.y << 32);
+                if (pw_out > 2) mo[2] = (uint64_t)y.z | ((uint64_t)y.w << 32);
+                const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
+                for (uint32_t w = 3; w < pw_out; w++) mo[w] = (uint64_t)ew[2 * w] | ((uint64_t)ew[2 * w + 1] << 32);
+            }
         }
     } else if (ti == kEmpty && cnt[r] != 0) {
         const uint32_t i = off[r];

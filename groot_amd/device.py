@@ -58,7 +58,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = _ffi.lib_path("libgroot_hip.so")
+        path = os.environ.get("GROOT_HIP_LIB") or _ffi.lib_path("libgroot_hip.so")   # (GROOT_HIP_LIB: instrumented builds, tools/)
         if not os.path.exists(path):
             raise ImportError(f"{path} missing: the HIP extension was not built (python -c 'import __graft_entry__ as g; g.build()')")
         L = C.CDLL(path)
