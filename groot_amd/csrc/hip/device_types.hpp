@@ -36,7 +36,7 @@ struct DeviceCounters {
     unsigned int mask_words;    // 64-bit words of the compact path sets of this batch (mask_compact_kernel)
     unsigned int todo_reads;    // reads sketch_sig_kernel handed to the full-width kernel (0 when that kernel ran alone)
     unsigned int seeded_reads;  // reads with at least one seed whose alignment is not tabulated: the align stage's share of the processing order (they sort first)
-    unsigned int pad3;
+    unsigned int tab_reads;     // reads the signature kernel answered from the outcome table
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };
@@ -96,16 +96,19 @@ static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
 //   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | sam.Records of the whole read << 16
 //   [4],[5] windows whose IncrementSubPath the read triggers (kEmpty = none; a string's calls are spread over its entries)
 //   [6..] path set, pw 64-bit words (lo, hi)
-constexpr uint32_t kOutHdrDw = 6;
+//   last four dwords of the entry: seed windows of the read (kEmpty = none; spread over the string's entries like the calls)
+constexpr uint32_t kOutHdrDw = 6, kOutSeedDw = 4;
 constexpr uint32_t kOutTab = 0x80000000u;                  // sig_info: the string's outcome is tabulated
 constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 26, kOutTravShift = 27;
 constexpr uint32_t kOutAllSeeds = 1u << 26;                // sig_info: ... and IncrementSubPath is called exactly once for each of the read's seed windows
+constexpr uint32_t kTodo = 0xFFFFFFFEu;                    // SeedArgs::tab_idx: text_lookup_kernel leaves the read to the full-width kernel
+constexpr uint32_t kTabSeedsHere = 0x40000000u;            // SeedArgs::tab_idx: text_lookup_kernel answered the read; order_first_kernel writes its seeds too
 constexpr uint32_t kTabCounted = 0x80000000u;              // SeedArgs::tab_idx: the seed stage has counted the read's IncrementSubPath calls
 // (entries are padded to a power of two of at least 64 bytes: a gather touches one 64-byte sector, never two)
 __host__ __device__ inline uint32_t out_stride_q(uint32_t pw)
 {
     uint32_t q = 4;
-    while (q * 16 < kOutHdrDw * 4 + 8 * pw) q <<= 1;
+    while (q * 16 < (kOutHdrDw + kOutSeedDw) * 4 + 8 * pw) q <<= 1;
     return q;
 }
 
@@ -177,6 +180,9 @@ struct DeviceIndex {
     // words per entry, entries of a string back to back in `ord` order
     const uint4 *out_tab;
     uint32_t out_stride_q;
+    // text_lookup_kernel: window-text strings with a tabulated outcome, keyed by their bases (open addressing, text_mask + 1 entries of 64 bytes); null = none
+    const uint4 *text_tab;
+    uint32_t text_mask;
     const uint8_t *win_nodes;       // [n_windows] min(255, contained nodes of the window): the span class of the scheduling key
 };
 

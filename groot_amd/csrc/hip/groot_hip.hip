@@ -76,6 +76,7 @@ struct Slot {
     uint32_t n_reads = 0, first_read_id = 0, max_len = 0;
     uint32_t uniform_len = 0;              // IN_PACKED16: every read has this length (0 = lengths differ): no length array on the wire
     bool mixed_len = false;                // the reads are known to differ in length (the align stage then refills its wavefronts earlier)
+    bool text_used = false;                // text_lookup_kernel ran first (the list behind it goes through the full-width kernel)
     bool sig_used = false;                 // the signature kernel ran in front of the full-width kernel for this batch
     bool one_len = false;                  // the reads are known to have max_len bases each, or the caller said so (submit_device with max_len)
     uint64_t n_bases = 0, n_exc = 0;
@@ -147,6 +148,9 @@ struct groot_ctx {
     double out_build_ms = 0;
     bool tab_capture = false;              // the capture pass of groot_hip_open is running (align stage records the IncrementSubPath windows)
     DevBuf<uint32_t> tab_idx, tab_hist, incr_cnt, incr_win;
+    DevBuf<uint4> text_tab;                // text_lookup_kernel: strings with a tabulated outcome, keyed by their bases
+    uint64_t text_entries = 0;
+    double text_hit_frac = 1.0;            // share of the latest batch's reads the outcome table answered: picks the first kernel of the seed stage
     std::vector<uint16_t> h_q_min_eq;      // host copy of DeviceIndex::q_min_eq: which seed kernel a batch of one read length gets
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
@@ -484,6 +488,20 @@ template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, uint32_t m
     else hipLaunchKernelGGL((sketch_sig_kernel<S, M5, (int)kTextMax / 16>), grid, dim3(kBlock), lds, st, a);
     hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
 }
+template <int S, int M5> static void launch_list_sm(const SeedArgs &a, dim3 list_grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
+}
+static void launch_list(uint32_t s, const SeedArgs &a, dim3 list_grid, hipStream_t st)
+{
+    const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
+    if (s == 21 && m5 == 6) return launch_list_sm<21, 6>(a, list_grid, st);
+    if (s == 21 && m5 == 10) return launch_list_sm<21, 10>(a, list_grid, st);
+    if (s == 21 && m5 == 14) return launch_list_sm<21, 14>(a, list_grid, st);
+    if (s == 21 && m5 == 2) return launch_list_sm<21, 2>(a, list_grid, st);
+    if (s == 20 && m5 == 6) return launch_list_sm<20, 6>(a, list_grid, st);
+    if (s == 30 && m5 == 14) return launch_list_sm<30, 14>(a, list_grid, st);
+}
 static bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
 {
     const uint32_t m5 = (uint32_t)(((uint64_t)k * GROOT_MULTI_SEED) & 31u);
@@ -570,6 +588,10 @@ static int grow_attempts(groot_ctx *c, uint32_t rows)
     return GROOT_OK;
 }
 
+struct IsTodo {     // reads text_lookup_kernel left to the full-width kernel
+    const uint32_t *tab_idx;
+    __host__ __device__ bool operator()(uint32_t r) const { return tab_idx[r] == kTodo; }
+};
 struct HasKey {     // reads the seed stage left for the align stage's graph walk carry a scheduling key
     const uint32_t *key;
     __host__ __device__ bool operator()(uint32_t r) const { return key[r] != kEmpty; }
@@ -617,7 +639,31 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         sig_useful = q < c->h_q_min_eq.size() && c->h_q_min_eq[q] == c->s;
     }
     s->sig_used = c->dix.sig && !c->prm.keep_sketches && sig_useful;
-    if (s->sig_used) {
+    // Which kernel sees the batch first?  When the outcome table answered most of the latest batch, the text lookup (no hashing at
+    // all; what it does not find goes through the full-width kernel, read by read); else the signature kernel as before.
+    s->text_used = s->sig_used && c->dix.text_tab && c->dix.out_tab && c->text_hit_frac >= 0.7 && s->max_len >= c->dix.w;
+    if (s->text_used) {
+        a.todo_list = c->todo_list.p;
+        a.todo_count = c->todo_count.p;
+        const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;
+        a.list_stride_dw = (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
+        const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
+        if (c->dix.w <= 128) hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a);
+        else hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+        {   // the reads it marked, as a list
+            size_t tb = 0;
+            IsTodo pred{c->tab_idx.p};
+            rocprim::counting_iterator<uint32_t> ids(0u);
+            HIP_TRY(c, rocprim::select(nullptr, tb, ids, c->todo_list.p, c->todo_count.p, (size_t)s->n_reads, pred, c->stream));
+            if (tb > c->sort_tmp.n) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, c->sort_tmp.alloc(tb + tb / 4));
+            }
+            HIP_TRY(c, rocprim::select(c->sort_tmp.p, tb, ids, c->todo_list.p, c->todo_count.p, (size_t)s->n_reads, pred, c->stream));
+        }
+        launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
+    } else if (s->sig_used) {
         // signature kernel first; what it cannot decide goes through the full-width kernel, read by read
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
@@ -731,6 +777,7 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
     hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, s->d_ctr.p);
     OrderTabArgs ot{};
     if (c->dix.out_tab) {
+        ot.seed_count = c->seed_count.p; ot.seed_win = c->seed_win.p; ot.seed_slots = c->seed_slots;
         ot.tab_idx = c->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
         ot.update_weights = update_weights ? 1 : 0;
         if (getenv("GROOT_EXP_NOATOM")) ot.update_weights <<= 1;   // experiments: everything but the call-count atomics
@@ -1028,7 +1075,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
             merged.flags = keep | again.flags;
             merged.q_rows = again.q_rows;
             merged.mask_words = again.mask_words;
-            merged.todo_reads = again.todo_reads;
+            merged.todo_reads = again.todo_reads; merged.tab_reads = again.tab_reads;
             h = merged;
         } else h = again;
     }
@@ -1071,6 +1118,8 @@ static int finish_counters(groot_ctx *c, Slot *s)
     // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
     if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
     if (s->n_reads && !c->tab_capture) c->dfs_frac = (double)h.seeded_reads / (double)s->n_reads;
+    if (s->n_reads && !c->tab_capture && c->dix.text_tab)
+        c->text_hit_frac = s->text_used ? 1.0 - (double)h.todo_reads / (double)s->n_reads : (double)h.tab_reads / (double)s->n_reads;
     s->n_mask_words = s->n_trav ? h.mask_words : 0;
     if (!c->prm.results_on_device && s->n_trav) {
         c->words_per_trav = (double)s->n_mask_words / (double)s->n_trav;
@@ -1279,6 +1328,11 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
     std::vector<groot_trav> travs;
     std::vector<uint64_t> masks;
     std::vector<uint32_t> icnt, iwin, nseeds, seedw;
+    uint32_t seed_rows = 0;
+    std::vector<uint32_t> text_recs;                       // 16 dwords per string: 0, sig_info word, packed bases
+    // (the text table serves reads of exactly WindowSize bases whose kmerCount puts Query on the every-slot-equal branch)
+    const uint32_t q_w = w - c->k + 1;
+    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && c->h_q_min_eq[q_w] == c->s && !getenv("GROOT_NO_TEXT_TABLE");
     c->out_strings = c->out_tabulated = c->out_entries = 0;
     int rc_all = GROOT_OK;
     auto flush = [&]() -> int {
@@ -1303,9 +1357,10 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
                 HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
                 HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
             }
-            nseeds.resize(m); seedw.resize((size_t)4 * m);
+            seed_rows = std::min<uint32_t>(kOutSeedDw * kOutMaxTrav, c->seed_slots);
+            nseeds.resize(m); seedw.resize((size_t)seed_rows * m);
             HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, std::min<uint32_t>(4, c->seed_slots), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * kIncrCap * 4, hipMemcpyDeviceToHost));
         }
@@ -1321,6 +1376,9 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
                 for (size_t t = t0; t < t1; t++)
                     for (uint32_t x = 0; x < pw; x++) recs += (uint64_t)__builtin_popcountll(masks[t * pw + x]);
                 const size_t first = tab.size() / (sq * 4);
+                // (its seed windows travel in the entries too when they fit: what text_lookup_kernel's reads report as their seeds)
+                const uint32_t nsd = nseeds[j] & 0x7FFFFFFFu;
+                const bool seeds_fit = nsd <= std::min<uint32_t>(kOutSeedDw * cnt, c->seed_slots) && nsd <= seed_rows;
                 if (cnt >= 1 && cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(kIncrCap, 2 * cnt) && recs <= 0xFFFFu && first + cnt < (1u << kOutIdxBits)) {
                     for (uint32_t e = 0; e < cnt; e++) {
                         const groot_trav &t = travs[t0 + e];
@@ -1330,6 +1388,8 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
                         tab[b + 3] = (uint32_t)t.flags | (e == 0 && (icnt[j] >> 31) ? 0x100u : 0u) | (e == 0 ? (uint32_t)recs << 16 : 0u);
                         tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * kIncrCap + 2 * e] : kEmpty;
                         tab[b + 5] = 2 * e + 1 < ni ? iwin[(size_t)j * kIncrCap + 2 * e + 1] : kEmpty;
+                        for (uint32_t x = 0; x < kOutSeedDw; x++)
+                            tab[b + sq * 4 - kOutSeedDw + x] = seeds_fit && kOutSeedDw * e + x < nsd ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
                         for (uint32_t x = 0; x < pw; x++) {
                             tab[b + kOutHdrDw + 2 * x] = (uint32_t)masks[(t0 + e) * pw + x];
                             tab[b + kOutHdrDw + 2 * x + 1] = (uint32_t)(masks[(t0 + e) * pw + x] >> 32);
@@ -1344,6 +1404,13 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
                         all_seeds = std::equal(a4, a4 + ni, b4) && std::adjacent_find(a4, a4 + ni) == a4 + ni;
                     }
                     info[where[j]] = kOutTab | ((cnt - 1) << kOutTravShift) | (all_seeds ? kOutAllSeeds : 0u) | (uint32_t)first;
+                    if (seeds_fit && text_ok) {            // text_lookup_kernel's table: the string itself, 2 bits per base
+                        const size_t b = text_recs.size();
+                        text_recs.resize(b + 16, 0);
+                        text_recs[b + 1] = info[where[j]];
+                        const uint8_t *sq8 = &seqs[(size_t)j * w];
+                        for (uint32_t x = 0; x < w; x++) text_recs[b + 2 + (x >> 4)] |= (uint32_t)((sq8[x] >> 1) & 3u) << (2 * (x & 15));
+                    }
                     c->out_tabulated++;
                 }
                 t0 = t1;
@@ -1391,6 +1458,35 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
     HIP_TRY(c, hipMemset(c->tab_hist.p, 0, (size_t)c->n_windows * sizeof(uint32_t)));
     c->dix.out_tab = c->out_tab.p;
     c->dix.out_stride_q = sq;
+    if (!text_recs.empty()) {
+        const size_t ns = text_recs.size() / 16;
+        uint32_t cap = 1024;
+        while (cap < 2 * ns) cap <<= 1;
+        std::vector<uint32_t> tt((size_t)cap * 16, 0);
+        const uint32_t tw = (w + 15) / 16;
+        uint64_t kept = 0;
+        for (size_t i = 0; i < ns; i++) {
+            const uint32_t *rec = &text_recs[i * 16];
+            uint64_t h = GROOT_TEXT_HASH_INIT;
+            const uint32_t twk = tw <= 8 ? 8 : 14;         // (the kernel instance hashes its whole register row; dwords past the string are zero)
+            for (uint32_t j = 0; j < twk; j++) h = text_hash_step(h, rec[2 + j]);
+            uint32_t slot = (uint32_t)h & (cap - 1);
+            bool dup = false;
+            for (; tt[(size_t)slot * 16 + 1] != 0; slot = (slot + 1) & (cap - 1))
+                if (tt[(size_t)slot * 16] == (uint32_t)(h >> 32) && !memcmp(&tt[(size_t)slot * 16 + 2], rec + 2, 14 * 4)) { dup = true; break; }
+            if (dup) continue;                              // the same bases in another window: same sketch class, same outcome
+            memcpy(&tt[(size_t)slot * 16], rec, 64);
+            tt[(size_t)slot * 16] = (uint32_t)(h >> 32);
+            kept++;
+        }
+        HIP_TRY(c, c->text_tab.alloc((size_t)cap * 4));
+        HIP_TRY(c, hipMemcpy(c->text_tab.p, tt.data(), (size_t)cap * 64, hipMemcpyHostToDevice));
+        c->dix.text_tab = c->text_tab.p;
+        c->dix.text_mask = cap - 1;
+        c->text_entries = kept;
+    }
+    if (getenv("GROOT_OPEN_STATS"))
+        fprintf(stderr, "[groot open]   text table: %llu distinct strings in %u slots of 64 bytes\n", (unsigned long long)c->text_entries, c->dix.text_mask + 1);
     if (getenv("GROOT_OPEN_STATS"))
         fprintf(stderr, "[groot open]   outcome table: %llu of %llu window-text strings tabulated, %llu entries of %u bytes\n", (unsigned long long)c->out_tabulated,
                 (unsigned long long)c->out_strings, (unsigned long long)c->out_entries, sq * 16);

@@ -198,6 +198,9 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
         atomicMax(sh + 1, (unsigned long long)most);
         atomicAdd(sh + 2, (unsigned long long)seeded);
     }
+    const unsigned long long tb = __ballot(tabulated);
+    if (tb && __builtin_amdgcn_mbcnt_hi((uint32_t)(tb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tb, 0u)) == 0 && tabulated)
+        atomicAdd(a.shards + (size_t)(blockIdx.x % kSeedShards) * kSeedShardStride + 3, (unsigned long long)__popcll(tb));
 }
 
 // What every seed kernel leaves behind for one read once its seed windows are known (n_hits of them, the first four in
@@ -923,6 +926,110 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1+K2+K3 for reads the index has seen before: text_lookup_kernel
+// ---------------------------------------------------------------------------------------------
+// A read that IS one of the window-text strings (bases [o, o + WindowSize) of a text row, either orientation) needs no hashing at
+// all: groot_hip_open proved per string that its KHF sketch is the window's (the full-width kernel sketched every one of them),
+// so ContainmentIndex.Query returns the window's sketch class for it (lshe.go:153-175 at a threshold that needs every slot equal),
+// and the outcome table holds what the graphMinion loop does with it.  The strings with a tabulated outcome whose IncrementSubPath
+// calls are exactly their seed windows sit in a hash table keyed by the TEXT (2 bits per base): one probe, one 64-byte entry holding
+// the text itself -- equality is decided on the bases, never on the hash.  Everything else (no entry: reads with errors, reads
+// from elsewhere, other lengths, bytes other than ACGT) goes onto the list of sketch_seed_kernel<..., LIST>, which hashes it.
+//   entry (64 bytes): [0] tag  [1] DeviceIndex::sig_info word of the string (0 = free slot)  [2..] the string, 16 bases per dword
+__host__ __device__ __forceinline__ uint64_t text_hash_step(uint64_t h, uint32_t dw)
+{
+    h = (h ^ dw) * 0x9E3779B97F4A7C15ULL;
+    return h ^ (h >> 29);
+}
+#define GROOT_TEXT_HASH_INIT 0xD6E8FEB86659FD93ULL
+template <int TW>
+__global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
+{
+    static_assert(TW >= 1 && TW <= 14, "a 64-byte entry holds 224 bases");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *badbits = reinterpret_cast<uint32_t *>(smem + kSigBad);
+    uint32_t *codes = reinterpret_cast<uint32_t *>(smem + kSigCodes);
+    const DeviceIndex &ix = a.ix;
+    const unsigned tid = threadIdx.x;
+    if (tid < 128) badbits[tid] = 0;
+    // ---- stage this block's reads as 2-bit codes (as sketch_sig_kernel does): one contiguous span, 16 bases per lane per load ----
+    const uint32_t r0 = blockIdx.x * kBlock;
+    const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
+    const uint64_t span0 = a.seq_off[r0], span1 = a.seq_off[r_end];
+    const uint64_t base16 = span0 & ~15ULL;
+    const uint64_t span_bytes = span1 - base16;
+    const bool in_lds = span_bytes <= a.lds_read_bytes;
+    __syncthreads();
+    if (in_lds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
+        const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
+        for (uint32_t i = tid; i < n16; i += kBlock) {
+            const uint4 v = src[i];
+            uint32_t bad = 0;
+            const uint32_t c = codes_of4(v.x, bad) | (codes_of4(v.y, bad) << 8) | (codes_of4(v.z, bad) << 16) | (codes_of4(v.w, bad) << 24);
+            codes[i] = c;
+            if (bad) atomicOr(&badbits[i >> 5], 1u << (i & 31));
+        }
+    }
+    __syncthreads();
+    const uint32_t r = r0 + tid;
+    if (r >= a.n_reads) return;
+    const uint64_t o0 = a.seq_off[r];
+    const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
+    bool mine = in_lds && len == ix.w;
+    if (mine) {
+        const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
+        for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
+            uint32_t bits = badbits[w];
+            if (w == c0 >> 5) bits &= ~0u << (c0 & 31);
+            if (w == c1 >> 5) bits &= ~0u >> (31 - (c1 & 31));
+            if (bits) mine = false;
+        }
+    }
+    // (no list atomics here: one counter for all wavefronts would cost more than this kernel; a stream compaction of the marks follows)
+    if (!mine) { a.tab_idx[r] = kTodo; return; }
+    const uint32_t P = 2u * (uint32_t)(o0 - base16);       // bit position of base 0 in `codes`
+    const uint32_t n_full = len >> 4, tail_mask = (1u << (2 * (len & 15))) - 1u;
+    uint32_t rdw[TW];
+    uint64_t h = GROOT_TEXT_HASH_INIT;
+#pragma unroll
+    for (int j = 0; j < TW; j++) {
+        const uint32_t mask = (uint32_t)j < n_full ? ~0u : ((uint32_t)j == n_full ? tail_mask : 0u);
+        rdw[j] = __builtin_amdgcn_alignbit(codes[(P >> 5) + j + 1], codes[(P >> 5) + j], P & 31) & mask;
+        h = text_hash_step(h, rdw[j]);
+    }
+    const uint32_t tag = (uint32_t)(h >> 32);
+    const uint4 *tab = ix.text_tab;
+    uint32_t info = 0;
+    for (uint32_t slot = (uint32_t)h & ix.text_mask;; slot = (slot + 1) & ix.text_mask) {
+        const uint4 *e = tab + (size_t)slot * 4;
+        constexpr int NQ = (2 + TW + 3) / 4;               // 16-byte words of an entry that hold something
+        uint32_t ed[4 * NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const uint4 v = e[i];
+            ed[4 * i] = v.x; ed[4 * i + 1] = v.y; ed[4 * i + 2] = v.z; ed[4 * i + 3] = v.w;
+        }
+        // the whole entry in ONE round trip (left alone the compiler loads the tag, tests it, and only then fetches the text)
+#pragma unroll
+        for (int i = 0; i < 4 * NQ; i++) asm volatile("" : "+v"(ed[i]));
+        if (ed[1] == 0) break;                             // free slot: the string is not in the table
+        if (ed[0] != tag) continue;
+        uint32_t diff = 0;
+#pragma unroll
+        for (int j = 0; j < TW; j++) diff |= ed[2 + j] ^ rdw[j];
+        if (!diff) { info = ed[1]; break; }
+    }
+    if (!info) { a.tab_idx[r] = kTodo; return; }
+    // the read's whole outcome is tabulated; order_first_kernel writes its seeds, its records and its call counts from the table
+    const uint32_t q = len - ix.k + 1;
+    if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;
+    a.sort_key[r] = kEmpty;
+    a.tab_idx[r] = (info & ((1u << kOutIdxBits) - 1u)) | kTabSeedsHere;
+    a.trav_cnt[r] = ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
+}
+
 // groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
 // thread (one 4-byte load, one 16-byte store); bytes other than ACGT are patched in from the exception list afterwards
 __global__ __launch_bounds__(kBlock) void unpack_reads_kernel(const uint32_t *__restrict__ packed, uint64_t n_words, uint4 *__restrict__ out)
@@ -961,23 +1068,26 @@ __global__ __launch_bounds__(64) void assign_q_rows_kernel(uint32_t *q_seen, uin
     if (blockIdx.x) return;
     const uint32_t lane = threadIdx.x;
     {
-        unsigned long long seeds = 0, most = 0, seeded = 0;
+        unsigned long long seeds = 0, most = 0, seeded = 0, tabbed = 0;
         for (uint32_t i = lane; i < kSeedShards; i += 64) {
             unsigned long long *sh = shards + (size_t)i * kSeedShardStride;
             seeds += sh[0];
             most = sh[1] > most ? sh[1] : most;
             seeded += sh[2];
-            sh[0] = 0; sh[1] = 0; sh[2] = 0;
+            tabbed += sh[3];
+            sh[0] = 0; sh[1] = 0; sh[2] = 0; sh[3] = 0;
         }
         for (int o = 32; o; o >>= 1) {
             seeds += __shfl_xor(seeds, o);
             seeded += __shfl_xor(seeded, o);
+            tabbed += __shfl_xor(tabbed, o);
             const unsigned long long other = __shfl_xor(most, o);
             most = other > most ? other : most;
         }
         if (!lane) {
             ctr->seeds += seeds;
             ctr->seeded_reads += (unsigned int)seeded;
+            ctr->tab_reads += (unsigned int)tabbed;
             if (most > ctr->max_seeds) ctr->max_seeds = (unsigned int)most;
         }
     }
@@ -1733,6 +1843,8 @@ __global__ void order_total_kernel(const uint32_t *off, const uint32_t *cnt, uin
 // entries from tab_idx[r] on --, and this kernel does what the align stage does for the others: the IncrementSubPath call counts
 // (graphminion.go:60-67) and the read / alignment counters (boss.go:195-200).
 struct OrderTabArgs {
+    uint32_t *seed_count, *seed_win;   // [n], [slots][n]: written here for the reads text_lookup_kernel answered (kTabSeedsHere)
+    uint32_t seed_slots;
     const uint32_t *tab_idx;     // [n] or null
     const uint4 *out_tab;
     uint32_t stride_q, first_read_id;
@@ -1746,14 +1858,16 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
                                                            uint32_t cap, uint32_t pw_in, uint32_t pw_out, DeviceCounters *ctr, OrderTabArgs t)
 {
     __shared__ unsigned long long red[4];
-    unsigned long long alns = 0, mapped = 0, multimapped = 0;
+    unsigned long long alns = 0, mapped = 0, multimapped = 0, seeds = 0;
     // (a pass whose seed stage ran out of slots / table rows is repeated as a whole: nothing may be counted in it)
     const bool live = !(ctr->flags & (kFlagSeedOverflow | kFlagQOverflow));
     // (grid-stride: the three counter atomics per workgroup below share one line, ~7 ns each -- a few thousand workgroups, not 40 000)
     for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
     const uint32_t tw = t.tab_idx ? t.tab_idx[r] : kEmpty;
-    const uint32_t ti = tw == kEmpty ? kEmpty : tw & ~kTabCounted;
+    const uint32_t ti = tw == kEmpty ? kEmpty : tw & ((1u << kOutIdxBits) - 1u);
     const bool count_here = (t.update_weights & 1u) && !(tw & kTabCounted);   // (else the seed stage counted the read's calls)
+    const bool seeds_here = tw != kEmpty && (tw & kTabSeedsHere);              // its seed windows are the table's call-count windows
+    uint32_t ns = 0;
     if (ti != kEmpty && live) {
         const uint32_t nt = cnt[r], i = off[r];
         const bool fits = i < cap && nt <= cap - i;
@@ -1766,6 +1880,13 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             if (count_here) {
                 if (x.x != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.x], 1u);
                 if (x.y != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.y], 1u);
+            }
+            if (seeds_here) {
+                const uint4 sd = e[t.stride_q - 1];
+                if (sd.x != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.x; ns++; }
+                if (sd.y != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.y; ns++; }
+                if (sd.z != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.z; ns++; }
+                if (sd.w != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.w; ns++; }
             }
             if (j == 0) { alns += h.w >> 16; mapped++; multimapped += (h.w >> 8) & 1u; }
             if (!fits) continue;
@@ -1783,6 +1904,7 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
                 for (uint32_t w = 3; w < pw_out; w++) mo[w] = (uint64_t)ew[2 * w] | ((uint64_t)ew[2 * w + 1] << 32);
             }
         }
+        if (seeds_here) { t.seed_count[r] = ns; seeds += ns; }
     } else if (ti == kEmpty && cnt[r] != 0) {
         const uint32_t i = off[r];
         if (i >= cap) atomicOr(&ctr->flags, kFlagTravOverflow);
@@ -1796,8 +1918,10 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
     alns = block_sum(alns, red);
     mapped = block_sum(mapped, red);
     multimapped = block_sum(multimapped, red);
+    seeds = block_sum(seeds, red);
     if (threadIdx.x == 0) {
         if (alns) atomicAdd(&ctr->alignments, alns);
+        if (seeds) atomicAdd(&ctr->seeds, seeds);
         if (t.update_weights) {
             if (mapped) atomicAdd(&ctr->mapped, mapped);
             if (multimapped) atomicAdd(&ctr->multimapped, multimapped);
