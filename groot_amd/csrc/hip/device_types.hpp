@@ -93,13 +93,15 @@ static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
 // produce for a read that IS bases [o, o + WindowSize) of a window text row -- every such read is the same string with the same seed
 // windows, so the outcome is a function of (window, row, o) and the ctx works it out once, at open, by running the align stage itself
 // on the string.  One entry per traversal record:
-//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | sam.Records of the whole read << 16
+//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | mapped << 9 | sam.Records of the whole read << 16
+//       (a string without any traversal has one entry with node = kEmpty: its calls, its seeds, its counters)
 //   [4],[5] windows whose IncrementSubPath the read triggers (kEmpty = none; a string's calls are spread over its entries)
 //   [6..] path set, pw 64-bit words (lo, hi)
 //   last four dwords of the entry: seed windows of the read (kEmpty = none; spread over the string's entries like the calls)
 constexpr uint32_t kOutHdrDw = 6, kOutSeedDw = 4;
 constexpr uint32_t kOutTab = 0x80000000u;                  // sig_info: the string's outcome is tabulated
-constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 26, kOutTravShift = 27;
+constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 25, kOutTravShift = 27;
+constexpr uint32_t kOutNoRec = 1u << 25;                   // sig_info: the string has seed windows (or none) but AlignRead reports nothing for it: one entry, no record
 constexpr uint32_t kOutAllSeeds = 1u << 26;                // sig_info: ... and IncrementSubPath is called exactly once for each of the read's seed windows
 constexpr uint32_t kTodo = 0xFFFFFFFEu;                    // SeedArgs::tab_idx: text_lookup_kernel leaves the read to the full-width kernel
 constexpr uint32_t kTabSeedsHere = 0x40000000u;            // SeedArgs::tab_idx: text_lookup_kernel answered the read; order_first_kernel writes its seeds too
@@ -141,6 +143,9 @@ struct DeviceIndex {
     // per window: which read prefixes (6-mer codes of oriented bases [0,6) and [6,12), 2 bits per base A=0 C=1 T=2 G=3)
     // can be spelled from any level-1 / level-2 start position of AlignRead (alignment.go:34-70): 2 x 4096 bits
     const uint32_t *win_prefix;
+    // per node: which 4-mers (2 bits per base) can be spelled from its offsets 0..10 (level 2 of AlignRead, alignment.go:47-70), the
+    // graph's 'N' and the bases past the node's end counting as wildcards: 256 bits; null = none
+    const uint32_t *node_pre4;
     // lookup structures
     const ExactEntry *exact;        // open addressing, exact_mask+1 slots
     uint32_t exact_mask;
@@ -173,7 +178,7 @@ struct DeviceIndex {
     // the same string): verdict bits (kRecNo* >> 24, both orientations) | dead-orientation class << 6, as the full-width kernel
     // produced them for exactly that string when the ctx was opened -- [(window * 2 + row) * sig_verdict_stride + o]; null = none
     // One u32 per such string since round 3.  Bit 31 clear: bits 0..7 = that verdict byte.  Bit 31 set: the whole outcome of the
-    // graphMinion loop for the string is tabulated (kOutTab): bits 27..30 = traversals - 1, bit 26 = kOutAllSeeds, bits 0..25 = index of its first OutEntry.
+    // graphMinion loop for the string is tabulated (kOutTab): bits 27..30 = traversals - 1, bit 26 = kOutAllSeeds, bit 25 = kOutNoRec, bits 0..24 = index of its first OutEntry.
     const uint32_t *sig_info;
     uint32_t sig_verdict_stride;
     // AlignRead outcomes of window-text strings (groot_hip_open ran the align stage on every one of them): out_stride_q 16-byte

@@ -129,6 +129,7 @@ struct groot_ctx {
 
     // index in HBM
     DevBuf<uint32_t> graph_win_end;
+    DevBuf<uint32_t> node_pre4;
     DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
         band_keys, band_ids;
     DevBuf<ExactEntry> band_hash;
@@ -780,7 +781,7 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
         ot.seed_count = c->seed_count.p; ot.seed_win = c->seed_win.p; ot.seed_slots = c->seed_slots;
         ot.tab_idx = c->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
         ot.update_weights = update_weights ? 1 : 0;
-        if (getenv("GROOT_EXP_NOATOM")) ot.update_weights <<= 1;   // experiments: everything but the call-count atomics
+        if (const char *e = getenv("GROOT_EXP_ORDER")) ot.exp = (uint32_t)atoi(e);   // experiments
         ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
         ot.q_tab = c->dix.w - c->k + 1; ot.n_windows = c->n_windows;
     }
@@ -1302,19 +1303,124 @@ static int enqueue(groot_ctx *c, Slot *s);
 static int collect_impl(groot_ctx *c, Slot **out);
 static int take_slot(groot_ctx *c, uint32_t n_reads, Slot **out);
 
-// Outcome table (DeviceIndex::out_tab, device_types.hpp OutEntry).  A read the signature kernel confirms by text IS bases
-// [o, o + WindowSize) of a window text row, and every such read brings the same seed windows (the row's sketch class): what the
-// graphMinion loop does with it -- which windows get IncrementSubPath, which traversals AlignRead reports, in which order
-// (graphminion.go:46-102, alignment.go:13-159) -- is a function of the string.  So the strings go through this ctx's own pipeline
-// once, as ordinary batches (signature kernel -> sort -> align_kernel -> ordering), the align stage additionally noting the windows
-// it counted, and every string with 1..16 traversals gets its records stored.  At run time such reads never reach the align stage.
-static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, const std::vector<uint32_t> &tlen, std::vector<uint32_t> &info,
-                               uint32_t w, uint32_t vstride)
+// Outcome table (DeviceIndex::out_tab, device_types.hpp OutEntry) and text table (DeviceIndex::text_tab).
+// What this ctx does with a read -- which windows ContainmentIndex.Query returns, which of them get IncrementSubPath, which
+// traversals AlignRead reports, in which order (lshe.go:153-175, graphminion.go:46-102, alignment.go:13-159) -- is a function of
+// the read's bases alone.  So the strings real reads are most likely to BE, every WindowSize-mer of every indexed sequence path on
+// both strands, go through the ctx's own pipeline once, as ordinary batches (signature kernel -> full-width kernel -> sort ->
+// align_kernel -> ordering), the align stage additionally noting the windows it counted, and every string with 1..16 traversals gets
+// its records stored: a memo of the pipeline's own results, nothing else.  At run time a read that equals such a string is
+// answered by text_lookup_kernel (keyed by the bases) or by the signature kernel (sig_info of the window-text strings, which are
+// path strings too) and never reaches the align stage.
+namespace {
+struct StringSet {                          // distinct strings at 2 bits per base, tw dwords each; open addressing over their hashes
+    uint32_t tw = 0;
+    std::vector<uint32_t> words;            // [n * tw]
+    std::vector<uint32_t> slots;            // index + 1, 0 = free
+    size_t n = 0;
+    uint32_t mask = 0;
+    void init(uint32_t tw_, size_t expect)
+    {
+        tw = tw_;
+        uint32_t cap = 1024;
+        while (cap < 2 * expect) cap <<= 1;
+        slots.assign(cap, 0);
+        mask = cap - 1;
+        words.reserve(expect * tw);
+    }
+    static uint64_t hash(const uint32_t *w, uint32_t tw)
+    {
+        uint64_t h = GROOT_TEXT_HASH_INIT;
+        for (uint32_t j = 0; j < tw; j++) h = text_hash_step(h, w[j]);
+        return h;
+    }
+    // index of the string, inserting it if `insert`; -1 if absent
+    long find(const uint32_t *w, bool insert)
+    {
+        const uint64_t h = hash(w, tw);
+        for (uint32_t s = (uint32_t)(h ^ (h >> 32)) & mask;; s = (s + 1) & mask) {
+            if (!slots[s]) {
+                if (!insert) return -1;
+                words.insert(words.end(), w, w + tw);
+                slots[s] = (uint32_t)++n;
+                return (long)n - 1;
+            }
+            if (!memcmp(&words[(size_t)(slots[s] - 1) * tw], w, (size_t)tw * 4)) return (long)slots[s] - 1;
+        }
+    }
+};
+// bases [i, i + len) of a sequence packed at 2 bits per base (16 per dword, trailing dwords zero-padded)
+inline void pack_at(const std::vector<uint32_t> &packed, size_t i, uint32_t len, uint32_t tw, uint32_t *out)
 {
+    const size_t d = i >> 4;
+    const uint32_t sh = 2 * (uint32_t)(i & 15);
+    for (uint32_t j = 0; j < tw; j++) {
+        const uint64_t two = (uint64_t)packed[d + j] | ((uint64_t)packed[d + j + 1] << 32);
+        out[j] = (uint32_t)(two >> sh);
+    }
+    const uint32_t full = len >> 4, tail = len & 15;
+    if (full < tw) out[full] &= tail ? (1u << (2 * tail)) - 1u : 0u;
+    for (uint32_t j = full + 1; j < tw; j++) out[j] = 0;
+}
+} // namespace
+
+static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const std::vector<uint8_t> &text, const std::vector<uint32_t> &tlen,
+                               std::vector<uint32_t> &info, uint32_t w, uint32_t vstride)
+{
+    const bool stats = getenv("GROOT_OPEN_STATS") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!stats) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[groot open]     memo: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     const uint32_t n = c->n_windows, pw = c->pw_view;
     const uint32_t sq = out_stride_q(pw);
+    const uint32_t tw = (w + 15) / 16;
     const uint32_t chunk = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(c->prm.max_batch_reads, 1u << 20), c->prm.max_batch_bases / w);
     if (!chunk) return GROOT_OK;
+    // ---- 1. the strings: every WindowSize-mer of every path, both strands, each once ----
+    StringSet set;
+    {
+        uint64_t expect = 0;
+        for (uint32_t p = 0; p < v->n_paths; p++) expect += v->path_len[p] >= w ? 2 * (uint64_t)(v->path_len[p] - w + 1) : 0;
+        set.init(tw, (size_t)std::min<uint64_t>(expect, 1ull << 30));
+        std::vector<uint8_t> seq;
+        std::vector<uint32_t> pk[2];
+        std::vector<uint32_t> bad_before[2];                // number of bytes other than ACGT before position i
+        uint32_t buf[16];
+        for (uint32_t g = 0; g < v->n_graphs; g++)
+            for (uint32_t lp = 0; lp < v->graph_path_off[g + 1] - v->graph_path_off[g]; lp++) {
+                seq.clear();
+                for (uint32_t node = v->graph_node_off[g]; node < v->graph_node_off[g + 1]; node++) {   // a path visits its nodes in ascending order (graph.go:243-262)
+                    if (!((v->node_mask[(size_t)node * v->path_words + (lp >> 6)] >> (lp & 63)) & 1ULL)) continue;
+                    seq.insert(seq.end(), v->bases + v->node_seq_off[node], v->bases + v->node_seq_off[node + 1]);
+                }
+                const size_t L = seq.size();
+                if (L < w) continue;
+                for (int st = 0; st < 2; st++) {
+                    pk[st].assign(L / 16 + tw + 3, 0);
+                    bad_before[st].assign(L + 1, 0);
+                    for (size_t i = 0; i < L; i++) {
+                        uint8_t b = st ? seq[L - 1 - i] : seq[i];
+                        const bool acgt = b == 'A' || b == 'C' || b == 'G' || b == 'T';
+                        if (st && acgt) b = b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A';
+                        bad_before[st][i + 1] = bad_before[st][i] + (acgt ? 0 : 1);
+                        if (acgt) pk[st][i >> 4] |= (uint32_t)((b >> 1) & 3u) << (2 * (i & 15));
+                    }
+                    for (size_t i = 0; i + w <= L; i++) {
+                        if (bad_before[st][i + w] != bad_before[st][i]) continue;
+                        pack_at(pk[st], i, w, tw, buf);
+                        (void)set.find(buf, true);
+                    }
+                }
+            }
+    }
+    lap("path strings");
+    const size_t NS = set.n;
+    if (!NS) return GROOT_OK;
+    // ---- 2. the pipeline, once per string ----
     HIP_TRY(c, c->incr_cnt.alloc(chunk));
     HIP_TRY(c, c->incr_win.alloc((size_t)chunk * kIncrCap));
     DevBuf<uint8_t> d_seq;
@@ -1322,117 +1428,106 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
     HIP_TRY(c, d_seq.alloc((size_t)chunk * w + 64));
     HIP_TRY(c, d_off.alloc((size_t)chunk + 1));
     std::vector<uint32_t> tab;                              // entries, sq * 4 dwords each
-    std::vector<uint8_t> seqs;
-    std::vector<uint64_t> offs;
-    std::vector<size_t> where;
+    std::vector<uint32_t> sinfo(NS, 0);                     // sig_info word per string (0 = not tabulated)
+    std::vector<uint8_t> in_text(NS, 0);                    // ... and it may go into the text table
+    std::vector<uint8_t> seqs((size_t)chunk * w);
+    std::vector<uint64_t> offs((size_t)chunk + 1);
+    for (uint32_t i = 0; i <= chunk; i++) offs[i] = (uint64_t)i * w;
+    HIP_TRY(c, hipMemcpy(d_off.p, offs.data(), ((size_t)chunk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     std::vector<groot_trav> travs;
     std::vector<uint64_t> masks;
     std::vector<uint32_t> icnt, iwin, nseeds, seedw;
-    uint32_t seed_rows = 0;
-    std::vector<uint32_t> text_recs;                       // 16 dwords per string: 0, sig_info word, packed bases
     // (the text table serves reads of exactly WindowSize bases whose kmerCount puts Query on the every-slot-equal branch)
     const uint32_t q_w = w - c->k + 1;
-    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && c->h_q_min_eq[q_w] == c->s && !getenv("GROOT_NO_TEXT_TABLE");
-    c->out_strings = c->out_tabulated = c->out_entries = 0;
+    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && !getenv("GROOT_NO_TEXT_TABLE");
+    c->out_strings = NS; c->out_tabulated = c->out_entries = 0;
     int rc_all = GROOT_OK;
-    auto flush = [&]() -> int {
-        const uint32_t m = (uint32_t)where.size();
-        if (!m) return GROOT_OK;
-        Slot *s = nullptr;
-        if (int rc = take_slot(c, m, &s)) return rc;
-        if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;      // (resident input: no ASCII staging is allocated for this)
-        HIP_TRY(c, hipMemcpy(d_seq.p, seqs.data(), seqs.size(), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(d_off.p, offs.data(), ((size_t)m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        s->input = Slot::IN_DEVICE; s->n_reads = m; s->first_read_id = 0; s->mixed_len = false; s->one_len = true;
-        s->n_bases = 0; s->n_exc = 0; s->max_len = w; s->uniform_len = 0;
-        s->ext_seq = d_seq.p; s->ext_off = d_off.p;
-        if (int rc = enqueue(c, s)) return rc;
-        Slot *done = nullptr;
-        if (int rc = collect_impl(c, &done)) return rc;
-        const bool ok = done->status == GROOT_OK;
-        const uint32_t nt = done->n_trav;
-        travs.resize(nt); masks.resize((size_t)nt * pw); icnt.resize(m); iwin.resize((size_t)m * kIncrCap);
-        if (ok) {
-            if (nt) {
-                HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            }
-            seed_rows = std::min<uint32_t>(kOutSeedDw * kOutMaxTrav, c->seed_slots);
-            nseeds.resize(m); seedw.resize((size_t)seed_rows * m);
-            HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * kIncrCap * 4, hipMemcpyDeviceToHost));
+    c->tab_capture = true;
+    for (size_t s0 = 0; s0 < NS && !rc_all; s0 += chunk) {
+        const uint32_t m = (uint32_t)std::min<size_t>(chunk, NS - s0);
+        static const char kBase[4] = {'A', 'C', 'T', 'G'};
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t *pwd = &set.words[(s0 + j) * tw];
+            uint8_t *dst = &seqs[(size_t)j * w];
+            for (uint32_t x = 0; x < w; x++) dst[x] = (uint8_t)kBase[(pwd[x >> 4] >> (2 * (x & 15))) & 3u];
         }
-        release_slot(c, done);
-        c->out_strings += m;
-        if (ok) {
+        auto run = [&]() -> int {
+            Slot *s = nullptr;
+            if (int rc = take_slot(c, m, &s)) return rc;
+            if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;      // (resident input: no staging is allocated for this)
+            HIP_TRY(c, hipMemcpy(d_seq.p, seqs.data(), (size_t)m * w, hipMemcpyHostToDevice));
+            s->input = Slot::IN_DEVICE; s->n_reads = m; s->first_read_id = 0; s->mixed_len = false; s->one_len = true;
+            s->n_bases = 0; s->n_exc = 0; s->max_len = w; s->uniform_len = 0;
+            s->ext_seq = d_seq.p; s->ext_off = d_off.p;
+            if (int rc = enqueue(c, s)) return rc;
+            Slot *done = nullptr;
+            if (int rc = collect_impl(c, &done)) return rc;
+            const bool ok = done->status == GROOT_OK;
+            const uint32_t nt = done->n_trav;
+            const uint32_t seed_rows = std::min<uint32_t>(kOutSeedDw * kOutMaxTrav, c->seed_slots);
+            travs.resize(nt); masks.resize((size_t)nt * pw); icnt.resize(m); iwin.resize((size_t)m * kIncrCap);
+            nseeds.resize(m); seedw.resize((size_t)seed_rows * m);
+            if (ok) {
+                if (nt) {
+                    HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
+                    HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                }
+                HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * kIncrCap * 4, hipMemcpyDeviceToHost));
+            }
+            release_slot(c, done);
+            if (!ok) return GROOT_OK;
             size_t t0 = 0;
             for (uint32_t j = 0; j < m; j++) {              // records come in (read, ord) order
                 size_t t1 = t0;
                 while (t1 < nt && travs[t1].read_id == j) t1++;
-                const uint32_t cnt = (uint32_t)(t1 - t0), ni = icnt[j] & 0x7FFFFFFFu;
+                const uint32_t cnt = (uint32_t)(t1 - t0), ni = icnt[j] & 0x7FFFFFFFu, nsd = nseeds[j] & 0x7FFFFFFFu;
                 uint64_t recs = 0;
                 for (size_t t = t0; t < t1; t++)
                     for (uint32_t x = 0; x < pw; x++) recs += (uint64_t)__builtin_popcountll(masks[t * pw + x]);
                 const size_t first = tab.size() / (sq * 4);
                 // (its seed windows travel in the entries too when they fit: what text_lookup_kernel's reads report as their seeds)
-                const uint32_t nsd = nseeds[j] & 0x7FFFFFFFu;
-                const bool seeds_fit = nsd <= std::min<uint32_t>(kOutSeedDw * cnt, c->seed_slots) && nsd <= seed_rows;
-                if (cnt >= 1 && cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(kIncrCap, 2 * cnt) && recs <= 0xFFFFu && first + cnt < (1u << kOutIdxBits)) {
-                    for (uint32_t e = 0; e < cnt; e++) {
-                        const groot_trav &t = travs[t0 + e];
+                const bool seeds_fit = nsd <= std::min<uint32_t>(kOutSeedDw * std::max(cnt, 1u), c->seed_slots) && nsd <= seed_rows;
+                const uint32_t n_ent = std::max(cnt, 1u);      // (no traversal: one entry for the calls, the seeds and the counters)
+                if (cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(kIncrCap, 2 * n_ent) && recs <= 0xFFFFu && first + n_ent < (1u << kOutIdxBits)) {
+                    for (uint32_t e = 0; e < n_ent; e++) {
                         const size_t b = tab.size();
                         tab.resize(b + sq * 4, 0);
-                        tab[b] = t.node; tab[b + 1] = t.offset; tab[b + 2] = t.graph_id;
-                        tab[b + 3] = (uint32_t)t.flags | (e == 0 && (icnt[j] >> 31) ? 0x100u : 0u) | (e == 0 ? (uint32_t)recs << 16 : 0u);
+                        if (cnt) {
+                            const groot_trav &t = travs[t0 + e];
+                            tab[b] = t.node; tab[b + 1] = t.offset; tab[b + 2] = t.graph_id; tab[b + 3] = (uint32_t)t.flags;
+                        } else tab[b] = kEmpty;
+                        // multimapped / mapped as the align stage counts them (boss.go:195-200): a read with seeds is mapped
+                        if (e == 0) tab[b + 3] |= ((icnt[j] >> 31) ? 0x100u : 0u) | (nsd ? 0x200u : 0u) | ((uint32_t)recs << 16);
                         tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * kIncrCap + 2 * e] : kEmpty;
                         tab[b + 5] = 2 * e + 1 < ni ? iwin[(size_t)j * kIncrCap + 2 * e + 1] : kEmpty;
                         for (uint32_t x = 0; x < kOutSeedDw; x++)
                             tab[b + sq * 4 - kOutSeedDw + x] = seeds_fit && kOutSeedDw * e + x < nsd ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
                         for (uint32_t x = 0; x < pw; x++) {
-                            tab[b + kOutHdrDw + 2 * x] = (uint32_t)masks[(t0 + e) * pw + x];
-                            tab[b + kOutHdrDw + 2 * x + 1] = (uint32_t)(masks[(t0 + e) * pw + x] >> 32);
+                            tab[b + kOutHdrDw + 2 * x] = cnt ? (uint32_t)masks[(t0 + e) * pw + x] : 0u;
+                            tab[b + kOutHdrDw + 2 * x + 1] = cnt ? (uint32_t)(masks[(t0 + e) * pw + x] >> 32) : 0u;
                         }
                     }
-                    // are the IncrementSubPath calls exactly the string's seed windows, once each?  (then the seed stage counts them)
-                    bool all_seeds = ni == (nseeds[j] & 0x7FFFFFFFu) && ni <= 4 && ni <= c->seed_slots;
+                    // are the IncrementSubPath calls exactly the string's seed windows, once each?  (then the signature kernel counts them itself)
+                    bool all_seeds = ni == nsd && ni <= 4 && ni <= c->seed_slots;
                     if (all_seeds) {
                         uint32_t a4[4], b4[4];
                         for (uint32_t x = 0; x < ni; x++) { a4[x] = iwin[(size_t)j * kIncrCap + x]; b4[x] = seedw[(size_t)x * m + j]; }
                         std::sort(a4, a4 + ni); std::sort(b4, b4 + ni);
                         all_seeds = std::equal(a4, a4 + ni, b4) && std::adjacent_find(a4, a4 + ni) == a4 + ni;
                     }
-                    info[where[j]] = kOutTab | ((cnt - 1) << kOutTravShift) | (all_seeds ? kOutAllSeeds : 0u) | (uint32_t)first;
-                    if (seeds_fit && text_ok) {            // text_lookup_kernel's table: the string itself, 2 bits per base
-                        const size_t b = text_recs.size();
-                        text_recs.resize(b + 16, 0);
-                        text_recs[b + 1] = info[where[j]];
-                        const uint8_t *sq8 = &seqs[(size_t)j * w];
-                        for (uint32_t x = 0; x < w; x++) text_recs[b + 2 + (x >> 4)] |= (uint32_t)((sq8[x] >> 1) & 3u) << (2 * (x & 15));
-                    }
+                    sinfo[s0 + j] = kOutTab | (cnt ? (cnt - 1) << kOutTravShift : kOutNoRec) | (all_seeds ? kOutAllSeeds : 0u) | (uint32_t)first;
+                    in_text[s0 + j] = seeds_fit && text_ok;
                     c->out_tabulated++;
                 }
                 t0 = t1;
             }
-        }
-        seqs.clear(); where.clear(); offs.assign(1, 0);
-        return GROOT_OK;
-    };
-    offs.assign(1, 0);
-    c->tab_capture = true;
-    for (uint32_t i = 0; i < n && !rc_all; i++) {
-        if (!tlen[i]) continue;
-        for (uint32_t row = 0; row < 2 && !rc_all; row++)
-            for (uint32_t o = 0; o + w <= tlen[i] && !rc_all; o++) {
-                const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax + o];
-                seqs.insert(seqs.end(), src, src + w);
-                offs.push_back(offs.back() + w);
-                where.push_back(((size_t)i * 2 + row) * vstride + o);
-                if (where.size() >= chunk) rc_all = flush();
-            }
+            return GROOT_OK;
+        };
+        rc_all = run();
     }
-    if (!rc_all) rc_all = flush();
     c->tab_capture = false;
     c->incr_cnt.release(); c->incr_win.release();
     // the capture batches counted IncrementSubPath calls and claimed rows of the call-count table: back to the state of a fresh ctx
@@ -1447,8 +1542,28 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
         c->trav_per_read = 1.25; c->words_per_trav = 0; c->dfs_frac = 1.0;
     }
     if (rc_all) return rc_all;
+    lap("pipeline on the strings");
     c->out_entries = tab.size() / (sq * 4);
     if (!c->out_entries) return GROOT_OK;
+    // ---- 3. sig_info of the window-text strings (the signature kernel's way into the table): they are path strings ----
+    {
+        uint32_t buf[16];
+        std::vector<uint32_t> pk;
+        for (uint32_t i = 0; i < n; i++) {
+            if (!tlen[i]) continue;
+            for (uint32_t row = 0; row < 2; row++) {
+                const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax];
+                pk.assign(tlen[i] / 16 + tw + 3, 0);
+                for (uint32_t x = 0; x < tlen[i]; x++) pk[x >> 4] |= (uint32_t)((src[x] >> 1) & 3u) << (2 * (x & 15));
+                for (uint32_t o = 0; o + w <= tlen[i]; o++) {
+                    pack_at(pk, o, w, tw, buf);
+                    const long j = set.find(buf, false);
+                    if (j >= 0 && sinfo[(size_t)j]) info[((size_t)i * 2 + row) * vstride + o] = sinfo[(size_t)j];
+                }
+            }
+        }
+    }
+    lap("sig_info");
     tab.resize(tab.size() + 16, 0);
     HIP_TRY(c, c->out_tab.alloc(c->out_entries * sq + 4));
     HIP_TRY(c, hipMemcpy(c->out_tab.p, tab.data(), (c->out_entries * sq + 4) * sizeof(uint4), hipMemcpyHostToDevice));
@@ -1458,38 +1573,38 @@ static int build_outcome_table(groot_ctx *c, const std::vector<uint8_t> &text, c
     HIP_TRY(c, hipMemset(c->tab_hist.p, 0, (size_t)c->n_windows * sizeof(uint32_t)));
     c->dix.out_tab = c->out_tab.p;
     c->dix.out_stride_q = sq;
-    if (!text_recs.empty()) {
-        const size_t ns = text_recs.size() / 16;
+    // ---- 4. text table: 64-byte entries {tag, sig_info word, bases}, keyed by the bases ----
+    // (only where Query is on the every-slot-equal branch for WindowSize-mers: the same condition under which the signature kernel
+    // decides reads; nothing depends on it for correctness -- the memo is the pipeline's own output -- it keeps the two paths alike)
+    if (text_ok && c->h_q_min_eq[q_w] == c->s) {
+        size_t ns = 0;
+        for (size_t j = 0; j < NS; j++) ns += in_text[j];
         uint32_t cap = 1024;
         while (cap < 2 * ns) cap <<= 1;
         std::vector<uint32_t> tt((size_t)cap * 16, 0);
-        const uint32_t tw = (w + 15) / 16;
-        uint64_t kept = 0;
-        for (size_t i = 0; i < ns; i++) {
-            const uint32_t *rec = &text_recs[i * 16];
-            uint64_t h = GROOT_TEXT_HASH_INIT;
-            const uint32_t twk = tw <= 8 ? 8 : 14;         // (the kernel instance hashes its whole register row; dwords past the string are zero)
-            for (uint32_t j = 0; j < twk; j++) h = text_hash_step(h, rec[2 + j]);
+        const uint32_t twk = tw <= 8 ? 8 : 14;             // (the kernel instance hashes its whole register row; dwords past the string are zero)
+        uint32_t rec[16];
+        for (size_t j = 0; j < NS; j++) {
+            if (!in_text[j]) continue;
+            memset(rec, 0, sizeof rec);
+            memcpy(rec + 2, &set.words[j * tw], (size_t)tw * 4);
+            const uint64_t h = StringSet::hash(rec + 2, twk);
             uint32_t slot = (uint32_t)h & (cap - 1);
-            bool dup = false;
-            for (; tt[(size_t)slot * 16 + 1] != 0; slot = (slot + 1) & (cap - 1))
-                if (tt[(size_t)slot * 16] == (uint32_t)(h >> 32) && !memcmp(&tt[(size_t)slot * 16 + 2], rec + 2, 14 * 4)) { dup = true; break; }
-            if (dup) continue;                              // the same bases in another window: same sketch class, same outcome
+            while (tt[(size_t)slot * 16 + 1] != 0) slot = (slot + 1) & (cap - 1);
+            rec[0] = (uint32_t)(h >> 32); rec[1] = sinfo[j];
             memcpy(&tt[(size_t)slot * 16], rec, 64);
-            tt[(size_t)slot * 16] = (uint32_t)(h >> 32);
-            kept++;
         }
         HIP_TRY(c, c->text_tab.alloc((size_t)cap * 4));
         HIP_TRY(c, hipMemcpy(c->text_tab.p, tt.data(), (size_t)cap * 64, hipMemcpyHostToDevice));
         c->dix.text_tab = c->text_tab.p;
         c->dix.text_mask = cap - 1;
-        c->text_entries = kept;
+        c->text_entries = ns;
     }
-    if (getenv("GROOT_OPEN_STATS"))
-        fprintf(stderr, "[groot open]   text table: %llu distinct strings in %u slots of 64 bytes\n", (unsigned long long)c->text_entries, c->dix.text_mask + 1);
-    if (getenv("GROOT_OPEN_STATS"))
-        fprintf(stderr, "[groot open]   outcome table: %llu of %llu window-text strings tabulated, %llu entries of %u bytes\n", (unsigned long long)c->out_tabulated,
-                (unsigned long long)c->out_strings, (unsigned long long)c->out_entries, sq * 16);
+    lap("text table");
+    if (stats)
+        fprintf(stderr, "[groot open]   memo: %llu of %llu distinct path strings tabulated, %llu entries of %u bytes; text table: %llu strings in %u slots of 64 bytes\n",
+                (unsigned long long)c->out_tabulated, (unsigned long long)c->out_strings, (unsigned long long)c->out_entries, sq * 16,
+                (unsigned long long)c->text_entries, c->dix.text_tab ? c->dix.text_mask + 1 : 0u);
     return GROOT_OK;
 }
 
@@ -1636,7 +1751,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     // 5. outcome table: the align stage itself, once, on every string that confirms reads
     if (c->dix.sig_info && !getenv("GROOT_NO_OUTCOME_TABLE") && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len) {
         const auto t0 = std::chrono::steady_clock::now();
-        if (int rc = build_outcome_table(c, text, tlen, verdict, w, vstride)) return rc;
+        if (int rc = build_outcome_table(c, v, text, tlen, verdict, w, vstride)) return rc;
         c->out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         lap("outcome table");
     }
@@ -1720,6 +1835,32 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
             });
         for (auto &x : th) x.join();
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
+    }
+    if (!getenv("GROOT_NO_NODE_PRE4")) {   // which 4-mers the level-2 start positions of every node can spell
+        std::vector<uint32_t> pre((size_t)v->n_nodes * 8, 0);
+        for (uint32_t nd = 0; nd < v->n_nodes; nd++) {
+            const uint32_t s0 = v->node_seq_off[nd], nlen = v->node_seq_off[nd + 1] - s0;
+            uint32_t *bits = &pre[(size_t)nd * 8];
+            for (uint32_t o = 0; o < std::min(nlen, 11u); o++) {
+                // every code compatible with the four positions (a wildcard position takes all four bases)
+                uint32_t codes[256], nc = 1;
+                codes[0] = 0;
+                for (uint32_t b = 0; b < 4; b++) {
+                    const uint8_t ch = o + b < nlen ? v->bases[s0 + o + b] : (uint8_t)'N';
+                    const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+                    if (acgt) {
+                        for (uint32_t i = 0; i < nc; i++) codes[i] |= (uint32_t)((ch >> 1) & 3u) << (2 * b);
+                    } else {
+                        for (uint32_t i = 0; i < nc; i++)
+                            for (uint32_t x = 1; x < 4; x++) codes[nc * x + i] = codes[i] | (x << (2 * b));
+                        nc *= 4;
+                    }
+                }
+                for (uint32_t i = 0; i < nc; i++) bits[codes[i] >> 5] |= 1u << (codes[i] & 31);
+            }
+        }
+        HIP_TRY(c, upload(c->node_pre4, pre.data(), pre.size()));
+        c->dix.node_pre4 = c->node_pre4.p;
     }
     lap("node records + prefix tables");
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));

@@ -71,6 +71,17 @@ __host__ __device__ __forceinline__ int kmer6_code(uint64_t r8)
     }
     return code;
 }
+// 8-bit code of the first 4 bases of r8, or -1 if one of them is not ACGT
+__host__ __device__ __forceinline__ int kmer4_code(uint64_t r8)
+{
+    int code = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned b = (unsigned)(r8 >> (8 * i)) & 0xFF;
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return -1;
+        code |= (int)((b >> 1) & 3) << (2 * i);
+    }
+    return code;
+}
 // DeviceIndex::win_prefix of one window: can no level-1/2 start position spell oriented read bases [0,12) = (c0, c1)?
 __device__ __forceinline__ bool prefix_absent(const uint32_t *tab, uint64_t c0, uint64_t c1, uint32_t eff)
 {
@@ -308,7 +319,7 @@ __device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint3
         counted = kTabCounted;
     }
     a.tab_idx[r] = (info & ((1u << kOutIdxBits) - 1u)) | counted;
-    a.trav_cnt[r] = ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
+    a.trav_cnt[r] = (info & kOutNoRec) ? 0u : ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
     seed_counters(a, r, q, n_hits, true);
 }
 
@@ -1027,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;
     a.sort_key[r] = kEmpty;
     a.tab_idx[r] = (info & ((1u << kOutIdxBits) - 1u)) | kTabSeedsHere;
-    a.trav_cnt[r] = ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
+    a.trav_cnt[r] = (info & kOutNoRec) ? 0u : ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
 }
 
 // groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
@@ -1366,6 +1377,30 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 return;
             }
             if (level == 2) {                               // 2. seed node shuffling (:47-70): offsets 0..10
+                // Contained nodes none of whose offsets 0..10 can spell the first four read bases would each cost a SCAN step
+                // that finds nothing (its 4-base filter is the same test): DeviceIndex::node_pre4 says so per node, four nodes
+                // per pair of trips.  A read that fails everywhere walks every contained node of every seed window in both
+                // orientations -- it is the slowest read of its batch, and the launch lasts as long as it does.
+                if (ix.node_pre4 && eff >= 4u && cn_cur < cn_end) {
+                    const int c4 = kmer4_code(pre8);
+                    if (c4 >= 0) {
+                        const uint32_t wi = (uint32_t)c4 >> 5, bi = (uint32_t)c4 & 31u;
+                        while (cn_cur < cn_end) {
+                            const uint32_t left = cn_end - cn_cur;
+                            const uint32_t n0 = ix.cn_node[cn_cur], n1 = left > 1 ? ix.cn_node[cn_cur + 1] : n0, n2 = left > 2 ? ix.cn_node[cn_cur + 2] : n0,
+                                           n3 = left > 3 ? ix.cn_node[cn_cur + 3] : n0;
+                            const uint32_t w0 = ix.node_pre4[(size_t)n0 * 8 + wi], w1 = ix.node_pre4[(size_t)n1 * 8 + wi], w2 = ix.node_pre4[(size_t)n2 * 8 + wi],
+                                           w3 = ix.node_pre4[(size_t)n3 * 8 + wi];
+                            uint32_t hit = 4;
+                            if (left > 3 && ((w3 >> bi) & 1u)) hit = 3;
+                            if (left > 2 && ((w2 >> bi) & 1u)) hit = 2;
+                            if (left > 1 && ((w1 >> bi) & 1u)) hit = 1;
+                            if ((w0 >> bi) & 1u) hit = 0;
+                            cn_cur += min(hit, left);
+                            if (hit < 4) break;
+                        }
+                    }
+                }
                 if (cn_cur < cn_end) {
                     const uint32_t node = ix.cn_node[cn_cur];
                     const uint32_t nlen = recs[node].seq_len;
@@ -1844,7 +1879,7 @@ __global__ void order_total_kernel(const uint32_t *off, const uint32_t *cnt, uin
 // (graphminion.go:60-67) and the read / alignment counters (boss.go:195-200).
 struct OrderTabArgs {
     uint32_t *seed_count, *seed_win;   // [n], [slots][n]: written here for the reads text_lookup_kernel answered (kTabSeedsHere)
-    uint32_t seed_slots;
+    uint32_t seed_slots, exp;
     const uint32_t *tab_idx;     // [n] or null
     const uint4 *out_tab;
     uint32_t stride_q, first_read_id;
@@ -1865,15 +1900,16 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
     for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
     const uint32_t tw = t.tab_idx ? t.tab_idx[r] : kEmpty;
     const uint32_t ti = tw == kEmpty ? kEmpty : tw & ((1u << kOutIdxBits) - 1u);
-    const bool count_here = (t.update_weights & 1u) && !(tw & kTabCounted);   // (else the seed stage counted the read's calls)
-    const bool seeds_here = tw != kEmpty && (tw & kTabSeedsHere);              // its seed windows are the table's call-count windows
+    const bool count_here = (t.update_weights & 1u) && !(tw & kTabCounted) && !(t.exp & 1u);   // (else the seed stage counted the read's calls)
+    const bool seeds_here = tw != kEmpty && (tw & kTabSeedsHere) && !(t.exp & 2u);              // its seed windows are the table's call-count windows
     uint32_t ns = 0;
     if (ti != kEmpty && live) {
         const uint32_t nt = cnt[r], i = off[r];
         const bool fits = i < cap && nt <= cap - i;
         if (!fits) atomicOr(&ctr->flags, kFlagTravOverflow);
         const uint32_t row = t.update_weights ? t.q_row[t.q_tab] : 0u;
-        for (uint32_t j = 0; j < nt; j++) {
+        const uint32_t n_ent = nt ? nt : 1u;                  // (a string without traversals still has its calls, seeds and counters)
+        for (uint32_t j = 0; j < n_ent; j++) {
             const uint4 *e = t.out_tab + (size_t)(ti + j) * t.stride_q;
             const uint4 h = e[0];                          // node, offset, graph, flags | multimapped << 8 | records << 16
             const uint4 x = e[1];                          // two call-count windows, first path word
@@ -1888,8 +1924,8 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
                 if (sd.z != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.z; ns++; }
                 if (sd.w != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.w; ns++; }
             }
-            if (j == 0) { alns += h.w >> 16; mapped++; multimapped += (h.w >> 8) & 1u; }
-            if (!fits) continue;
+            if (j == 0) { alns += h.w >> 16; mapped += (h.w >> 9) & 1u; multimapped += (h.w >> 8) & 1u; }
+            if (!fits || !nt || (t.exp & 4u)) continue;
             groot_trav tr;
             tr.read_id = t.first_read_id + r; tr.graph_id = h.z; tr.node = h.x; tr.offset = h.y;
             tr.ord = (uint16_t)j; tr.flags = (uint8_t)h.w; tr.reserved = 0;

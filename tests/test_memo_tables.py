@@ -1,0 +1,98 @@
+"""Round 3: the memo of the pipeline's own results (groot_hip.hip build_outcome_table).  Every WindowSize-mer of every indexed
+path goes through the ctx's pipeline once at open; at run time a read that equals such a string is answered from the outcome
+table -- found by its bases (text_lookup_kernel) or by its signature (sketch_sig_kernel + sig_info) -- and never reaches the
+align stage.  Whatever the route, seeds / records / counters / IncrementSubPath call counts equal the oracle's
+(lshe.go:153-175, graphminion.go:46-102, alignment.go:13-159), batch after batch, and equal the ctx opened without the tables."""
+import numpy as np
+import pytest
+
+from groot_amd import device, synth
+from oracle import oracle_py as O
+from test_signature_path import mixed_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(hip_lib):
+    assert device.device_count() > 0, "no MI355X visible: the HIP path has no CPU fallback"
+
+
+def perfect_batch(index, n, first):
+    cat, o, lens = synth.reference_sequences(index)
+    seq, off, _ = synth.reads_np(cat, o, lens, n, 100, first=first)
+    return seq, off
+
+
+def check_batch(al, orc_index, seq, off, att_before):
+    """one batch through `al`, compared with a fresh oracle run; returns the counts and the call-count table after it"""
+    al.submit(seq, off)
+    counts = al.wait()
+    orc = O.Run(orc_index, 0.99)
+    orc.batch(seq, off)
+    assert np.array_equal(al.seeds(), orc.seeds().astype(device.SEED_DTYPE))
+    got, exp = al.alns(), orc.alns()
+    assert len(got) == len(exp) and all(np.array_equal(got[f], exp[f]) for f in exp.dtype.names)
+    for k in ("received", "mapped", "multimapped", "alignments", "seeds", "revcomp_panics"):
+        assert counts[k] == orc.counts()[k], k
+    att = al.attempts().copy()
+    oatt = orc.attempts()
+    delta = att.astype(np.int64)
+    delta[: att_before.shape[0]] -= att_before
+    assert np.array_equal(delta[: oatt.shape[0]], oatt) and not delta[oatt.shape[0]:].any()
+    return counts, att
+
+
+@pytest.mark.parametrize("tables", ["all", "no_text", "none"])
+def test_batches_of_changing_composition(argannot_index, monkeypatch, tables):
+    """error-free reads (the text lookup answers them), then a mixed batch (errors, N, other lengths: the lookup's share drops and
+    the ctx goes back to the signature kernel), then error-free reads again: every batch equals the oracle, and the call
+    counts accumulate over the batches whichever kernel counted them"""
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+        monkeypatch.delenv(v, raising=False)
+    if tables == "no_text":
+        monkeypatch.setenv("GROOT_NO_TEXT_TABLE", "1")
+    if tables == "none":
+        monkeypatch.setenv("GROOT_NO_OUTCOME_TABLE", "1")
+    index = argannot_index
+    al = device.Aligner(index, max_batch_reads=8192, max_read_len=128)
+    att = np.zeros((0, index.view.n_windows), dtype=np.uint32)
+    shares = []
+    for b, (seq, off) in enumerate([perfect_batch(index, 6000, 0), mixed_batch(index, 6000, seed=3), mixed_batch(index, 5000, seed=4),
+                                    perfect_batch(index, 7000, 50_000), perfect_batch(index, 7000, 90_000)]):
+        counts, att = check_batch(al, index, seq, off, att)
+        shares.append(counts["full_sketch_reads"] / counts["received"])
+    if tables == "all":
+        assert shares[0] < 0.03 and shares[-1] < 0.03     # error-free reads: found by their bases, or by their signature
+    al.close()
+
+
+def test_reads_without_any_record_are_tabulated_too(argannot_index, monkeypatch):
+    """strings for which nothing is reported (no seed window at all, or seeds and no traversal in either orientation) have an
+    entry of their own -- their counters, their IncrementSubPath calls, no record -- instead of a trip through the align stage"""
+    monkeypatch.delenv("GROOT_NO_OUTCOME_TABLE", raising=False)
+    index = argannot_index
+    seq, off = perfect_batch(index, 60000, 0)
+    orc = O.Run(index, 0.99)
+    orc.batch(seq, off)
+    assert np.unique(orc.alns()["read_id"]).size < 60000, "the sample holds no read without records: enlarge it"
+    al = device.Aligner(index, max_batch_reads=65536, max_read_len=128)
+    counts, _ = check_batch(al, index, seq, off, np.zeros((0, index.view.n_windows), dtype=np.uint32))
+    assert counts["full_sketch_reads"] < 0.01 * 60000      # (what is left: reads holding a byte other than ACGT)
+    # a second, identical batch: everything doubles in the call-count table
+    a1 = al.attempts().copy()
+    al.submit(seq, off)
+    al.wait()
+    assert np.array_equal(al.attempts(), 2 * a1)
+    al.close()
+
+
+def test_small_index_and_small_buffers(small_index, monkeypatch):
+    """the capture pass of open and the run-time path with every buffer starting too small (grow-and-redo paths)"""
+    monkeypatch.setenv("GROOT_TEST_SMALL_BUFFERS", "1")
+    index = small_index
+    al = device.Aligner(index, max_batch_reads=4096, max_read_len=128, max_seeds_per_read=1)
+    att = np.zeros((0, index.view.n_windows), dtype=np.uint32)
+    for seq, off in (perfect_batch(index, 3000, 0), mixed_batch(index, 3000, seed=8), perfect_batch(index, 3000, 7000)):
+        _, att = check_batch(al, index, seq, off, att)
+    al.close()
