@@ -23,7 +23,8 @@ enum : uint32_t {
     kFlagQOverflow = 64u,     // more distinct kmerCounts among the seeded reads than the call-count table has rows
 };
 
-constexpr uint32_t kIncrCap = 8;      // AlignArgs::incr_win slots per read
+constexpr uint32_t kIncrCap = 8;      // AlignArgs::incr_win slots per read in the capture pass of groot_hip_open (a second pass with kIncrCapBig takes the few strings that need more)
+constexpr uint32_t kIncrCapBig = 2048;
 constexpr uint32_t kSeedShards = 64, kSeedShardStride = 16;   // seed-stage counters: one 128-byte line per shard
 constexpr uint32_t kOvfShards = 256;  // overflow traversal lists, picked by workgroup id: spreads the atomics
 
@@ -79,6 +80,7 @@ static_assert(sizeof(ReadRec) == 32, "read record is two 16-byte words");
 // (F) / its reverse complement (R) in the read's first seed window, as established by the seed stage
 constexpr uint32_t kRecCountMask = 0x00FFFFFFu;
 constexpr uint32_t kRecNo12F = 1u << 24, kRecNo3F = 1u << 25, kRecNo4F = 1u << 26;   // R = F << 3
+constexpr uint32_t kRecAscending = 1u << 30;                // cnt_flags: the read's seed windows were written in ascending order
 constexpr uint32_t kPrefixWords = 256;   // words per window in DeviceIndex::win_prefix
 
 // a traversal record on its way to the host: what cannot be derived there (graph = graph of the node, ord = position among
@@ -93,14 +95,15 @@ static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
 // produce for a read that IS bases [o, o + WindowSize) of a window text row -- every such read is the same string with the same seed
 // windows, so the outcome is a function of (window, row, o) and the ctx works it out once, at open, by running the align stage itself
 // on the string.  One entry per traversal record:
-//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | mapped << 9 | sam.Records of the whole read << 16
+//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | mapped << 9 | traversals of the string << 16 (first entry)
 //       (a string without any traversal has one entry with node = kEmpty: its calls, its seeds, its counters)
 //   [4],[5] windows whose IncrementSubPath the read triggers (kEmpty = none; a string's calls are spread over its entries)
 //   [6..] path set, pw 64-bit words (lo, hi)
 //   last four dwords of the entry: seed windows of the read (kEmpty = none; spread over the string's entries like the calls)
 constexpr uint32_t kOutHdrDw = 6, kOutSeedDw = 4;
 constexpr uint32_t kOutTab = 0x80000000u;                  // sig_info: the string's outcome is tabulated
-constexpr uint32_t kOutMaxTrav = 16, kOutIdxBits = 25, kOutTravShift = 27;
+// sig_info bits 27..30: traversals - 1, or 15 = more than fifteen: the number is in the string's first entry ([3] bits 16..31)
+constexpr uint32_t kOutMaxTrav = 4095, kOutIdxBits = 25, kOutTravShift = 27, kOutTravLong = 15;
 constexpr uint32_t kOutNoRec = 1u << 25;                   // sig_info: the string has seed windows (or none) but AlignRead reports nothing for it: one entry, no record
 constexpr uint32_t kOutAllSeeds = 1u << 26;                // sig_info: ... and IncrementSubPath is called exactly once for each of the read's seed windows
 constexpr uint32_t kTodo = 0xFFFFFFFEu;                    // SeedArgs::tab_idx: text_lookup_kernel leaves the read to the full-width kernel
@@ -245,6 +248,7 @@ struct AlignArgs {
     // groot_hip_open's capture pass for the outcome table: per read the windows whose IncrementSubPath was called, in call order
     // ([n_reads][kIncrCap], count in incr_cnt[r] bits 0..30, bit 31 = the read touched more than one graph); null otherwise
     uint32_t *incr_cnt, *incr_win;
+    uint32_t incr_cap;           // slots per read in incr_win
     uint32_t round_lanes;        // lanes a wavefront fills per round; 0 = 64, fewer when the batch leaves the align stage little to do (see the kernel)
     uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;

@@ -147,6 +147,7 @@ struct groot_ctx {
     DevBuf<uint4> out_tab;                 // AlignRead outcomes of the window-text strings (DeviceIndex::out_tab)
     uint64_t out_strings = 0, out_tabulated = 0, out_entries = 0;   // strings that confirm reads / of them tabulated / table entries
     double out_build_ms = 0;
+    uint32_t incr_cap = kIncrCap;
     bool tab_capture = false;              // the capture pass of groot_hip_open is running (align stage records the IncrementSubPath windows)
     DevBuf<uint32_t> tab_idx, tab_hist, incr_cnt, incr_win;
     DevBuf<uint4> text_tab;                // text_lookup_kernel: strings with a tabulated outcome, keyed by their bases
@@ -648,7 +649,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.todo_count = c->todo_count.p;
         const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;
         a.list_stride_dw = (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
-        const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
+        const size_t lds = kTextBad + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
         if (c->dix.w <= 128) hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a);
         else hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a);
         HIP_TRY(c, hipGetLastError());
@@ -752,10 +753,10 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
     if (c->tab_capture) {
-        a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p;
+        a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p; a.incr_cap = c->incr_cap;
         HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
     }
-    if (const char *e = getenv("GROOT_ROUND_LANES")) a.round_lanes = (uint32_t)std::max(8, std::min(64, atoi(e)));   // experiments
+    if (const char *e = getenv("GROOT_ROUND_LANES")) a.round_lanes = (uint32_t)std::max(1, std::min(64, atoi(e)));   // experiments
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
@@ -1107,6 +1108,12 @@ static int finish_counters(groot_ctx *c, Slot *s)
     for (int e = 0; e < 32; e++)
         if (h.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, h.dbg[e], h.dbg[32 + e]);
     fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", h.dbg[63]);
+#if GROOT_WORK_COUNTERS == 2
+    fprintf(stderr, "[groot work] slow reads (%llu):", h.dbg[128]);
+    for (int i = 0; i < 60 && (unsigned long long)i < h.dbg[128]; i++) fprintf(stderr, " %llu:%llu", h.dbg[129 + i] & 0xFFFFFFFFull, h.dbg[129 + i] >> 32);
+    fprintf(stderr, "\n");
+#endif
+    for (int i = 0; i < 5; i++) fprintf(stderr, "[groot work] FETCH part %d: %.1f ms summed over wavefronts\n", i, (double)h.dbg[40 + i] / 1e5);
     for (int ph = 0; ph < 3; ph++)
         fprintf(stderr, "[groot work] phase %d: %llu steps, %.2f us per step (wall clock, per wave)\n", ph, h.dbg[27 + ph],
                 h.dbg[27 + ph] ? (double)h.dbg[24 + ph] / 100.0 / (double)h.dbg[27 + ph] : 0.0);
@@ -1421,8 +1428,6 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     const size_t NS = set.n;
     if (!NS) return GROOT_OK;
     // ---- 2. the pipeline, once per string ----
-    HIP_TRY(c, c->incr_cnt.alloc(chunk));
-    HIP_TRY(c, c->incr_win.alloc((size_t)chunk * kIncrCap));
     DevBuf<uint8_t> d_seq;
     DevBuf<uint64_t> d_off;
     HIP_TRY(c, d_seq.alloc((size_t)chunk * w + 64));
@@ -1437,96 +1442,108 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     std::vector<groot_trav> travs;
     std::vector<uint64_t> masks;
     std::vector<uint32_t> icnt, iwin, nseeds, seedw;
+    std::vector<size_t> big;                                // strings with more calls / seeds than the first pass keeps: second pass
     // (the text table serves reads of exactly WindowSize bases whose kmerCount puts Query on the every-slot-equal branch)
     const uint32_t q_w = w - c->k + 1;
     const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && !getenv("GROOT_NO_TEXT_TABLE");
     c->out_strings = NS; c->out_tabulated = c->out_entries = 0;
     int rc_all = GROOT_OK;
     c->tab_capture = true;
-    for (size_t s0 = 0; s0 < NS && !rc_all; s0 += chunk) {
-        const uint32_t m = (uint32_t)std::min<size_t>(chunk, NS - s0);
-        static const char kBase[4] = {'A', 'C', 'T', 'G'};
+    static const char kBase[4] = {'A', 'C', 'T', 'G'};
+    // one batch: strings ids[0..m) through the pipeline; incr_cap call-count windows and up to seed_rows seed windows kept per string
+    auto run = [&](const size_t *ids, uint32_t m, uint32_t incr_cap, bool second_pass) -> int {
         for (uint32_t j = 0; j < m; j++) {
-            const uint32_t *pwd = &set.words[(s0 + j) * tw];
+            const uint32_t *pwd = &set.words[ids[j] * tw];
             uint8_t *dst = &seqs[(size_t)j * w];
             for (uint32_t x = 0; x < w; x++) dst[x] = (uint8_t)kBase[(pwd[x >> 4] >> (2 * (x & 15))) & 3u];
         }
-        auto run = [&]() -> int {
-            Slot *s = nullptr;
-            if (int rc = take_slot(c, m, &s)) return rc;
-            if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;      // (resident input: no staging is allocated for this)
-            HIP_TRY(c, hipMemcpy(d_seq.p, seqs.data(), (size_t)m * w, hipMemcpyHostToDevice));
-            s->input = Slot::IN_DEVICE; s->n_reads = m; s->first_read_id = 0; s->mixed_len = false; s->one_len = true;
-            s->n_bases = 0; s->n_exc = 0; s->max_len = w; s->uniform_len = 0;
-            s->ext_seq = d_seq.p; s->ext_off = d_off.p;
-            if (int rc = enqueue(c, s)) return rc;
-            Slot *done = nullptr;
-            if (int rc = collect_impl(c, &done)) return rc;
-            const bool ok = done->status == GROOT_OK;
-            const uint32_t nt = done->n_trav;
-            const uint32_t seed_rows = std::min<uint32_t>(kOutSeedDw * kOutMaxTrav, c->seed_slots);
-            travs.resize(nt); masks.resize((size_t)nt * pw); icnt.resize(m); iwin.resize((size_t)m * kIncrCap);
-            nseeds.resize(m); seedw.resize((size_t)seed_rows * m);
-            if (ok) {
-                if (nt) {
-                    HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
-                    HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
-                }
-                HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * kIncrCap * 4, hipMemcpyDeviceToHost));
+        c->incr_cap = incr_cap;
+        HIP_TRY(c, c->incr_cnt.reserve(m));
+        HIP_TRY(c, c->incr_win.reserve((size_t)m * incr_cap));
+        Slot *s = nullptr;
+        if (int rc = take_slot(c, m, &s)) return rc;
+        if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;      // (resident input: no staging is allocated for this)
+        HIP_TRY(c, hipMemcpy(d_seq.p, seqs.data(), (size_t)m * w, hipMemcpyHostToDevice));
+        s->input = Slot::IN_DEVICE; s->n_reads = m; s->first_read_id = 0; s->mixed_len = false; s->one_len = true;
+        s->n_bases = 0; s->n_exc = 0; s->max_len = w; s->uniform_len = 0;
+        s->ext_seq = d_seq.p; s->ext_off = d_off.p;
+        if (int rc = enqueue(c, s)) return rc;
+        Slot *done = nullptr;
+        if (int rc = collect_impl(c, &done)) return rc;
+        const bool ok = done->status == GROOT_OK;
+        const uint32_t nt = done->n_trav;
+        const uint32_t seed_rows = second_pass ? c->seed_slots : std::min<uint32_t>(4 * kOutSeedDw, c->seed_slots);
+        travs.resize(nt); masks.resize((size_t)nt * pw); icnt.resize(m); iwin.resize((size_t)m * incr_cap);
+        nseeds.resize(m); seedw.resize((size_t)seed_rows * m);
+        if (ok) {
+            if (nt) {
+                HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
             }
-            release_slot(c, done);
-            if (!ok) return GROOT_OK;
-            size_t t0 = 0;
-            for (uint32_t j = 0; j < m; j++) {              // records come in (read, ord) order
-                size_t t1 = t0;
-                while (t1 < nt && travs[t1].read_id == j) t1++;
-                const uint32_t cnt = (uint32_t)(t1 - t0), ni = icnt[j] & 0x7FFFFFFFu, nsd = nseeds[j] & 0x7FFFFFFFu;
-                uint64_t recs = 0;
-                for (size_t t = t0; t < t1; t++)
-                    for (uint32_t x = 0; x < pw; x++) recs += (uint64_t)__builtin_popcountll(masks[t * pw + x]);
-                const size_t first = tab.size() / (sq * 4);
-                // (its seed windows travel in the entries too when they fit: what text_lookup_kernel's reads report as their seeds)
-                const bool seeds_fit = nsd <= std::min<uint32_t>(kOutSeedDw * std::max(cnt, 1u), c->seed_slots) && nsd <= seed_rows;
-                const uint32_t n_ent = std::max(cnt, 1u);      // (no traversal: one entry for the calls, the seeds and the counters)
-                if (cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(kIncrCap, 2 * n_ent) && recs <= 0xFFFFu && first + n_ent < (1u << kOutIdxBits)) {
-                    for (uint32_t e = 0; e < n_ent; e++) {
-                        const size_t b = tab.size();
-                        tab.resize(b + sq * 4, 0);
-                        if (cnt) {
-                            const groot_trav &t = travs[t0 + e];
-                            tab[b] = t.node; tab[b + 1] = t.offset; tab[b + 2] = t.graph_id; tab[b + 3] = (uint32_t)t.flags;
-                        } else tab[b] = kEmpty;
-                        // multimapped / mapped as the align stage counts them (boss.go:195-200): a read with seeds is mapped
-                        if (e == 0) tab[b + 3] |= ((icnt[j] >> 31) ? 0x100u : 0u) | (nsd ? 0x200u : 0u) | ((uint32_t)recs << 16);
-                        tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * kIncrCap + 2 * e] : kEmpty;
-                        tab[b + 5] = 2 * e + 1 < ni ? iwin[(size_t)j * kIncrCap + 2 * e + 1] : kEmpty;
-                        for (uint32_t x = 0; x < kOutSeedDw; x++)
-                            tab[b + sq * 4 - kOutSeedDw + x] = seeds_fit && kOutSeedDw * e + x < nsd ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
-                        for (uint32_t x = 0; x < pw; x++) {
-                            tab[b + kOutHdrDw + 2 * x] = cnt ? (uint32_t)masks[(t0 + e) * pw + x] : 0u;
-                            tab[b + kOutHdrDw + 2 * x + 1] = cnt ? (uint32_t)(masks[(t0 + e) * pw + x] >> 32) : 0u;
-                        }
+            HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * incr_cap * 4, hipMemcpyDeviceToHost));
+        }
+        release_slot(c, done);
+        if (!ok) return GROOT_OK;
+        size_t t0 = 0;
+        for (uint32_t j = 0; j < m; j++) {                  // records come in (read, ord) order
+            size_t t1 = t0;
+            while (t1 < nt && travs[t1].read_id == j) t1++;
+            const size_t sid = ids[j];
+            const uint32_t cnt = (uint32_t)(t1 - t0), ni = icnt[j] & 0x7FFFFFFFu, nsd = nseeds[j] & 0x7FFFFFFFu;
+            if (!second_pass && (ni > incr_cap || nsd > seed_rows)) { big.push_back(sid); t0 = t1; continue; }
+            const size_t first = tab.size() / (sq * 4);
+            const uint32_t n_ent = std::max(cnt, 1u);       // (no traversal: one entry for the calls, the seeds and the counters)
+            // (its seed windows travel in the entries too when they fit: what text_lookup_kernel's reads report as their seeds)
+            const bool seeds_fit = nsd <= std::min<uint32_t>(kOutSeedDw * n_ent, c->seed_slots) && nsd <= seed_rows;
+            if (cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(incr_cap, 2 * n_ent) && first + n_ent < (1u << kOutIdxBits)) {
+                for (uint32_t e = 0; e < n_ent; e++) {
+                    const size_t b = tab.size();
+                    tab.resize(b + sq * 4, 0);
+                    if (cnt) {
+                        const groot_trav &t = travs[t0 + e];
+                        tab[b] = t.node; tab[b + 1] = t.offset; tab[b + 2] = t.graph_id; tab[b + 3] = (uint32_t)t.flags;
+                    } else tab[b] = kEmpty;
+                    // multimapped / mapped as the align stage counts them (boss.go:195-200): a read with seeds is mapped
+                    if (e == 0) tab[b + 3] |= ((icnt[j] >> 31) ? 0x100u : 0u) | (nsd ? 0x200u : 0u) | (cnt << 16);
+                    tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * incr_cap + 2 * e] : kEmpty;
+                    tab[b + 5] = 2 * e + 1 < ni ? iwin[(size_t)j * incr_cap + 2 * e + 1] : kEmpty;
+                    for (uint32_t x = 0; x < kOutSeedDw; x++)
+                        tab[b + sq * 4 - kOutSeedDw + x] = seeds_fit && kOutSeedDw * e + x < nsd ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
+                    for (uint32_t x = 0; x < pw; x++) {
+                        tab[b + kOutHdrDw + 2 * x] = cnt ? (uint32_t)masks[(t0 + e) * pw + x] : 0u;
+                        tab[b + kOutHdrDw + 2 * x + 1] = cnt ? (uint32_t)(masks[(t0 + e) * pw + x] >> 32) : 0u;
                     }
-                    // are the IncrementSubPath calls exactly the string's seed windows, once each?  (then the signature kernel counts them itself)
-                    bool all_seeds = ni == nsd && ni <= 4 && ni <= c->seed_slots;
-                    if (all_seeds) {
-                        uint32_t a4[4], b4[4];
-                        for (uint32_t x = 0; x < ni; x++) { a4[x] = iwin[(size_t)j * kIncrCap + x]; b4[x] = seedw[(size_t)x * m + j]; }
-                        std::sort(a4, a4 + ni); std::sort(b4, b4 + ni);
-                        all_seeds = std::equal(a4, a4 + ni, b4) && std::adjacent_find(a4, a4 + ni) == a4 + ni;
-                    }
-                    sinfo[s0 + j] = kOutTab | (cnt ? (cnt - 1) << kOutTravShift : kOutNoRec) | (all_seeds ? kOutAllSeeds : 0u) | (uint32_t)first;
-                    in_text[s0 + j] = seeds_fit && text_ok;
-                    c->out_tabulated++;
                 }
-                t0 = t1;
+                // are the IncrementSubPath calls exactly the string's seed windows, once each?  (then the signature kernel counts them itself)
+                bool all_seeds = ni == nsd && ni <= 4 && ni <= c->seed_slots;
+                if (all_seeds) {
+                    uint32_t a4[4], b4[4];
+                    for (uint32_t x = 0; x < ni; x++) { a4[x] = iwin[(size_t)j * incr_cap + x]; b4[x] = seedw[(size_t)x * m + j]; }
+                    std::sort(a4, a4 + ni); std::sort(b4, b4 + ni);
+                    all_seeds = std::equal(a4, a4 + ni, b4) && std::adjacent_find(a4, a4 + ni) == a4 + ni;
+                }
+                sinfo[sid] = kOutTab | (cnt ? std::min(cnt - 1, kOutTravLong) << kOutTravShift : kOutNoRec) | (all_seeds ? kOutAllSeeds : 0u) | (uint32_t)first;
+                in_text[sid] = seeds_fit && text_ok;
+                c->out_tabulated++;
             }
-            return GROOT_OK;
-        };
-        rc_all = run();
+            t0 = t1;
+        }
+        return GROOT_OK;
+    };
+    {
+        std::vector<size_t> ids(chunk);
+        for (size_t s0 = 0; s0 < NS && !rc_all; s0 += chunk) {
+            const uint32_t m = (uint32_t)std::min<size_t>(chunk, NS - s0);
+            std::iota(ids.begin(), ids.begin() + m, s0);
+            rc_all = run(ids.data(), m, kIncrCap, false);
+        }
+        // second pass: the few strings whose reads bring dozens of seed windows (a sequence shared by many graphs): everything kept
+        const uint32_t chunk2 = std::min<uint32_t>(chunk, 4096);
+        for (size_t s0 = 0; s0 < big.size() && !rc_all; s0 += chunk2)
+            rc_all = run(big.data() + s0, (uint32_t)std::min<size_t>(chunk2, big.size() - s0), kIncrCapBig, true);
     }
     c->tab_capture = false;
     c->incr_cnt.release(); c->incr_win.release();
@@ -1602,8 +1619,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     }
     lap("text table");
     if (stats)
-        fprintf(stderr, "[groot open]   memo: %llu of %llu distinct path strings tabulated, %llu entries of %u bytes; text table: %llu strings in %u slots of 64 bytes\n",
-                (unsigned long long)c->out_tabulated, (unsigned long long)c->out_strings, (unsigned long long)c->out_entries, sq * 16,
+        fprintf(stderr, "[groot open]   memo: %llu of %llu distinct path strings tabulated (%llu in the second pass), %llu entries of %u bytes; text table: %llu strings in %u slots of 64 bytes\n",
+                (unsigned long long)c->out_tabulated, (unsigned long long)c->out_strings, (unsigned long long)big.size(), (unsigned long long)c->out_entries, sq * 16,
                 (unsigned long long)c->text_entries, c->dix.text_tab ? c->dix.text_mask + 1 : 0u);
     return GROOT_OK;
 }

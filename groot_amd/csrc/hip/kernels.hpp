@@ -220,7 +220,7 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
 __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
                                               const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
                                               const uint32_t s2, const uint32_t s3, const bool high, const bool have_codes = false,
-                                              const uint32_t code_f = 0, const uint32_t code_r = 0, const SeedAhead *ahead = nullptr)
+                                              const uint32_t code_f = 0, const uint32_t code_r = 0, const SeedAhead *ahead = nullptr, const bool asc = false)
 {
     // have_codes: the read is all ACGT and at least 12 bases long; code_f / code_r = 2-bit codes of oriented bases [0,12) of
     // the forward read / its reverse complement (base i at bits 2i)
@@ -274,7 +274,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
     }
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (high ? 0x80000000u : 0u));
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (asc ? kRecAscending : 0u) | (high ? 0x80000000u : 0u));
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);
@@ -283,7 +283,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
 // the same for a read known to be bases [o, o + WindowSize) of a window text row: its verdicts come from the table made at open
 __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
                                                     const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
-                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes)
+                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes, const bool asc)
 {
     a.seed_count[r] = n_hits;
     if (a.sort_key) {
@@ -293,10 +293,19 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
     }
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u));
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u) | (asc ? kRecAscending : 0u));
         rq[1] = make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);
+}
+
+// traversal records of a string with a tabulated outcome (info = its DeviceIndex::sig_info word)
+__device__ __forceinline__ uint32_t tab_travs(const DeviceIndex &ix, const uint32_t info)
+{
+    if (info & kOutNoRec) return 0u;
+    const uint32_t f = (info >> kOutTravShift) & 15u;
+    if (f != kOutTravLong) return f + 1u;
+    return ix.out_tab[(size_t)(info & ((1u << kOutIdxBits) - 1u)) * ix.out_stride_q].w >> 16;   // (a read of a sequence that dozens of graphs share)
 }
 
 // the same for a read whose whole graphMinion outcome is tabulated (info = its DeviceIndex::sig_info word): nothing is left for the
@@ -319,7 +328,7 @@ __device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint3
         counted = kTabCounted;
     }
     a.tab_idx[r] = (info & ((1u << kOutIdxBits) - 1u)) | counted;
-    a.trav_cnt[r] = (info & kOutNoRec) ? 0u : ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
+    a.trav_cnt[r] = tab_travs(a.ix, info);
     seed_counters(a, r, q, n_hits, true);
 }
 
@@ -484,9 +493,13 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
     const uint32_t min_eq = q <= ix.max_q ? ix.q_min_eq[q] : (uint32_t)s_ + 1;
     uint32_t min_win = kEmpty;
     uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;   // first four seeds, for the read record
+    bool asc = true;
+    uint32_t prev_id = 0;
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
         if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
+        asc &= n_hits == 0 || id > prev_id;                // (the exact / signature tables return windows in ascending id)
+        prev_id = id;
         n_hits++;
         min_win = min(min_win, id);
     };
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
             }
         }
     }
-    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0);
+    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0, false, 0, 0, nullptr, asc);
     };   // one_read
     if constexpr (LIST) {
         const uint32_t n_todo = *a.todo_count;
@@ -630,6 +643,7 @@ __host__ __device__ __forceinline__ uint64_t sig_hash_fin(uint64_t x)
 
 // LDS: a static 512-byte table ({leaving, entering} base -> 16-byte entries, at strides 16 and 64, see below; static so
 // that its address folds into the ds_read offsets), then dynamic:
+constexpr uint32_t kTextBad = 2048;    // text_lookup_kernel: bytes of its bad-group bit set (one bit per 4 bases of a span of up to 64 KB)
 constexpr uint32_t kSigBad = 0;        // 4096 bits: 16-byte chunks of the span holding a byte other than ACGT
 constexpr uint32_t kSigCodes = 512;    // one dword per 16 bases
 #ifndef GROOT_SIG_WAVES
@@ -919,9 +933,13 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     if (n_tagged && cls == kEmpty) { todo_push(a, r); return; }
     uint32_t n_hits = 0, min_win = kEmpty;
     uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;
+    bool asc = true;
+    uint32_t prev_id = 0;
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
         if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
+        asc &= n_hits == 0 || id > prev_id;                // (the exact / signature tables return windows in ascending id)
+        prev_id = id;
         n_hits++;
         min_win = min(min_win, id);
     };
@@ -933,8 +951,8 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (e.x == tag && e.z == cls) hit(e.y);
         }
     if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte, s0, s1, s2, s3);
-    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win]);
-    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead);   // all bytes are ACGT
+    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc);
+    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead, asc);   // all bytes are ACGT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -959,11 +977,12 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
 {
     static_assert(TW >= 1 && TW <= 14, "a 64-byte entry holds 224 bases");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *badbits = reinterpret_cast<uint32_t *>(smem + kSigBad);
-    uint32_t *codes = reinterpret_cast<uint32_t *>(smem + kSigCodes);
+    // LDS: one bit per 4 bases of the span (set: a byte other than ACGT among them), then one dword of codes per 16 bases
+    uint32_t *badbits = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *codes = reinterpret_cast<uint32_t *>(smem + kTextBad);
     const DeviceIndex &ix = a.ix;
     const unsigned tid = threadIdx.x;
-    if (tid < 128) badbits[tid] = 0;
+    for (uint32_t i = tid; i < kTextBad / 4; i += kBlock) badbits[i] = 0;
     // ---- stage this block's reads as 2-bit codes (as sketch_sig_kernel does): one contiguous span, 16 bases per lane per load ----
     const uint32_t r0 = blockIdx.x * kBlock;
     const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
@@ -977,10 +996,11 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
         const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
         for (uint32_t i = tid; i < n16; i += kBlock) {
             const uint4 v = src[i];
-            uint32_t bad = 0;
-            const uint32_t c = codes_of4(v.x, bad) | (codes_of4(v.y, bad) << 8) | (codes_of4(v.z, bad) << 16) | (codes_of4(v.w, bad) << 24);
+            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            const uint32_t c = codes_of4(v.x, b0) | (codes_of4(v.y, b1) << 8) | (codes_of4(v.z, b2) << 16) | (codes_of4(v.w, b3) << 24);
             codes[i] = c;
-            if (bad) atomicOr(&badbits[i >> 5], 1u << (i & 31));
+            const uint32_t bad = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
+            if (bad) atomicOr(&badbits[i >> 3], bad << (4 * (i & 7)));
         }
     }
     __syncthreads();
@@ -990,7 +1010,8 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
     bool mine = in_lds && len == ix.w;
     if (mine) {
-        const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
+        // groups of 4 bases the read touches (a neighbour's byte in a shared group can send the read to the list: conservative)
+        const uint32_t c0 = (uint32_t)(o0 - base16) >> 2, c1 = (uint32_t)(o0 - base16 + len - 1) >> 2;
         for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
             uint32_t bits = badbits[w];
             if (w == c0 >> 5) bits &= ~0u << (c0 & 31);
@@ -1038,7 +1059,7 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;
     a.sort_key[r] = kEmpty;
     a.tab_idx[r] = (info & ((1u << kOutIdxBits) - 1u)) | kTabSeedsHere;
-    a.trav_cnt[r] = (info & kOutNoRec) ? 0u : ((info >> kOutTravShift) & (kOutMaxTrav - 1u)) + 1u;
+    a.trav_cnt[r] = tab_travs(ix, info);
 }
 
 // groot_hip_submit_packed: 2 bits per base back to ASCII in HBM (code (byte >> 1) & 3: A=0 C=1 T=2 G=3), 16 bases per
@@ -1270,7 +1291,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
     uint32_t U = 64;
     if (a.round_lanes) U = a.round_lanes;
     else
-        while (U > 8u && n_todo < U * (gridDim.x * (uint32_t)(kBlock / 64))) U >>= 1;
+        while (U > 1u && n_todo < U * (gridDim.x * (uint32_t)(kBlock / 64))) U >>= 1;
     const uint32_t n_rounds = (n_todo + U - 1u) / U;
     // (odd on purpose: with an even count the two-round chunks behind the head start at multiples of 128 slots and the kernel is
     // 6 % slower -- measured both ways, cause not established)
@@ -1478,6 +1499,12 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
         bool advance = false;                                   // leave the current scan range (one call site: the code is large)
 
         if (run == PH_FETCH) {
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
+#define GROOT_SUBT(i) do { const unsigned long long t__ = wall_clock64(); if ((threadIdx.x & 63) == (__ffsll((unsigned long long)__ballot(1)) - 1)) atomicAdd(&a.ctr->dbg[40 + (i)], t__ - wc_sub); wc_sub = t__; } while (0)
+            unsigned long long wc_sub = wall_clock64();
+#else
+#define GROOT_SUBT(i) ((void)0)
+#endif
             if (!have_read) {
                 GROOT_EV(3);
                 r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
@@ -1486,11 +1513,14 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 const uint32_t sc = ra.w;
                 cnt = min(sc & kRecCountMask, a.seed_slots);   // overflow already flagged; batch is re-run
                 cls = a.perm ? (sc >> 24) & 0x3Fu : 0x80u;     // bit 7: no verdicts without the seed stage's sort keys
+                if (sc & kRecAscending) cls |= 0x100u;         // bit 8: the read's seed list is in ascending window order
                 if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
                 high_byte = sc >> 31;
                 len = ra.z;
                 p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
                 sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
+                if (cnt > 4) sd0 = 0;                          // (then sd0 is the position in the seed list: see below)
+                GROOT_SUBT(0);
                 if (LDSR && 2 + 4 * ((len + 27) >> 4) > a.lds_stride_dw) {   // longer than the max_len the batch was submitted with
                     atomicOr(&a.ctr->flags, kFlagLongRead);
                     a.trav_cnt[r] = 0;
@@ -1520,6 +1550,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                     }
                 }
             }
+            GROOT_SUBT(1);
             // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
             uint32_t nw = kEmpty;
             if (cnt <= 4) {                                   // the seeds travel in the read record
@@ -1527,6 +1558,23 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 if (cnt > 1 && (long long)sd1 > last && sd1 < nw) nw = sd1;
                 if (cnt > 2 && (long long)sd2 > last && sd2 < nw) nw = sd2;
                 if (cnt > 3 && (long long)sd3 > last && sd3 < nw) nw = sd3;
+            } else if (cls & 0x100u) {
+                // An ascending list is walked, not searched (a read of a sequence that many graphs share brings a hundred seed
+                // windows: looking through all of them for every one of them made it the slowest read of its batch by far).
+                // sd0 = first position not handled yet; after a graph is done `last` has jumped past its windows: bisect.
+                uint32_t lo = sd0;
+                uint32_t cand = lo < cnt ? a.seed_win[(size_t)lo * a.n_reads + r] : kEmpty;
+                if (lo < cnt && (long long)cand <= last) {
+                    uint32_t hi = cnt;
+                    lo++;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((long long)a.seed_win[(size_t)mid * a.n_reads + r] > last) hi = mid; else lo = mid + 1;
+                    }
+                    cand = lo < cnt ? a.seed_win[(size_t)lo * a.n_reads + r] : kEmpty;
+                }
+                if (lo < cnt) nw = cand;
+                sd0 = lo + 1;
             } else
                 for (uint32_t j = 0; j < cnt; j++) {
                     const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
@@ -1536,6 +1584,12 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 GROOT_EV(4);
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
                 atomicAdd(&a.ctr->dbg[64 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // when in its round the lane finished
+#endif
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
+                if (wc_iter - wc_round0 >= 100) {              // slow reads, by name (meaningful with GROOT_ROUND_LANES=1)
+                    const unsigned long long sl = atomicAdd(&a.ctr->dbg[128], 1ull);
+                    if (sl < 60) a.ctr->dbg[129 + sl] = (unsigned long long)r | ((unsigned long long)(wc_iter - wc_round0) << 32);
+                }
 #endif
                 a.trav_cnt[r] = ord;
                 mapped++;                                     // boss.go:195-200
@@ -1550,6 +1604,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             uint4 wa, wb;                                     // the whole lshe.Key in one 32-byte load
             load32(ix.win_rec + w, wa, wb);
             g = wa.x;
+            GROOT_SUBT(2);
             if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
             if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
             if (a.update_weights) {                            // :67 IncrementSubPath
@@ -1567,10 +1622,11 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                     }
                 }
             }
+            GROOT_SUBT(3);
             if (a.incr_cnt) {              // capture pass: which windows had IncrementSubPath called, in call order
                 const uint32_t n = a.incr_cnt[r];
                 a.incr_cnt[r] = n + 1;
-                if (n < kIncrCap) a.incr_win[(size_t)r * kIncrCap + n] = w;
+                if (n < a.incr_cap) a.incr_win[(size_t)r * a.incr_cap + n] = w;
             }
             if (a.no_align) continue;                         // :70-72
             seed = wa.y; off0 = wa.z;
@@ -1579,6 +1635,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             seed_s0 = wb.z; seed_len = wb.w;
             GROOT_EV(5);
             advance = start_orientation(0);
+            GROOT_SUBT(4);
         } else if (run == PH_SCAN) {
             if (sc_pos >= sc_end) { GROOT_EV(6); advance = true; }   // only after a DFS that used the range's last offset
             else {
@@ -1913,18 +1970,26 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             const uint4 *e = t.out_tab + (size_t)(ti + j) * t.stride_q;
             const uint4 h = e[0];                          // node, offset, graph, flags | multimapped << 8 | records << 16
             const uint4 x = e[1];                          // two call-count windows, first path word
+            const uint4 y = pw_out > 1 ? e[2] : make_uint4(0, 0, 0, 0);   // path words 1, 2
+            const uint4 sd = e[t.stride_q - 1];            // seed windows (the four loads of one entry are in flight together)
             if (count_here) {
                 if (x.x != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.x], 1u);
                 if (x.y != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.y], 1u);
             }
             if (seeds_here) {
-                const uint4 sd = e[t.stride_q - 1];
                 if (sd.x != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.x; ns++; }
                 if (sd.y != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.y; ns++; }
                 if (sd.z != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.z; ns++; }
                 if (sd.w != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.w; ns++; }
             }
-            if (j == 0) { alns += h.w >> 16; mapped += (h.w >> 9) & 1u; multimapped += (h.w >> 8) & 1u; }
+            if (j == 0) { mapped += (h.w >> 9) & 1u; multimapped += (h.w >> 8) & 1u; }
+            if (nt) {                                      // one sam.Record per path of the traversal (alignment.go:114-156)
+                alns += __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
+                if (pw_out > 3) {
+                    const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
+                    for (uint32_t w = 6; w < 2 * pw_out; w++) alns += __popc(ew[w]);
+                }
+            }
             if (!fits || !nt || (t.exp & 4u)) continue;
             groot_trav tr;
             tr.read_id = t.first_read_id + r; tr.graph_id = h.z; tr.node = h.x; tr.offset = h.y;
@@ -1933,7 +1998,6 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             uint64_t *mo = mask_out + (size_t)(i + j) * pw_out;
             mo[0] = (uint64_t)x.z | ((uint64_t)x.w << 32);
             if (pw_out > 1) {
-                const uint4 y = e[2];
                 mo[1] = (uint64_t)y.x | ((uint64_t)y.y << 32);
                 if (pw_out > 2) mo[2] = (uint64_t)y.z | ((uint64_t)y.w << 32);
                 const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
