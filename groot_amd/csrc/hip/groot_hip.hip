@@ -152,6 +152,7 @@ struct groot_ctx {
     DevBuf<uint32_t> tab_idx, tab_hist, incr_cnt, incr_win;
     DevBuf<uint4> text_tab;                // text_lookup_kernel: strings with a tabulated outcome, keyed by their bases
     uint64_t text_entries = 0;
+    uint32_t batches_without_text = 0;
     double text_hit_frac = 1.0;            // share of the latest batch's reads the outcome table answered: picks the first kernel of the seed stage
     std::vector<uint16_t> h_q_min_eq;      // host copy of DeviceIndex::q_min_eq: which seed kernel a batch of one read length gets
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
@@ -643,7 +644,10 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     s->sig_used = c->dix.sig && !c->prm.keep_sketches && sig_useful;
     // Which kernel sees the batch first?  When the outcome table answered most of the latest batch, the text lookup (no hashing at
     // all; what it does not find goes through the full-width kernel, read by read); else the signature kernel as before.
-    s->text_used = s->sig_used && c->dix.text_tab && c->dix.out_tab && c->text_hit_frac >= 0.7 && s->max_len >= c->dix.w;
+    // (the share is only known exactly while the lookup runs: every eighth batch tries it again)
+    const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= 8;
+    s->text_used = !c->prm.keep_sketches && c->dix.text_tab && c->dix.out_tab && text_try && s->max_len >= c->dix.w && !c->tab_capture;
+    if (s->text_used) c->batches_without_text = 0;
     if (s->text_used) {
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
@@ -1495,17 +1499,21 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
             const uint32_t cnt = (uint32_t)(t1 - t0), ni = icnt[j] & 0x7FFFFFFFu, nsd = nseeds[j] & 0x7FFFFFFFu;
             if (!second_pass && (ni > incr_cap || nsd > seed_rows)) { big.push_back(sid); t0 = t1; continue; }
             const size_t first = tab.size() / (sq * 4);
-            const uint32_t n_ent = std::max(cnt, 1u);       // (no traversal: one entry for the calls, the seeds and the counters)
-            // (its seed windows travel in the entries too when they fit: what text_lookup_kernel's reads report as their seeds)
-            const bool seeds_fit = nsd <= std::min<uint32_t>(kOutSeedDw * n_ent, c->seed_slots) && nsd <= seed_rows;
-            if (cnt <= kOutMaxTrav && ni <= std::min<uint32_t>(incr_cap, 2 * n_ent) && first + n_ent < (1u << kOutIdxBits)) {
+            // entries: one per traversal (at least one), and as many more -- without a record -- as the string's IncrementSubPath calls
+            // (two per entry) and seed windows (four per entry) need: at lower containment thresholds a read brings several windows
+            // of one graph and one traversal
+            const bool seeds_fit = nsd <= c->seed_slots && nsd <= seed_rows;
+            const uint32_t n_ent = std::max(std::max(cnt, 1u), std::max((ni + 1) / 2, seeds_fit ? (nsd + kOutSeedDw - 1) / kOutSeedDw : 0u));
+            const uint32_t n_extra = n_ent - std::max(cnt, 1u);
+            if (cnt <= kOutMaxTrav && ni <= incr_cap && n_extra < (1u << 12) && first + n_ent < (1u << kOutIdxBits)) {
                 for (uint32_t e = 0; e < n_ent; e++) {
                     const size_t b = tab.size();
                     tab.resize(b + sq * 4, 0);
-                    if (cnt) {
+                    if (e < cnt) {
                         const groot_trav &t = travs[t0 + e];
                         tab[b] = t.node; tab[b + 1] = t.offset; tab[b + 2] = t.graph_id; tab[b + 3] = (uint32_t)t.flags;
                     } else tab[b] = kEmpty;
+                    if (e == 0) tab[b + 2] = (tab[b + 2] & 0xFFFFFu) | (n_extra << 20);   // (graph ids stay below 2^20: checked at open)
                     // multimapped / mapped as the align stage counts them (boss.go:195-200): a read with seeds is mapped
                     if (e == 0) tab[b + 3] |= ((icnt[j] >> 31) ? 0x100u : 0u) | (nsd ? 0x200u : 0u) | (cnt << 16);
                     tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * incr_cap + 2 * e] : kEmpty;
@@ -1513,8 +1521,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                     for (uint32_t x = 0; x < kOutSeedDw; x++)
                         tab[b + sq * 4 - kOutSeedDw + x] = seeds_fit && kOutSeedDw * e + x < nsd ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
                     for (uint32_t x = 0; x < pw; x++) {
-                        tab[b + kOutHdrDw + 2 * x] = cnt ? (uint32_t)masks[(t0 + e) * pw + x] : 0u;
-                        tab[b + kOutHdrDw + 2 * x + 1] = cnt ? (uint32_t)(masks[(t0 + e) * pw + x] >> 32) : 0u;
+                        tab[b + kOutHdrDw + 2 * x] = e < cnt ? (uint32_t)masks[(t0 + e) * pw + x] : 0u;
+                        tab[b + kOutHdrDw + 2 * x + 1] = e < cnt ? (uint32_t)(masks[(t0 + e) * pw + x] >> 32) : 0u;
                     }
                 }
                 // are the IncrementSubPath calls exactly the string's seed windows, once each?  (then the signature kernel counts them itself)
@@ -1591,9 +1599,9 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     c->dix.out_tab = c->out_tab.p;
     c->dix.out_stride_q = sq;
     // ---- 4. text table: 64-byte entries {tag, sig_info word, bases}, keyed by the bases ----
-    // (only where Query is on the every-slot-equal branch for WindowSize-mers: the same condition under which the signature kernel
-    // decides reads; nothing depends on it for correctness -- the memo is the pipeline's own output -- it keeps the two paths alike)
-    if (text_ok && c->h_q_min_eq[q_w] == c->s) {
+    // (at ANY containment threshold: the memo is the pipeline's own output for the string under this ctx's parameters, whichever
+    // branch of Query produced its seeds)
+    if (text_ok) {
         size_t ns = 0;
         for (size_t j = 0; j < NS; j++) ns += in_text[j];
         uint32_t cap = 1024;
@@ -1766,7 +1774,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     c->dix.sig_mask = cap - 1;
     c->dix.win_text = c->win_text.p;
     // 5. outcome table: the align stage itself, once, on every string that confirms reads
-    if (c->dix.sig_info && !getenv("GROOT_NO_OUTCOME_TABLE") && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len) {
+    if (c->dix.sig_info && !getenv("GROOT_NO_OUTCOME_TABLE") && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
         const auto t0 = std::chrono::steady_clock::now();
         if (int rc = build_outcome_table(c, v, text, tlen, verdict, w, vstride)) return rc;
         c->out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -220,7 +220,8 @@ __device__ __forceinline__ void seed_counters(const SeedArgs &a, const uint32_t 
 __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
                                               const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
                                               const uint32_t s2, const uint32_t s3, const bool high, const bool have_codes = false,
-                                              const uint32_t code_f = 0, const uint32_t code_r = 0, const SeedAhead *ahead = nullptr, const bool asc = false)
+                                              const uint32_t code_f = 0, const uint32_t code_r = 0, const SeedAhead *ahead = nullptr, const bool asc = false,
+                                              const uint32_t max_win = 0)
 {
     // have_codes: the read is all ACGT and at least 12 bases long; code_f / code_r = 2-bit codes of oriented bases [0,12) of
     // the forward read / its reverse complement (base i at bits 2i)
@@ -275,7 +276,9 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
         rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (asc ? kRecAscending : 0u) | (high ? 0x80000000u : 0u));
-        rq[1] = make_uint4(s0, s1, s2, s3);
+        // (more than four seeds: the smallest and the largest window instead of the first two -- the align stage starts at the
+        // smallest and knows when nothing is left without looking through the list)
+        rq[1] = n_hits > 4 ? make_uint4(min_win, max_win, s2, s3) : make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);
 }
@@ -283,7 +286,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
 // the same for a read known to be bases [o, o + WindowSize) of a window text row: its verdicts come from the table made at open
 __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
                                                     const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
-                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes, const bool asc)
+                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes, const bool asc, const uint32_t max_win)
 {
     a.seed_count[r] = n_hits;
     if (a.sort_key) {
@@ -294,7 +297,7 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
         rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u) | (asc ? kRecAscending : 0u));
-        rq[1] = make_uint4(s0, s1, s2, s3);
+        rq[1] = n_hits > 4 ? make_uint4(min_win, max_win, s2, s3) : make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);
 }
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
     uint32_t min_win = kEmpty;
     uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;   // first four seeds, for the read record
     bool asc = true;
-    uint32_t prev_id = 0;
+    uint32_t prev_id = 0, max_win = 0;
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
         if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
         prev_id = id;
         n_hits++;
         min_win = min(min_win, id);
+        max_win = max(max_win, id);
     };
     if (min_eq == (uint32_t)s_) {
         // Containment > t needs every slot equal: windows with an identical sketch.  One probe
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_
             }
         }
     }
-    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0, false, 0, 0, nullptr, asc);
+    seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0, false, 0, 0, nullptr, asc, max_win);
     };   // one_read
     if constexpr (LIST) {
         const uint32_t n_todo = *a.todo_count;
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     uint32_t n_hits = 0, min_win = kEmpty;
     uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;
     bool asc = true;
-    uint32_t prev_id = 0;
+    uint32_t prev_id = 0, max_win = 0;
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
         if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
@@ -942,6 +946,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         prev_id = id;
         n_hits++;
         min_win = min(min_win, id);
+        max_win = max(max_win, id);
     };
     if (n_tagged == 1) hit(only_id);
     else if (n_tagged)
@@ -951,8 +956,8 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (e.x == tag && e.z == cls) hit(e.y);
         }
     if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte, s0, s1, s2, s3);
-    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc);
-    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead, asc);   // all bytes are ACGT
+    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc, max_win);
+    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead, asc, max_win);   // all bytes are ACGT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1519,7 +1524,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 len = ra.z;
                 p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
                 sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
-                if (cnt > 4) sd0 = 0;                          // (then sd0 is the position in the seed list: see below)
+                if (cnt > 4 && (cls & 0x100u)) sd0 = 0;        // (ascending list: sd0 is the position in it; else sd0 / sd1 = smallest / largest window)
                 GROOT_SUBT(0);
                 if (LDSR && 2 + 4 * ((len + 27) >> 4) > a.lds_stride_dw) {   // longer than the max_len the batch was submitted with
                     atomicOr(&a.ctr->flags, kFlagLongRead);
@@ -1575,7 +1580,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                 }
                 if (lo < cnt) nw = cand;
                 sd0 = lo + 1;
-            } else
+            } else if (last < 0) nw = sd0;                    // the smallest window, from the read record
+            else if ((long long)sd1 > last)                   // (else nothing is left: no look at the list)
                 for (uint32_t j = 0; j < cnt; j++) {
                     const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
                     if ((long long)cand > last && cand < nw) nw = cand;
@@ -1965,10 +1971,11 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
         const bool fits = i < cap && nt <= cap - i;
         if (!fits) atomicOr(&ctr->flags, kFlagTravOverflow);
         const uint32_t row = t.update_weights ? t.q_row[t.q_tab] : 0u;
-        const uint32_t n_ent = nt ? nt : 1u;                  // (a string without traversals still has its calls, seeds and counters)
+        uint32_t n_ent = nt ? nt : 1u;                        // (a string without traversals still has its calls, seeds and counters)
         for (uint32_t j = 0; j < n_ent; j++) {
             const uint4 *e = t.out_tab + (size_t)(ti + j) * t.stride_q;
-            const uint4 h = e[0];                          // node, offset, graph, flags | multimapped << 8 | records << 16
+            uint4 h = e[0];                                // node, offset, graph (| entries without a record << 20 in the first), flags | ...
+            if (j == 0) { n_ent += h.z >> 20; h.z &= 0xFFFFFu; }
             const uint4 x = e[1];                          // two call-count windows, first path word
             const uint4 y = pw_out > 1 ? e[2] : make_uint4(0, 0, 0, 0);   // path words 1, 2
             const uint4 sd = e[t.stride_q - 1];            // seed windows (the four loads of one entry are in flight together)
@@ -1983,14 +1990,14 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
                 if (sd.w != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.w; ns++; }
             }
             if (j == 0) { mapped += (h.w >> 9) & 1u; multimapped += (h.w >> 8) & 1u; }
-            if (nt) {                                      // one sam.Record per path of the traversal (alignment.go:114-156)
+            if (j < nt) {                                  // one sam.Record per path of the traversal (alignment.go:114-156)
                 alns += __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
                 if (pw_out > 3) {
                     const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
                     for (uint32_t w = 6; w < 2 * pw_out; w++) alns += __popc(ew[w]);
                 }
             }
-            if (!fits || !nt || (t.exp & 4u)) continue;
+            if (!fits || j >= nt || (t.exp & 4u)) continue;
             groot_trav tr;
             tr.read_id = t.first_read_id + r; tr.graph_id = h.z; tr.node = h.x; tr.offset = h.y;
             tr.ord = (uint16_t)j; tr.flags = (uint8_t)h.w; tr.reserved = 0;

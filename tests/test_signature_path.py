@@ -83,10 +83,12 @@ def test_general_lsh_threshold_goes_to_the_full_width_kernel(small_index, monkey
     seq, off = mixed_batch(small_index, n=3000, seed=5)
     a = run(small_index, seq, off, monkeypatch, no_sig=False, threshold=0.9)
     b = run(small_index, seq, off, monkeypatch, no_sig=True, threshold=0.9)
-    assert a["counts"]["full_sketch_reads"] == len(off) - 1          # fewer than all slots must agree: not the signature kernel's case
+    # fewer than all slots must agree: not the signature kernel's case.  What the memo of open knows (error-free window-sized reads)
+    # is answered by the text lookup at any threshold; everything else takes the full-width kernel
+    assert b["counts"]["full_sketch_reads"] == len(off) - 1 and 0 < a["counts"]["full_sketch_reads"] < len(off) - 1
     assert np.array_equal(a["seeds"], b["seeds"]) and np.array_equal(a["att"], b["att"])
     assert len(a["alns"]) == len(b["alns"]) and all(np.array_equal(a["alns"][f], b["alns"][f]) for f in a["alns"].dtype.names)
-    assert {k: v for k, v in a["counts"].items()} == {k: v for k, v in b["counts"].items()}
+    assert {k: v for k, v in a["counts"].items() if k != "full_sketch_reads"} == {k: v for k, v in b["counts"].items() if k != "full_sketch_reads"}
 
 
 def test_reads_with_n_next_to_clean_reads(small_index, monkeypatch):
