@@ -7,11 +7,11 @@ HOST_SRC := $(addprefix groot_amd/csrc/host/,index.cpp gob.cpp graphs.cpp fastq.
 
 all: $(B)/libgroot_host.so $(B)/libgroot_hip.so $(B)/groot-hip
 
-$(B)/libgroot_host.so: $(HOST_SRC) groot_amd/csrc/host/host_common.hpp groot_amd/csrc/common/view_check.hpp $(wildcard include/*.h)
+$(B)/libgroot_host.so: $(HOST_SRC) groot_amd/csrc/host/host_common.hpp $(wildcard groot_amd/csrc/common/*.hpp) $(wildcard include/*.h)
 	@mkdir -p $(B)
 	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -shared -o $@ $(HOST_SRC) -lpthread -lz
 
-$(B)/libgroot_hip.so: $(wildcard groot_amd/csrc/hip/*) groot_amd/csrc/common/view_check.hpp $(wildcard include/*.h)
+$(B)/libgroot_hip.so: $(wildcard groot_amd/csrc/hip/*) $(wildcard groot_amd/csrc/common/*.hpp) $(wildcard include/*.h)
 	@mkdir -p $(B)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Iinclude -Igroot_amd/csrc/hip -o $@ groot_amd/csrc/hip/groot_hip.hip
 

@@ -97,8 +97,10 @@ func (idx *Index) NodeSegID() []uint32 { return u32s(idx.view.node_seg_id, idx.N
 
 // Ctx is one GPU context (groot_ctx): the replicated index in HBM plus a ring of batches in flight
 type Ctx struct {
-	h   *C.groot_ctx
-	idx *Index
+	h      *C.groot_ctx
+	idx    *Index
+	device int
+	params Params
 }
 
 // Params mirrors the fields of groot_params a host sets
@@ -136,11 +138,46 @@ func Open(device int, idx *Index, p Params) (*Ctx, error) {
 	if p.PipelineDepth != 0 {
 		prm.pipeline_depth = C.uint32_t(p.PipelineDepth)
 	}
-	c := &Ctx{idx: idx}
+	c := &Ctx{idx: idx, device: device, params: p}
+	if c.params.MaxReadLen == 0 {
+		c.params.MaxReadLen = uint32(prm.max_read_len)
+	}
 	if rc := C.groot_hip_open(&c.h, C.int(device), &idx.view, &prm); rc != 0 {
 		return nil, fmt.Errorf("groot_hip_open: %s", C.GoString(C.groot_hip_last_error(nil)))
 	}
 	return c, nil
+}
+
+// MaxReadLen is the longest read the ctx accepts (a longer one fails its batch with GROOT_E_NOSPACE)
+func (c *Ctx) MaxReadLen() int { return int(c.params.MaxReadLen) }
+
+// Reopen replaces the ctx by one that accepts reads of up to maxReadLen bases and carries the IncrementSubPath call counts
+// over (groot_hip_attempts_export -> close -> open -> groot_hip_attempts_import): the reference has no read length limit
+// (boss.go:145-203), the device sizes its LDS staging and DFS stacks for one.  Nothing may be in flight.
+func (c *Ctx) Reopen(maxReadLen int) error {
+	var nRows, nWin C.uint32_t
+	if rc := C.groot_hip_attempts_export(c.h, nil, nil, 0, &nRows, &nWin); rc != 0 {
+		return c.err("groot_hip_attempts_export")
+	}
+	q := make([]uint32, int(nRows)+1)
+	counts := make([]uint32, int(nRows)*int(nWin)+1)
+	if rc := C.groot_hip_attempts_export(c.h, (*C.uint32_t)(unsafe.Pointer(&q[0])), (*C.uint32_t)(unsafe.Pointer(&counts[0])), nRows, &nRows, &nWin); rc != 0 {
+		return c.err("groot_hip_attempts_export")
+	}
+	p := c.params
+	p.MaxReadLen = uint32(maxReadLen)
+	bigger, err := Open(c.device, c.idx, p)
+	if err != nil {
+		return err
+	}
+	if rc := C.groot_hip_attempts_import(bigger.h, (*C.uint32_t)(unsafe.Pointer(&q[0])), (*C.uint32_t)(unsafe.Pointer(&counts[0])), nRows); rc != 0 {
+		err := bigger.err("groot_hip_attempts_import")
+		bigger.Close()
+		return err
+	}
+	C.groot_hip_close(c.h)
+	c.h, c.params = bigger.h, bigger.params
+	return nil
 }
 
 // Close releases the GPU context
@@ -163,6 +200,7 @@ type Batch struct {
 	ExcPos  []uint64
 	ExcByte []byte
 	nBases  uint64
+	maxLen  int
 }
 
 // Add appends read.Seq to the batch (FASTQread.Seq as it came: no upper-casing, sketch.go:258-282 removed the QC)
@@ -182,15 +220,21 @@ func (b *Batch) Add(seq []byte) error {
 		b.nBases++
 	}
 	b.Lens = append(b.Lens, uint16(len(seq)))
+	if len(seq) > b.maxLen {
+		b.maxLen = len(seq)
+	}
 	return nil
 }
+
+// MaxLen is the length of the longest read in the batch
+func (b *Batch) MaxLen() int { return b.maxLen }
 
 // Len is the number of reads in the batch
 func (b *Batch) Len() int { return len(b.Lens) }
 
 // Reset empties the batch, keeping its capacity
 func (b *Batch) Reset() {
-	b.Packed, b.Lens, b.ExcPos, b.ExcByte, b.nBases = b.Packed[:0], b.Lens[:0], b.ExcPos[:0], b.ExcByte[:0], 0
+	b.Packed, b.Lens, b.ExcPos, b.ExcByte, b.nBases, b.maxLen = b.Packed[:0], b.Lens[:0], b.ExcPos[:0], b.ExcByte[:0], 0, 0
 }
 
 // Submit enqueues the batch (copy to pinned staging -> H2D -> kernels -> D2H, asynchronous).  ErrFull means

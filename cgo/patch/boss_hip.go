@@ -66,7 +66,7 @@ func (theBoss *theBoss) mapReadsHIP() error {
 	ctxs := make([]*groothip.Ctx, nGPU)
 	for d := range ctxs {
 		c, err := groothip.Open(d, idx, groothip.Params{ContainmentThreshold: theBoss.info.ContainmentThreshold,
-			NoExactAlign: theBoss.info.Sketch.NoExactAlign, MaxReadLen: 512, MaxBatchReads: uint32(batchReads()), PipelineDepth: depth})
+			NoExactAlign: theBoss.info.Sketch.NoExactAlign, MaxReadLen: 256, MaxBatchReads: uint32(batchReads()), PipelineDepth: depth})
 		if err != nil {
 			return err
 		}
@@ -99,6 +99,28 @@ func (theBoss *theBoss) mapReadsHIP() error {
 		return nil
 	}
 	submit := func(d int, b *hipBatch) error {
+		// The reference accepts reads of any length (boss.go:145-203); a ctx is sized for one.  A batch holding a longer read makes
+		// EVERY ctx grow -- drain what is in flight, reopen with room to spare, call counts carried over -- so that all ctxs keep
+		// the same kmerCount range and groot_hip_attempts_allreduce can sum their tables at the end (groot_hip_main.cpp does the same).
+		if b.wire.MaxLen() > ctxs[d].MaxReadLen() {
+			want := 2 * ctxs[d].MaxReadLen()
+			for want < b.wire.MaxLen() {
+				want *= 2
+			}
+			if want > 65535 {
+				want = 65535
+			}
+			for e := range ctxs {
+				for len(pending[e]) > 0 {
+					if err := collect(e); err != nil {
+						return err
+					}
+				}
+				if err := ctxs[e].Reopen(want); err != nil {
+					return err
+				}
+			}
+		}
 		for len(pending[d]) >= depth {
 			if err := collect(d); err != nil {
 				return err

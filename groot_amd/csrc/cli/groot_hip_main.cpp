@@ -619,6 +619,24 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         logf("\ttotal number of exact alignments: %llu", (unsigned long long)alignments);
         // graph weights: exact call counts from the devices (summed over the GPUs: one RCCL all-reduce of a table with one row
         // per kmerCount that occurred), one replay of IncrementSubPath on the host
+        // (a context that met a longer read was reopened with a larger limit, the others were not: the tables can only be summed
+        // over contexts with the same kmerCount range, so the shorter ones follow now -- export, reopen, import, as grow_ctx does)
+        uint32_t longest = 0;
+        for (auto &g : gpus) longest = std::max(longest, g->max_read_len);
+        for (auto &g : gpus) {
+            if (g->max_read_len == longest) continue;
+            uint32_t n_rows = 0, nw = 0;
+            if (groot_hip_attempts_export(g->ctx, nullptr, nullptr, 0, &n_rows, &nw)) die("%s", groot_hip_last_error(g->ctx));
+            std::vector<uint32_t> qv(n_rows), cnt((size_t)n_rows * nw);
+            if (n_rows && groot_hip_attempts_export(g->ctx, qv.data(), cnt.data(), n_rows, &n_rows, &nw)) die("%s", groot_hip_last_error(g->ctx));
+            groot_hip_close(g->ctx);
+            g->ctx = nullptr;
+            g->max_read_len = longest;
+            groot_params prm = params_for(longest);
+            logf("\tGPU %d: reopening its context for reads up to %u bases (another context met one) before the call counts are summed", g->device, longest);
+            if (groot_hip_open(&g->ctx, g->device, &v, &prm)) die("%s", groot_hip_last_error(nullptr));
+            if (n_rows && groot_hip_attempts_import(g->ctx, qv.data(), cnt.data(), n_rows)) die("%s", groot_hip_last_error(g->ctx));
+        }
         std::vector<groot_ctx *> ctxs;
         for (auto &g : gpus) ctxs.push_back(g->ctx);
         if (groot_hip_attempts_allreduce(ctxs.data(), (int)ctxs.size())) die("%s", groot_hip_last_error(ctxs[0]));

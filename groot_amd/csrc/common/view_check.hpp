@@ -3,6 +3,7 @@
 // must come back as GROOT_E_FORMAT, not as out-of-bounds reads on the host or the GPU.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -31,6 +32,21 @@ inline std::string check_index_view(const groot_index_view *v)
         return std::string();
     };
     std::string e;
+    // payload arrays that hold something must be there
+    {
+        const struct { const void *p; uint64_t n; const char *name; } need[] = {
+            {v->bases, v->n_bases, "bases"}, {v->edges, v->n_edges, "edges"}, {v->np_path, v->n_np, "np_path"}, {v->np_pos, v->n_np, "np_pos"},
+            {v->node_mask, (uint64_t)v->n_nodes * v->path_words, "node_mask"}, {v->node_seg_id, v->n_nodes, "node_seg_id"},
+            {v->path_len, v->n_paths, "path_len"}, {v->path_names, v->n_name_bytes, "path_names"},
+            {v->win_graph, v->n_windows, "win_graph"}, {v->win_node, v->n_windows, "win_node"}, {v->win_offset, v->n_windows, "win_offset"},
+            {v->win_merge_span, v->n_windows, "win_merge_span"}, {v->win_sketch, (uint64_t)v->n_windows * v->sketch_size, "win_sketch"},
+            {v->cn_node, v->n_cn, "cn_node"}, {v->win_ref, v->n_wref, "win_ref"}};
+        for (const auto &x : need)
+            if (x.n && !x.p) return bad((std::string(x.name) + " is null although its count is %llu").c_str(), x.n);
+    }
+    if (v->n_windows && (v->window_size == 0 || v->window_size < v->kmer_size)) return bad("window size %llu below the k-mer size %llu", v->window_size, v->kmer_size);
+    if (v->n_windows && v->num_window_kmers != v->window_size - v->kmer_size + 1)
+        return bad("num_window_kmers=%llu does not belong to window size %llu", v->num_window_kmers, v->window_size);
     if (v->n_graphs) {
         if (!(e = offsets(v->graph_node_off, v->n_graphs, v->n_nodes, "graph_node_off")).empty()) return e;
         if (!(e = offsets(v->graph_path_off, v->n_graphs, v->n_paths, "graph_path_off")).empty()) return e;

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "../common/cpus.hpp"
 #include "../common/view_check.hpp"
 #include "kernels.hpp"
 
@@ -416,7 +417,7 @@ template <int PW> void build_node_records(const groot_index_view *v, std::vector
             for (uint32_t e = 0; e < deg; e++) {
                 const uint32_t c = v->edges[e0 + e];
                 r.edges[e] = c;
-                r.child_first[e] = v->bases[v->node_seq_off[c]];
+                r.child_first[e] = v->node_seq_off[c] < v->node_seq_off[c + 1] ? v->bases[v->node_seq_off[c]] : (uint8_t)0;   // (an empty node spells nothing)
             }
         } else {
             r.edges[0] = e0;
@@ -1023,7 +1024,7 @@ static void expand_travs(const groot_ctx *c, Slot *s)
             out[i] = t;
         }
     };
-    const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / (1u << 18));   // (memory bound: 2-3 ms per 10 M records)
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, granted_cpus()), n / (1u << 18));   // (memory bound: 2-3 ms per 10 M records)
     if (nt <= 1) { span(0, n); return; }
     std::vector<std::thread> th;
     const size_t per = (n + nt - 1) / nt;
@@ -1650,7 +1651,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     //    consecutive windows of equal sketch into the first one (:293-333).  Texts stop at a base other than ACGT.
     std::vector<uint8_t> text((size_t)n * 2 * kTextMax + 64, 0);
     std::vector<uint32_t> tlen(n, 0);
-    const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned nt = std::min(32u, granted_cpus());
     {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
@@ -1849,7 +1850,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     }
     {
         std::vector<uint32_t> k5((size_t)v->n_windows * kPrefixWords, 0);
-        const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        const unsigned nt = std::min(32u, granted_cpus());
         PrefixTables pt;
         pt.v = v;
         pt.positions(nt);
@@ -2005,7 +2006,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         {
             std::atomic<uint32_t> next{0};
             std::vector<std::thread> th;
-            const uint32_t workers = std::min<uint32_t>(lmax, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+            const uint32_t workers = std::min<uint32_t>(lmax, std::min(16u, granted_cpus()));
             for (uint32_t t = 0; t < workers; t++)
                 th.emplace_back([&]() { for (uint32_t b; (b = next.fetch_add(1)) < lmax;) band(b); });
             for (auto &x : th) x.join();
@@ -2511,9 +2512,18 @@ int groot_hip_attempts_layout(groot_ctx *c, const uint32_t *q_values, uint32_t n
     DevBuf<uint32_t> own;
     uint32_t *dst = (uint32_t *)d_table;
     if (!dst) { HIP_TRY(c, own.alloc((size_t)cap * c->n_windows)); dst = own.p; }
+    // (a caller re-laying out the buffer the table already lives in: its rows are staged first, or the memset below would wipe
+    // them and the row moves could overlap)
+    DevBuf<uint32_t> stage;
+    const uint32_t *src = c->attempts_ptr;
+    if (dst == c->attempts_ptr && !qs.empty()) {
+        HIP_TRY(c, stage.alloc(qs.size() * (size_t)c->n_windows));
+        HIP_TRY(c, hipMemcpy(stage.p, c->attempts_ptr, qs.size() * (size_t)c->n_windows * 4, hipMemcpyDeviceToDevice));
+        src = stage.p;
+    }
     if (n_q) HIP_TRY(c, hipMemset(dst, 0, (size_t)n_q * c->n_windows * 4));
     for (size_t r = 0; r < qs.size(); r++)
-        HIP_TRY(c, hipMemcpy(dst + (size_t)new_row[r] * c->n_windows, c->attempts_ptr + r * c->n_windows, (size_t)c->n_windows * 4, hipMemcpyDeviceToDevice));
+        HIP_TRY(c, hipMemcpy(dst + (size_t)new_row[r] * c->n_windows, src + r * c->n_windows, (size_t)c->n_windows * 4, hipMemcpyDeviceToDevice));
     std::vector<uint32_t> rowmap(c->max_q + 2, kEmpty);
     for (uint32_t i = 0; i < n_q; i++) rowmap[q_values[i]] = i;
     HIP_TRY(c, hipMemcpy(c->q_row.p, rowmap.data(), rowmap.size() * 4, hipMemcpyHostToDevice));
@@ -2637,7 +2647,10 @@ int groot_hip_attempts_allreduce(groot_ctx *const *ctxs, int n_ctx)
         if (ctxs[i]->n_windows != c0->n_windows || ctxs[i]->max_q != c0->max_q) return fail(c0, GROOT_E_INVALID, "ctxs were opened on different indexes / read length limits");
         if (ctxs[i]->att_external) return fail(c0, GROOT_E_STATE, "ctx %d keeps its table in a caller-owned buffer", i);
     }
-    if (n_ctx == 1) return drain(c0);
+    // GROOT_FORCE_RCCL=1: take the RCCL branch even when all ctxs share one device (a communicator over a single device is legal):
+    // the one way to run dlopen, the symbol lookups, the enum values and the grouped in-place ncclAllReduce on a one-GPU box
+    const bool force_rccl = getenv("GROOT_FORCE_RCCL") != nullptr;
+    if (n_ctx == 1 && !force_rccl) return drain(c0);
     // union row layout (ascending kmerCount) on every ctx
     std::vector<uint32_t> all;
     for (int i = 0; i < n_ctx; i++) {
@@ -2665,7 +2678,7 @@ int groot_hip_attempts_allreduce(groot_ctx *const *ctxs, int n_ctx)
         HIP_TRY(c0, hipGetLastError());
         HIP_TRY(c0, hipStreamSynchronize(ctxs[l]->stream));
     }
-    if (lead.size() > 1) {
+    if (lead.size() > 1 || force_rccl) {
         // one RCCL communicator over the distinct devices, one in-place ncclAllReduce(sum, uint32) per device: ring over xGMI
         if (!g_rccl.load()) return fail(c0, GROOT_E_DEVICE, "librccl.so could not be loaded: %s", dlerror());
         std::vector<int> devs;

@@ -774,7 +774,9 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         seed_epilogue(a, r, o0, len, q, 0, kEmpty, kEmpty, kEmpty, kEmpty, kEmpty, false);
         return;
     }
-    bool fast = in_lds && len >= k && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
+    // (len >= WindowSize: only then does the read cover whole WindowSize-mers of a text, whose sketches are proven; a shorter
+    // read is a substring with FEWER k-mers -- its minima may differ below the 27 signature bits -- and takes the full-width kernel)
+    bool fast = in_lds && len >= k && len >= ix.w && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
     if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch
     if (fast) {
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;

@@ -106,6 +106,9 @@ int64_t groot_fastq_next_batch(groot_fastq *fq, uint32_t max_reads, uint8_t *seq
                 int rc = read_line(fq, fq->line[fq->have]);
                 if (rc < 0) return rc;
                 if (rc == 0) break;
+                // an empty line reaches FastqHandler.Run as nil (append([]byte(nil), ...) of no bytes): it cannot fill l1, l2 or l3
+                // (sketch.go:217-222) -- only the fourth line is taken as it comes
+                if (fq->have < 3 && fq->line[fq->have].empty()) continue;
                 fq->have++;
             }
             if (fq->have < 4) break;   // a trailing partial record is dropped, as in FastqHandler.Run

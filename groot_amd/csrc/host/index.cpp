@@ -11,6 +11,7 @@
 // Go-map-order dependent, so segment ids produced here are deterministic
 // but not those of a Go-built index -- parity is defined on id-free coordinates.
 #include "host_common.hpp"
+#include "../common/cpus.hpp"
 #include "../common/view_check.hpp"
 
 #include <algorithm>
@@ -605,33 +606,7 @@ template <class T> static bool get_vec(std::ifstream &i, std::vector<T> &v)
 }
 
 namespace groot {
-unsigned usable_cpus()
-{
-    static const unsigned cached = []() -> unsigned {
-        unsigned n = std::max(1u, std::thread::hardware_concurrency());
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
-        // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us
-        double quota = 0;
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[64];
-            long long period = 0;
-            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
-            fclose(f);
-        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-            long long qv = -1, period = 0;
-            if (fscanf(g, "%lld", &qv) != 1) qv = -1;
-            fclose(g);
-            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
-            if (qv > 0 && period > 0) quota = (double)qv / (double)period;
-        }
-        if (quota >= 1.0) n = std::min<unsigned>(n, (unsigned)(quota + 0.5));
-        if (const char *e = getenv("GROOT_THREADS")) { const int v = atoi(e); if (v > 0) n = (unsigned)v; }
-        return std::max(1u, n);
-    }();
-    return cached;
-}
+unsigned usable_cpus() { return granted_cpus(); }
 } // namespace groot
 
 extern "C" {

@@ -243,16 +243,44 @@ static int parse_block(groot_reads *r, std::unique_ptr<RawBlock> blk, bool last_
     std::vector<uint32_t> nl(n_lines);
     parallel_for(T, n_ranges, [&](size_t i) { if (!nl_part[i].empty()) memcpy(nl.data() + part_off[i], nl_part[i].data(), nl_part[i].size() * 4); });
     nl_part.clear();
-    const size_t n_rec = n_lines / 4;
-    const size_t cut = n_rec ? (size_t)nl[4 * n_rec - 1] + 1 : 0;
-    if (!last_block) r->carry.assign(text + cut, text + n);       // lines of the next record (and a partial line): carried over
-    // (at the end of all input a trailing partial record is dropped, as in FastqHandler.Run)
-    if (!n_rec) return GROOT_OK;
-    auto line = [&](size_t li, uint32_t &pos, uint32_t &len) {
+    auto raw_line = [&](size_t li, uint32_t &pos, uint32_t &len) {
         pos = li ? nl[li - 1] + 1 : 0;
         len = nl[li] - pos;
         if (len && text[pos + len - 1] == '\r') len--;            // bufio.ScanLines drops one trailing '\r'
     };
+    // FastqHandler.Run (sketch.go:216-236) fills l1, l2, l3 with the next line that is not nil -- and an EMPTY line arrives as nil
+    // (append([]byte(nil), scanner.Bytes()...) of no bytes) -- then takes whatever comes next as l4.  Blank lines before an ID,
+    // a sequence or a '+' line are therefore skipped (a file ending in an extra newline followed by a second file maps fine);
+    // only files that hold one pay for the regrouping.
+    std::vector<uint8_t> any_blank(n_ranges, 0);
+    parallel_for(T, n_ranges, [&](size_t i) {
+        for (size_t li = part_off[i]; li < part_off[i + 1]; li++) {
+            uint32_t p, l;
+            raw_line(li, p, l);
+            if (!l) { any_blank[i] = 1; return; }
+        }
+    });
+    std::vector<uint32_t> rec_line;                                // [4 * n_rec] line of every record field; empty = lines 4i .. 4i+3
+    size_t n_rec = n_lines / 4;
+    if (std::find(any_blank.begin(), any_blank.end(), 1) != any_blank.end()) {
+        uint32_t field = 0, cur[4];
+        for (size_t li = 0; li < n_lines; li++) {
+            uint32_t p, l;
+            raw_line(li, p, l);
+            if (field < 3 && !l) continue;
+            cur[field++] = (uint32_t)li;
+            if (field == 4) { rec_line.insert(rec_line.end(), cur, cur + 4); field = 0; }
+        }
+        n_rec = rec_line.size() / 4;
+        if (rec_line.empty()) rec_line.push_back(0);               // (non-empty = "regrouped")
+    }
+    const bool regrouped = !rec_line.empty();
+    const size_t last_line = n_rec ? (regrouped ? (size_t)rec_line[4 * n_rec - 1] : 4 * n_rec - 1) : 0;
+    const size_t cut = n_rec ? (size_t)nl[last_line] + 1 : 0;
+    if (!last_block) r->carry.assign(text + cut, text + n);       // lines of the next record (and a partial line): carried over
+    // (at the end of all input a trailing partial record is dropped, as in FastqHandler.Run)
+    if (!n_rec) return GROOT_OK;
+    auto line = [&](size_t fi, uint32_t &pos, uint32_t &len) { raw_line(regrouped ? (size_t)rec_line[fi] : fi, pos, len); };
     // ---- pass A: validate, sizes (parallel over record ranges) ----
     const size_t n_tasks = std::max<size_t>(1, std::min<size_t>(T * 4, n_rec / 4096 + 1));
     std::vector<uint64_t> task_bases(n_tasks, 0);

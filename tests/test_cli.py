@@ -205,6 +205,15 @@ def test_reads_longer_than_the_context_was_opened_for(cli, argannot_index, tmp_p
         res.append((read_bam(bam)[2], _gfas(str(tmp_path / f"g_{tag}")), open(log).read()))
     assert "reopening the GPU context" in res[0][2] and "reopening the GPU context" not in res[1][2]
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and len(res[0][0]) > 400
+    # several contexts, only ONE of which meets the long read: the others follow before the call counts are summed,
+    # instead of the run dying after the BAM is written
+    bam, log = str(tmp_path / "multi.bam"), str(tmp_path / "multi.log")
+    r = run([cli, "align", "-i", str(idx_dir), "-f", str(fq), "--log", log, "-g", str(tmp_path / "g_multi"), "--bam", bam, "--batch", "128",
+             "--maxReadLen", "160", "-p", "2", "--ctxPerGpu", "3", "--depth", "2"])
+    assert r.returncode == 0, r.stderr
+    text = open(log).read()
+    assert "reopening the GPU context" in text and "before the call counts are summed" in text
+    assert read_bam(bam)[2] == res[1][0] and _gfas(str(tmp_path / "g_multi")) == res[1][1]
 
 
 @pytest.mark.gpu

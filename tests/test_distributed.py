@@ -88,3 +88,39 @@ def test_two_ranks_equal_one(msa_dir, tmp_path):
     # alignment records of the shards, concatenated in rank order, are the single-process records
     al = np.concatenate([np.load(os.path.join(tmp_path, f"alns{r}.npy")) for r in range(2)])
     assert np.array_equal(al, run.alns())
+
+
+# ---- the RCCL branch of groot_hip_attempts_allreduce, executed on ONE GPU --------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ctx", [1, 2])
+def test_rccl_branch_on_one_gpu(small_index, monkeypatch, hip_lib, n_ctx):
+    """GROOT_FORCE_RCCL=1 builds the communicator even though every ctx sits on the same device (ncclCommInitAll over one device),
+    so dlopen("librccl"), the six symbols, the hand-copied enum values (ncclUint32 = 3, ncclSum = 0) and the grouped in-place
+    ncclAllReduce really run.  One ctx: the table comes back unchanged.  Two ctxs with different shards: the kernel folds the
+    second into the first, RCCL all-reduces that single rank, both ctxs end up with the sum = the single-ctx table of all reads."""
+    from groot_amd import device, synth
+
+    index = small_index
+    cat, off, lens = synth.reference_sequences(index)
+    n = 4000
+    seq, so, _ = synth.reads_np(cat, off, lens, n, 100)
+    monkeypatch.delenv("GROOT_FORCE_RCCL", raising=False)
+    ref = device.Aligner(index, max_batch_reads=n, max_read_len=128)
+    ref.submit(seq, so)
+    ref.wait()
+    want_q, want = ref.attempts_rows()
+    ref.close()
+    assert want.sum() > 0
+    monkeypatch.setenv("GROOT_FORCE_RCCL", "1")
+    als = [device.Aligner(index, max_batch_reads=n, max_read_len=128) for _ in range(n_ctx)]
+    per = n // n_ctx
+    for i, al in enumerate(als):
+        lo, hi = i * per, (n if i == n_ctx - 1 else (i + 1) * per)
+        al.submit(seq[int(so[lo]):int(so[hi])], so[lo:hi + 1] - so[lo], first_read_id=lo)
+        al.wait()
+    device.attempts_allreduce(als)
+    for al in als:
+        q, got = al.attempts_rows()
+        assert np.array_equal(q, want_q) and np.array_equal(got, want)
+    for al in als:
+        al.close()

@@ -1,6 +1,8 @@
 """The pipelined boundary (submit / collect-the-oldest, several batches in flight in ONE ctx) and the compact
 call-count table, against the one-batch-at-a-time path and the CPU oracle.  The reference seam is the continuous
 stream of boss.go:145-203; what must hold is that batching, pipelining and the wire format change nothing."""
+import os
+
 import numpy as np
 import pytest
 
@@ -175,6 +177,13 @@ def test_allreduce_over_ctxs_and_fixed_layout(small_index):
     run_a = O.Run(small_index)
     run_a.batch(a_seq, a_off)
     assert np.array_equal(table.cpu().numpy().astype(np.uint32), run_a.attempts()[70])
+    # re-laying out the SAME caller-owned buffer (a wider layout, rows move): the counts survive
+    wide = torch.zeros(3 * nw, dtype=torch.int32, device="cuda")
+    al.attempts_layout([70], wide.data_ptr())
+    assert np.array_equal(wide[:nw].cpu().numpy().astype(np.uint32), run_a.attempts()[70])
+    al.attempts_layout([60, 65, 70], wide.data_ptr())
+    got = wide.cpu().numpy().astype(np.uint32).reshape(3, nw)
+    assert np.array_equal(got[2], run_a.attempts()[70]) and not got[:2].any()
     al.submit(b_seq, b_off)                     # kmerCounts outside the fixed layout: refused, not dropped silently
     with pytest.raises(host.GrootError) as e:
         al.wait()
@@ -255,4 +264,71 @@ def test_grow_and_redo_paths_inside_the_pipeline(small_index, monkeypatch):
     assert all(sum(r["counts"][k] for r in got) == oc[k] for k in ("received", "mapped", "multimapped", "alignments", "seeds"))
     att, oatt = al.attempts(), run.attempts()
     assert np.array_equal(att[: oatt.shape[0]], oatt) and not att[oatt.shape[0]:].any()
+    al.close()
+
+
+def test_cgo_call_sequence(small_index, tmp_path):
+    """cgo/ctest.c makes the calls package groothip makes (cgo/groothip/groothip.go: LoadGob -> Open -> packed16 Submit with three
+    batches in flight, caller buffers scribbled over after every submit -> Collect / unpack / Release -> Reopen for a longer
+    read -> Weights) on a Go-format index directory; its counters, records and weights equal the Python binding's.
+    The seam is theBoss.mapReads, src/pipeline/boss.go:108-242."""
+    import json
+    import subprocess
+
+    from conftest import REPO
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "cgo")])
+    index = small_index
+    gob_dir = str(tmp_path / "idx")
+    os.makedirs(gob_dir)
+    index.save_gob(gob_dir)
+    index2 = host.Index.load_gob(gob_dir)                     # (node ids as the gob files give them)
+    cat, o, lens = synth.reference_sequences(index2)
+    seq, off, _ = synth.reads_np(cat, o, lens, 5000, 100)
+    reads = [bytes(seq[int(off[i]):int(off[i + 1])]) for i in range(5000)]
+    reads[1234] = reads[1234][:50] + b"N" + reads[1234][51:]
+    # one read longer than the ctxs are opened for (128): the harness reopens them, call counts carried over
+    longest = max(range(len(lens)), key=lambda i: int(lens[i]))
+    reads[4100] = bytes(cat[int(o[longest]):int(o[longest]) + min(300, int(lens[longest]))])
+    path = str(tmp_path / "reads.txt")
+    with open(path, "wb") as f:
+        f.write(b"\n".join(reads) + b"\n")
+    batch = 1000
+    out = subprocess.run([os.path.join(REPO, "build", "cgo_ctest"), gob_dir, path, str(batch)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr[-800:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["batches"] == 5 and got["reopened"] == 1
+
+    def mix(h, v):
+        h = ((h ^ v) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        return h ^ (h >> 29)
+
+    al = device.Aligner(index2, max_batch_reads=batch, max_read_len=512)
+    tot = dict(received=0, mapped=0, multimapped=0, alignments=0, travs=0, records=0)
+    rh = 0
+    for b0 in range(0, 5000, batch):
+        s2, o2 = O.pack_reads(reads[b0:b0 + batch])
+        al.submit(s2, o2, first_read_id=0)
+        c = al.wait()
+        for k in ("received", "mapped", "multimapped", "alignments"):
+            tot[k] += c[k]
+        t, m = al.travs()
+        tot["travs"] += len(t)
+        for i in range(len(t)):
+            for w in range(m.shape[1]):
+                word = int(m[i, w])
+                while word:
+                    pid = 64 * w + (word & -word).bit_length() - 1
+                    word &= word - 1
+                    for v in (int(t["read_id"][i]), int(t["graph_id"][i]), pid, int(t["node"][i]), (int(t["offset"][i]) << 8) | int(t["flags"][i])):
+                        rh = mix(rh, v)
+                    tot["records"] += 1
+    for k, v in tot.items():
+        assert got[k] == v, k
+    assert got["record_hash"] == "%016x" % rh
+    q, counts = al.attempts_rows()
+    kf, kt = device.weights_rows(index2, q, counts)
+    wh = 0
+    for bits in kf.view(np.uint64):
+        wh = mix(wh, int(bits))
+    assert got["weights_hash"] == "%016x" % wh and got["kmer_total"] == int(kt.sum()) and got["rows"] == len(q)
     al.close()

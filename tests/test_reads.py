@@ -84,6 +84,20 @@ def test_edge_cases(native_libs, tmp_path):
         assert bytes(asc) == b"".join(es)
         exc = sum(len(x["exc_pos"]) for x in batches)
         assert exc == 6                                                                  # N N a c g t
+    # blank lines: FastqHandler.Run skips them before an ID, a sequence or a '+' line (an empty line is a nil slice there,
+    # sketch.go:217-222) and takes the fourth line as it comes -- a file ending in an extra newline followed by a second file,
+    # blank lines between records, an empty quality line
+    d = tmp_path / "d.fq"
+    e2 = tmp_path / "e.fq"
+    d.write_bytes(b"@b1\nACGTACGT\n+\nIIIIIIII\n\n\n@b2\n\nGGGG\n\r\n+\nIIII\n\n")
+    e2.write_bytes(b"@b3\nTTTTT\n+\n\n@b4\nCC\n+\nII\n")
+    en, es, eq = serial([str(d), str(e2)])
+    assert en == [b"b1", b"b2", b"b3", b"b4"] and es == [b"ACGTACGT", b"GGGG", b"TTTTT", b"CC"]
+    for block in (0, 9, 16, 37):
+        gn, gs, gq, _ = parallel([str(d), str(e2)], threads=2, block_bytes=block)
+        assert (gn, gs) == (en, es), block
+        # (a quality line shorter than its sequence: the line scanner pads with '!', the parallel reader reports the short line)
+        assert [q[: len(s)].ljust(len(s), b"!") for q, s in zip(gq, gs)] == [q[: len(s)].ljust(len(s), b"!") for q, s in zip(eq, es)]
     # an ID line that does not start with '@' is an error (seqio.go:179-181)
     bad = tmp_path / "bad.fq"
     bad.write_bytes(b"@ok\nACGT\n+\nIIII\nr2\nACGT\n+\nIIII\n")
