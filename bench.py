@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- Mreads/s aligned on MI355X for BASELINE.json's workload (configs[2]).
 
-A step = one pass of the whole `groot align` hot path (sketch -> LSH-Ensemble seed -> graph DFS alignment -> canonical
-ordering of the traversal records) over one batch of synthetic 100 bp reads that is already resident in HBM; the records
-stay in HBM (`value`).  Reads shard across GPUs (one process per GPU, index replicated); the only exchange is one RCCL
-all-reduce of the IncrementSubPath call counts after the last step (inside the timed region).
+A step = one pass of the whole `groot align` hot path (seed stage -> align stage -> canonical ordering of the traversal
+records) over one batch of synthetic 100 bp reads that is already resident in HBM; the records stay in HBM (`value`, as the
+bench contract asks: inputs resident when the timed region starts).  Reads shard across GPUs (one process per GPU, index
+replicated); the only exchange is one RCCL all-reduce of the IncrementSubPath call counts after the last step (inside the
+timed region).
 
 Beside `value` the same JSON line carries, at N=1:
-  host_fed      pinned host buffers -> groot_hip_submit_acquired (2-bit bases + u16 lengths over PCIe) -> kernels ->
-                traversal records back in pinned host memory (groot_hip_collect), several batches in flight in ONE ctx:
-                SURVEY 8d's "first submit -> last collect" rate, PCIe in both directions included
+  robustness    the same ctx on reads the memo of groot_hip_open cannot answer: 1 % substitutions per base; 99 % random reads
+  thresholds    configs[4]'s containment-threshold sweep on the 100 bp reads (t = 0.97, 0.95, 0.90)
+  mixed         configs[4] at single-GPU scale: resfinder.90, 2 M reads of 75..150 bases, both strands, t = 0.99 .. 0.90,
+                and one gzip-streamed run of build/groot-hip align
+  host_fed      pinned host buffers -> groot_hip_submit_acquired (2-bit bases over PCIe) -> kernels -> traversal records
+                back in pinned host memory (groot_hip_collect), several batches in flight in ONE ctx: SURVEY 8d's
+                "first submit -> last collect" rate, PCIe in both directions included; runs for >= 5 s
   cli_e2e       build/groot-hip align: FASTQ file -> BAM file + GFAs, the whole process
-  cpu_baseline  the oracle (CPU restatement of the reference path) as one process per hardware thread
+  cpu_baseline  the oracle (CPU restatement of the reference path) as one process per granted CPU
 
   python bench.py --gpus 1 --steps 200 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -33,7 +38,7 @@ sys.path.insert(0, REPO)
 
 READ_LEN = 100
 HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
-PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc.json")
 
 
 def usable_cpus():
@@ -116,6 +121,170 @@ def cpu_baseline(index_path, seconds):
             "single_core": {"value": one, "sample": f"{one_n} reads, one process, {one_wall:.1f} s"},
             "scaling_efficiency": allv / (one * cores),
             "note": "oracle/groot_oracle.c = CPU restatement of the reference path; the Go binary itself cannot be built in this image"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def resident_rate(al, d_seq_ptr, d_off_ptr, R, max_len, steps, warmup, mixed=False):
+    """`steps` batches of R reads that sit in HBM through ctx `al`, two in flight (the ctx is a pipeline: the next batch is
+    enqueued while the GPU works on this one); returns (Mreads/s, mean stage ms, counts of the last batch)"""
+    import torch
+
+    for _ in range(warmup):
+        al.submit_device(d_seq_ptr, d_off_ptr, R, first_read_id=0, max_len=max_len, mixed=mixed)
+        al.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage, pending, counts = {}, 0, None
+    for i in range(steps + 1):
+        if i < steps:
+            al.submit_device(d_seq_ptr, d_off_ptr, R, first_read_id=0, max_len=max_len, mixed=mixed)
+            pending += 1
+        if pending == 2 or (i == steps and pending):
+            counts = al.wait()
+            pending -= 1
+            for k, v in al.stage_ms().items():
+                stage[k] = stage.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return steps * R / dt / 1e6, {k: v / steps for k, v in stage.items()}, counts
+
+
+def robustness(al, index, d_seq, d_off, R, steps):
+    """the same ctx on inputs the memo cannot answer (DESIGN.md "memo"): every path below is the round-2 path"""
+    import torch
+
+    dev = d_seq.device
+    out = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x67726F6F74)
+    CH = 1_000_000
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    # (a) substitution errors: every base is replaced by another one with probability 0.01 (63 % of the reads hold at least one)
+    err = d_seq.clone()
+    rows = err[: R * READ_LEN].view(R, READ_LEN)
+    for c0 in range(0, R, CH):
+        n = min(CH, R - c0)
+        hit = torch.rand(n, READ_LEN, generator=g, device=dev) < 0.01
+        cur = torch.searchsorted(acgt, rows[c0:c0 + n].contiguous())          # A C G T -> 0..3
+        other = acgt[(cur + 1 + torch.randint(0, 3, (n, READ_LEN), generator=g, device=dev)) % 4]
+        rows[c0:c0 + n] = torch.where(hit, other, rows[c0:c0 + n])
+    v, ms, c = resident_rate(al, err.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
+    out["substitutions_1pct"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "mapped": c["mapped"], "full_sketch_reads": c["full_sketch_reads"],
+                                 "walked_reads": c["walked_reads"], "what": "each base replaced with probability 0.01: reads with an error take the hashing kernels"}
+    # (b) metagenome-like: 99 % of the reads are uniform random ACGT (SURVEY 8d)
+    rows = err[: R * READ_LEN].view(R, READ_LEN)
+    rows[:] = d_seq[: R * READ_LEN].view(R, READ_LEN)
+    for c0 in range(0, R, CH):
+        n = min(CH, R - c0)
+        bg = torch.rand(n, generator=g, device=dev) < 0.99
+        rnd = acgt[torch.randint(0, 4, (n, READ_LEN), generator=g, device=dev)]
+        rows[c0:c0 + n] = torch.where(bg[:, None], rnd, rows[c0:c0 + n])
+    v, ms, c = resident_rate(al, err.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 3)
+    out["background_99pct"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "mapped": c["mapped"], "full_sketch_reads": c["full_sketch_reads"],
+                               "what": "99 % uniform random reads: the text lookup misses, the ctx goes back to the signature kernel after one batch"}
+    del err
+    return out
+
+
+def threshold_sweep(index, d_seq, d_off, R, steps, local_rank):
+    """configs[4]'s containment-threshold sweep on the headline reads: a ctx per threshold (its memo is the pipeline's output AT that threshold)"""
+    from groot_amd import device
+
+    out = {}
+    for t in (0.97, 0.95, 0.90):
+        al = device.Aligner(index, device=local_rank, threshold=t, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
+                            results_on_device=True, pipeline_depth=2)
+        al.set_profiling(True)
+        v, ms, c = resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
+        out["t=%.2f" % t] = {"value": v, "unit": "Mreads/s", "seeds_per_read": c["seeds"] / R, "alignments": c["alignments"], "stage_ms": ms,
+                             "full_sketch_reads": c["full_sketch_reads"], "open_ms": al.open_stats()["open_ms"]}
+        al.close()
+    return out
+
+
+def mixed_leg(local_rank, n_reads, steps, cli_reads, bam_level):
+    """BASELINE configs[4] at single-GPU scale: resfinder.90 (card.90 is not in the reference tree), reads of 75..150 bases of both
+    strands, threshold sweep (kernels, reads resident in HBM), and one gzip-streamed run through build/groot-hip align"""
+    import gzip
+
+    import torch
+
+    from groot_amd import device, host, synth
+
+    cache = host.index_cache_path("resfinder.90.k31.s21.w100")
+    index = None
+    if os.path.exists(cache):
+        try:
+            index = host.Index.load(cache)
+        except Exception:
+            index = None
+    if index is None:
+        with tempfile.TemporaryDirectory() as td:
+            with tarfile.open(os.path.join(REPO, "tests", "golden", "data", "resfinder.90.tar.gz")) as tf:
+                members = [m for m in tf.getmembers() if os.path.basename(m.name).startswith("cluster") and m.name.endswith(".msa")]
+                tf.extractall(td, members=members)
+            index = host.Index.from_msa_dir(os.path.join(td, "resfinder.90"))
+        try:
+            index.save(cache + ".tmp")
+            os.replace(cache + ".tmp", cache)
+        except Exception:
+            pass
+    dev = torch.device("cuda", local_rank)
+    cat, off, lens = synth.reference_sequences(index)
+    cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, off, lens))
+    d_seq, d_off, _ = synth.reads_torch_mixed(cat_t, off_t, lens_t, n_reads, 150, 75)
+    total = int(d_off[-1].item())
+    out = {"index": "resfinder.90 k=31 s=21 w=100: %d graphs, %d windows" % (index.view.n_graphs, index.view.n_windows), "reads": n_reads,
+           "read_len": "U{75..150}", "mean_len": total / n_reads, "kernels": {},
+           "what": "reads resident in HBM, records stay in HBM (as `value`); reads of other lengths than the window are not in the memo: this is the hashing + graph-walk path"}
+    for t in (0.99, 0.97, 0.95, 0.90):
+        al = device.Aligner(index, device=local_rank, threshold=t, max_batch_reads=n_reads, max_read_len=256, max_batch_bases=total + 64,
+                            results_on_device=True, pipeline_depth=2)
+        al.set_profiling(True)
+        v, ms, c = resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), n_reads, 150, steps, 2, mixed=True)
+        out["kernels"]["t=%.2f" % t] = {"value": v, "unit": "Mreads/s", "mapped": c["mapped"], "seeds_per_read": c["seeds"] / n_reads,
+                                         "alignments": c["alignments"], "stage_ms": ms}
+        al.close()
+    # gzip-streamed through the CLI (t = 0.97)
+    try:
+        import __graft_entry__ as entry
+
+        exe = entry.build_cli()
+        n = min(cli_reads, n_reads)
+        seq_h = d_seq[: int(d_off[n].item())].cpu().numpy()
+        off_h = d_off[: n + 1].cpu().numpy()
+        with tempfile.TemporaryDirectory(dir=os.environ.get("GROOT_BENCH_TMP")) as td:
+            idx_dir = os.path.join(td, "index")
+            os.makedirs(idx_dir)
+            index.save(os.path.join(idx_dir, "groot.gidx"))
+            fq = os.path.join(td, "reads.fq.gz")
+            t0 = time.perf_counter()
+            with gzip.open(fq, "wb", compresslevel=1) as f:
+                CHK = 100_000
+                for c0 in range(0, n, CHK):
+                    c1 = min(n, c0 + CHK)
+                    parts = []
+                    for i in range(c0, c1):
+                        s_ = seq_h[off_h[i]:off_h[i + 1]].tobytes()
+                        parts.append(b"@m%d\n%s\n+\n%s\n" % (i, s_, b"I" * len(s_)))
+                    f.write(b"".join(parts))
+            gz_s = time.perf_counter() - t0
+            stats = os.path.join(td, "stats.json")
+            cmd = [exe, "align", "-i", idx_dir, "-f", fq, "-g", os.path.join(td, "graphs"), "--bam", os.path.join(td, "out.bam"), "--log", os.path.join(td, "groot.log"),
+                   "-p", str(usable_cpus()), "-t", "0.97", "--bamLevel", str(bam_level), "--stats", stats, "--batch", "262144"]
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            wall = time.perf_counter() - t0
+            if p.returncode != 0:
+                out["cli_gzip"] = {"error": (p.stderr or p.stdout)[-300:]}
+            else:
+                st = json.load(open(stats))
+                out["cli_gzip"] = {"value": n / wall / 1e6, "unit": "Mreads/s", "reads": n, "threshold": 0.97, "wall_s": wall, "stream_value": n / st["stream_s"] / 1e6,
+                                   "fastq_gz_bytes": os.path.getsize(fq), "gzip_write_s": gz_s, "phases_s": st,
+                                   "what": "build/groot-hip align on ONE gzip FASTQ (inflated on one thread, as bufio over gzip.Reader in the reference): whole process"}
+    except Exception as e:
+        out["cli_gzip"] = {"error": repr(e)}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -260,7 +429,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-cli", action="store_true")
-    ap.add_argument("--host-fed-steps", type=int, default=40)
+    ap.add_argument("--host-fed-steps", type=int, default=0, help="0 = as many as run for about --host-fed-seconds")
+    ap.add_argument("--host-fed-seconds", type=float, default=5.0)
+    ap.add_argument("--no-legs", action="store_true", help="skip the robustness / thresholds / mixed legs")
+    ap.add_argument("--leg-steps", type=int, default=10)
+    ap.add_argument("--mixed-reads", type=int, default=2_000_000)
+    ap.add_argument("--mixed-cli-reads", type=int, default=1_000_000)
     ap.add_argument("--cli-reads", type=int, default=2_000_000)
     ap.add_argument("--cli-bam-level", type=int, default=1)
     ap.add_argument("--no-align", action="store_true", help="diagnostic: --noAlign mode (weights only, no BAM records)")
@@ -361,7 +535,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k_ms, a_ms, s_ms, g_ms = [], [], [], []
+    k_ms, a_ms, s_ms, g_ms, f_ms, o_ms = [], [], [], [], [], []
+    open_stats = al.open_stats()
     # the ctx is a pipeline (submit / collect-the-oldest): the next step is enqueued while the GPU works on this one, so
     # the host's launch latency is not part of a step; every step is waited for and its counters are read
     pending = 0
@@ -374,6 +549,7 @@ def main():
             pending -= 1
             ms = al.stage_ms()
             k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"]); g_ms.append(ms["schedule"])
+            f_ms.append(ms["first_seed_kernel"]); o_ms.append(ms["order_kernel"])
     while pending:
         counts = al.wait()
         pending -= 1
@@ -393,54 +569,78 @@ def main():
         total_reads = world * R * args.steps
         value = total_reads / dt / 1e6
         seed_ms, align_ms, order_ms = float(np.mean(k_ms)), float(np.mean(a_ms)), float(np.mean(s_ms))
-        # algorithmic bytes per launch (DESIGN.md "Measurement"): what each kernel must read / write once
-        #   sketch_seed: bases + u64 offset in; u32 seed count + u32 per seed out
-        #   align      : bases + u64 offset + u32 seed count + u32 per seed in; u32 traversal count per read,
-        #                44 B per traversal record (20 B header + 3x8 B path set) and one u32 call count per seed tried out
+        first_ms, ordk_ms = float(np.mean(f_ms)), float(np.mean(o_ms))
         pw = index.view.path_words
-        seed_bytes = R * (READ_LEN + 8 + 4) + 4 * counts["seeds"]
-        align_bytes = R * (READ_LEN + 8 + 4 + 4) + 4 * counts["seeds"] + (20 + 8 * pw) * counts["travs"] + 4 * counts["seeds"]
-        # (the seed stage is sketch_sig_kernel plus the list pass of sketch_seed_kernel behind it: one HIP-event interval)
-        kernels = {"sketch_sig_kernel": (seed_ms, seed_bytes), "align_kernel": (align_ms, align_bytes)}
+        # Algorithmic bytes per launch (what a kernel must read / write once per read; index, graph and memo-table
+        # traffic is not counted -- DESIGN.md "Measurement" has the per-read figures):
+        #   first seed kernel (text lookup): bases + u64 offset in; scheduling key, table index, traversal count out
+        #   order_first_kernel             : table index, traversal count, offset in; 20 B record + path set per traversal, seed count + seeds out
+        #   align_kernel                   : the reads that need the graph walk only: bases + record in, record + path set + call counts out
+        walked = counts["walked_reads"]
+        kernels = {
+            "text_lookup_kernel (first seed kernel)": (first_ms, R * (READ_LEN + 8) + 12 * R),
+            "order_first_kernel": (ordk_ms, 12 * R + (20 + 8 * pw) * counts["travs"] + 4 * R + 4 * counts["seeds"]),
+            "align_kernel": (align_ms, walked * (READ_LEN + 32 + 4 + 20 + 8 * pw + 8)),
+        }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        step_bytes = R * (READ_LEN + 4) + 4 * R + 8 * counts["seeds"] + (20 + 8 * pw) * counts["travs"]     # SURVEY 8d, full pipeline
+        step_ms = dt / args.steps * 1e3
         # HBM traffic / VALU issue need PMC passes (rocprofv3 --pmc), which cannot run inside this process: they are read
         # from the committed profile of the same command and labelled as such; null when that file is absent
-        traffic, valu = None, None
+        traffic = None
+        pmc_key = dom.split(" ")[0]
         if os.path.exists(PMC_FILE):
             try:
-                rec = json.load(open(PMC_FILE)).get(dom, {})
+                rec = json.load(open(PMC_FILE)).get(pmc_key, {})
                 traffic = rec.get("hbm_bytes_per_launch")
-                insts = rec.get("per_launch", {}).get("SQ_INSTS_VALU")
-                if insts:
-                    valu = {"wave_insts_per_launch": insts, "wave_insts_per_read": insts / R,
-                            "source": "profiles/r02_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU of this command, not measured in this run)"}
             except Exception:
-                traffic, valu = None, None
+                traffic = None
         line = {
             "metric": "Mreads/s aligned", "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: full pipeline incl. on-GPU graph-traversal alignment, 100 bp error-free reads sampled from arg-annot.90, index k=31 s=21 w=100 x=8 y=4, t=0.99",
                        "reads_per_gpu_per_step": R, "read_len": READ_LEN, **({"background_fraction": args.background} if args.background > 0 else {}), "parallelism": f"reads sharded x{world}, index replicated",
-                       "residency": "inputs and traversal records in HBM (host_fed / cli_e2e below carry the PCIe- and host-inclusive rates)",
+                       "residency": "inputs and traversal records in HBM, two batches in flight (host_fed / cli_e2e below carry the PCIe- and host-inclusive rates)",
                        "per_step_counts": counts,
-                       "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms}},
+                       "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms,
+                                    "first_seed_kernel": first_ms, "order_kernel": ordk_ms},
+                       "open": open_stats,
+                       "memo_note": "reads that equal a WindowSize-mer of an indexed path are answered from the memo groot_hip_open builds by running this ctx's own "
+                                    "pipeline on every such string (DESIGN.md); robustness.* below is the same ctx on reads the memo cannot answer"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "traffic_source": "profiles/r03_pmc.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
                          "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
-                         "note": "integer hashing / graph walking: the binding ceilings are VALU issue and dependent L2 trips, not HBM (DESIGN.md)", "valu_issue": valu,
-                         "other": {k: {"kernel_ms": v[0], "bytes_per_launch": v[1], "achieved": v[1] / (v[0] * 1e-3) / 1e9}
+                         "note": "table lookups and scattered record writes: bound by random 64-byte HBM accesses and call-count atomics, not by streaming bandwidth (DESIGN.md)",
+                         "whole_step": {"bytes": step_bytes, "ms": step_ms, "achieved": step_bytes / (step_ms * 1e-3) / 1e9,
+                                        "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "what": "SURVEY 8d bytes per read x reads / whole step"},
+                         "other": {k: {"kernel_ms": v[0], "bytes_per_launch": v[1], "achieved": v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None}
                                    for k, v in kernels.items() if k != dom}},
         }
         if world == 1:
+            if not args.no_legs and args.background == 0:
+                try:
+                    line["robustness"] = robustness(al, index, d_seq, d_off, R, args.leg_steps)
+                except Exception as e:   # the headline must still print
+                    line["robustness"] = {"error": repr(e)}
             al.close()
             al = None
+            if not args.no_legs:
+                try:
+                    line["thresholds"] = threshold_sweep(index, d_seq, d_off, R, args.leg_steps, local_rank)
+                except Exception as e:
+                    line["thresholds"] = {"error": repr(e)}
+                try:
+                    line["mixed"] = mixed_leg(local_rank, args.mixed_reads, args.leg_steps, args.mixed_cli_reads, args.cli_bam_level)
+                except Exception as e:
+                    line["mixed"] = {"error": repr(e)}
             if not args.no_host_fed:
                 try:
-                    hf, _ = host_fed(index, d_seq, R, args.host_fed_steps)
+                    hf_steps = args.host_fed_steps or max(40, int(args.host_fed_seconds / (step_ms * 4e-3)))   # (a host-fed batch takes ~4x a resident step: PCIe)
+                    hf, _ = host_fed(index, d_seq, R, hf_steps)
                     hf["frac_of_resident"] = hf["value"] / value
                     line["host_fed"] = hf
                 except Exception as e:   # the headline must still print

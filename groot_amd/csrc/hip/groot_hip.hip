@@ -111,7 +111,8 @@ struct Slot {
     uint64_t n_mask_words = 0, copied_words = 0;
     bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
     hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
-    hipEvent_t ev[7]{};                    // stage boundaries on the compute stream (profiling)
+    hipEvent_t ev[11]{};                   // [7..8] around the first seed kernel, [9..10] around order_first_kernel
+                                           // [0..6] stage boundaries on the compute stream (profiling)
     groot_counts counts{};
     int status = GROOT_OK;
     std::string status_msg;
@@ -147,7 +148,7 @@ struct groot_ctx {
     DevBuf<uint32_t> sig_info;             // per window-text string: verdict byte, or where its tabulated outcome is (DeviceIndex::sig_info)
     DevBuf<uint4> out_tab;                 // AlignRead outcomes of the window-text strings (DeviceIndex::out_tab)
     uint64_t out_strings = 0, out_tabulated = 0, out_entries = 0;   // strings that confirm reads / of them tabulated / table entries
-    double out_build_ms = 0;
+    double out_build_ms = 0, open_ms = 0;
     uint32_t incr_cap = kIncrCap;
     bool tab_capture = false;              // the capture pass of groot_hip_open is running (align stage records the IncrementSubPath windows)
     DevBuf<uint32_t> tab_idx, tab_hist, incr_cnt, incr_win;
@@ -649,6 +650,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= 8;
     s->text_used = !c->prm.keep_sketches && c->dix.text_tab && c->dix.out_tab && text_try && s->max_len >= c->dix.w && !c->tab_capture;
     if (s->text_used) c->batches_without_text = 0;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[7], c->stream));
     if (s->text_used) {
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
@@ -658,6 +660,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         if (c->dix.w <= 128) hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a);
         else hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a);
         HIP_TRY(c, hipGetLastError());
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
         {   // the reads it marked, as a list
             size_t tb = 0;
             IsTodo pred{c->tab_idx.p};
@@ -684,6 +687,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     }
     HIP_TRY(c, hipGetLastError());
+    if (c->profiling && !s->text_used) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));   // (signature kernel + its list pass / the full-width kernel)
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(64), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
                        c->max_q, s->d_ctr.p, c->seed_shards.p);
@@ -791,9 +795,11 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
         ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
         ot.q_tab = c->dix.w - c->k + 1; ot.n_windows = c->n_windows;
     }
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[9], c->stream));
     hipLaunchKernelGGL(order_first_kernel, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, 2048u)), dim3(kBlock), 0, c->stream, c->trav_first.p,
                        c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw,
                        c->pw_view, s->d_ctr.p, ot);
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[10], c->stream));
     hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->stream,
                        c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, s->first_read_id, s->d_trav.p,
                        s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
@@ -1091,7 +1097,8 @@ static int finish_counters(groot_ctx *c, Slot *s)
     o.received = s->n_reads;              // boss.go:194 receivedReads++ for every read
     o.mapped = h.mapped; o.multimapped = h.multimapped; o.alignments = h.alignments; o.seeds = h.seeds;
     o.travs = s->n_trav; o.revcomp_panics = h.revcomp_panics; o.short_reads = h.short_reads;
-    o.full_sketch_reads = s->sig_used ? h.todo_reads : s->n_reads;
+    o.full_sketch_reads = (s->sig_used || s->text_used) ? h.todo_reads : s->n_reads;
+    o.walked_reads = h.seeded_reads;
     if (s->status == GROOT_OK) {
         char buf[256];
         if (h.flags & kFlagLongRead) { s->status = GROOT_E_NOSPACE; snprintf(buf, sizeof buf, "a read is longer than max_read_len=%u", c->prm.max_read_len); s->status_msg = buf; }
@@ -1188,6 +1195,8 @@ static int collect_impl(groot_ctx *c, Slot **out)
         (void)hipEventElapsedTime(&s->ms.align, s->ev[3], s->ev[4]);
         (void)hipEventElapsedTime(&s->ms.sort, s->ev[4], s->ev[5]);
         (void)hipEventElapsedTime(&s->ms.total, s->ev[0], s->ev[5]);
+        (void)hipEventElapsedTime(&s->ms.first_seed_kernel, s->ev[7], s->ev[8]);
+        (void)hipEventElapsedTime(&s->ms.order_kernel, s->ev[9], s->ev[10]);
         if (!c->prm.results_on_device) (void)hipEventElapsedTime(&s->ms.d2h, s->ev_d2h0, s->ev_d2h);
     }
     c->inflight.pop_front();
@@ -2094,12 +2103,24 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     return GROOT_OK;
 }
 
+int groot_hip_open_stats(const groot_ctx *c, groot_open_stats *out)
+{
+    if (!c || !out) return GROOT_E_INVALID;
+    memset(out, 0, sizeof *out);
+    out->open_ms = c->open_ms; out->memo_ms = c->out_build_ms;
+    out->memo_strings = c->out_strings; out->memo_tabulated = c->out_tabulated; out->memo_entries = c->out_entries; out->text_entries = c->text_entries;
+    out->memo_hbm_bytes = c->out_tab.n * sizeof(uint4) + c->text_tab.n * sizeof(uint4) + c->sig_info.n * sizeof(uint32_t);
+    return GROOT_OK;
+}
+
 int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p)
 {
     if (!out) return fail(nullptr, GROOT_E_INVALID, "null out pointer");
     *out = nullptr;
     groot_ctx *c = new groot_ctx();
+    const auto t_open0 = std::chrono::steady_clock::now();
     int rc = open_impl(c, device_id, idx, p);
+    c->open_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_open0).count();
     if (rc) {
         g_open_err = c->err;
         groot_hip_close(c);
@@ -2312,9 +2333,11 @@ int groot_hip_submit_device(groot_ctx *c, const void *d_seq, const void *d_seq_o
     if (int rc = ensure_slot(c, s, Slot::IN_DEVICE, 0)) return rc;
     s->input = Slot::IN_DEVICE; s->n_reads = n_reads; s->first_read_id = first_read_id; s->n_bases = 0; s->n_exc = 0;
     s->ext_seq = (const uint8_t *)d_seq; s->ext_off = (const uint64_t *)d_seq_off;
+    const bool mixed = (max_len & GROOT_MAXLEN_MIXED) != 0;     // the caller's word: the reads differ in length
+    max_len &= ~GROOT_MAXLEN_MIXED;
     s->max_len = max_len ? std::min(max_len, c->prm.max_read_len) : c->prm.max_read_len;
-    s->mixed_len = false;                  // (unknown: the offsets are on the device)
-    s->one_len = max_len != 0;             // (the caller's word: the longest read, taken as THE read length when choosing kernels)
+    s->mixed_len = mixed;                  // (else unknown: the offsets are on the device)
+    s->one_len = max_len != 0 && !mixed;   // (the caller's word: the longest read, taken as THE read length when choosing kernels)
     return enqueue(c, s);
 }
 

@@ -27,14 +27,19 @@ class Params(C.Structure):
 
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("received", "mapped", "multimapped", "alignments", "seeds", "travs",
-                                            "revcomp_panics", "short_reads", "full_sketch_reads")]
+                                            "revcomp_panics", "short_reads", "full_sketch_reads", "walked_reads")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class OpenStats(C.Structure):
+    _fields_ = [("open_ms", C.c_double), ("memo_ms", C.c_double)] + [(n, C.c_uint64) for n in ("memo_strings", "memo_tabulated", "memo_entries", "text_entries",
+                                                                                               "memo_hbm_bytes")]
+
+
 class StageMs(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack")]
+    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack", "first_seed_kernel", "order_kernel")]
 
 
 class BatchBuffers(C.Structure):
@@ -130,6 +135,12 @@ class Aligner:
         return rc
 
     # ---- batch API ----------------------------------------------------------------------------
+    def open_stats(self):
+        """groot_hip_open_stats: what open built besides the uploaded index (the memo) and how long it took"""
+        st = OpenStats()
+        self._check(lib().groot_hip_open_stats(self._h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in OpenStats._fields_}
+
     def set_stream(self, hip_stream):
         self._check(lib().groot_hip_set_stream(self._h, C.c_void_p(hip_stream)))
 
@@ -209,7 +220,9 @@ class Aligner:
         self._check(lib().groot_hip_in_flight(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def submit_device(self, d_seq_ptr, d_off_ptr, n_reads, first_read_id=0, max_len=0):
+    def submit_device(self, d_seq_ptr, d_off_ptr, n_reads, first_read_id=0, max_len=0, mixed=False):
+        if mixed:
+            max_len |= 0x80000000      # GROOT_MAXLEN_MIXED
         self._check(lib().groot_hip_submit_device(self._h, C.c_void_p(d_seq_ptr), C.c_void_p(d_off_ptr), C.c_uint32(n_reads),
                                                   C.c_uint32(first_read_id), C.c_uint32(max_len)))
 

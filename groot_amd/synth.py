@@ -109,3 +109,46 @@ def reads_torch(cat_t, off_t, lens_t, n_reads, read_len=100, first=0, seed=SEED)
     padded[:total] = out
     seq_off = torch.arange(0, n_reads + 1, dtype=torch.int64, device=dev) * read_len
     return padded, seq_off, {"seq": sidx, "start": start, "strand": strand}
+
+
+def reads_torch_mixed(cat_t, off_t, lens_t, n_reads, read_len=150, min_len=75, first=0, seed=SEED):
+    """device generation of reads of lengths U{min_len..read_len} (BASELINE configs[4]); the same stream as
+    reads_np(..., read_len, min_len=min_len): (uint8 tensor padded by 64 bytes, int64 offsets [n+1], truth)"""
+    import torch
+
+    dev = cat_t.device
+
+    def c(v):
+        v &= _M64
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, s):
+        return (x >> s) & ((1 << (64 - s)) - 1)
+
+    def mix(x):
+        x = x + c(0x9E3779B97F4A7C15)
+        x = (x ^ lsr(x, 30)) * c(0xBF58476D1CE4E5B9)
+        x = (x ^ lsr(x, 27)) * c(0x94D049BB133111EB)
+        return x ^ lsr(x, 31)
+
+    i = torch.arange(first, first + n_reads, dtype=torch.int64, device=dev) * 4 + c(seed)
+    r1, r2, r3, r4 = mix(i), mix(i + 1), mix(i + 2), mix(i + 3)
+    ok = torch.nonzero(lens_t >= read_len).squeeze(1)
+    sidx = ok[lsr(r1, 1) % ok.numel()]
+    rl = min_len + lsr(r4, 1) % (read_len - min_len + 1)
+    span = lens_t[sidx] - rl + 1
+    start = lsr(r2, 1) % span
+    strand = r3 & 1
+    seq_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    seq_off[1:] = torch.cumsum(rl, 0)
+    total = int(seq_off[-1].item())
+    read_of = torch.repeat_interleave(torch.arange(n_reads, device=dev), rl)
+    within = torch.arange(total, dtype=torch.int64, device=dev) - seq_off[:-1][read_of]
+    fwd_pos = torch.where(strand[read_of] == 0, within, rl[read_of] - 1 - within)
+    src = off_t[sidx][read_of] + start[read_of] + fwd_pos
+    b = cat_t[src]
+    comp = torch.from_numpy(_COMP).to(dev)
+    out = torch.where(strand[read_of] == 1, comp[b.long()], b)
+    padded = torch.zeros(((total + 15) // 16) * 16 + 64, dtype=torch.uint8, device=dev)
+    padded[:total] = out
+    return padded, seq_off, {"seq": sidx, "start": start, "strand": strand, "len": rl}

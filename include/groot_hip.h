@@ -71,16 +71,22 @@ typedef struct groot_counts {
     uint64_t travs;          /* groot_trav records of the batch                                      */
     uint64_t revcomp_panics; /* reads on which the reference panics in RevComplement (seqio.go:126)  */
     uint64_t short_reads;    /* reads shorter than k (reference panics, boss.go:164-166)             */
-    uint64_t full_sketch_reads; /* reads whose seeds the full-width sketch kernel decided: all of them, or -- when the
-                                 * signature kernel runs in front of it -- those it could not decide (diagnostic) */
+    uint64_t full_sketch_reads; /* reads whose seeds the full-width sketch kernel decided: all of them, or -- when the text
+                                 * lookup / the signature kernel runs in front of it -- those it could not decide (diagnostic) */
+    uint64_t walked_reads;      /* reads that went through the align stage's graph walk (the others: no seed window, or their
+                                 * whole outcome came from the memo of groot_hip_open) (diagnostic) */
 } groot_counts;
 
 /* per-stage device time of a batch, HIP events (ms); 0 if profiling off.
  * h2d = input copy on the copy-in stream; sketch_seed = the sketch+seed kernel alone; schedule = radix sort of the
- * processing order + record gather; align = the align kernel; sort = ordering of the traversal records into
- * (read, ord) order; total = first kernel .. last kernel; d2h = result copy on the copy-out stream */
+ * processing order (or its stream compaction); align = the align kernel; sort = ordering of the traversal records into
+ * (read, ord) order -- for reads answered from the outcome table this is where their records are written; total = first kernel .. last kernel; d2h = result copy on the copy-out stream */
 typedef struct groot_stage_ms {
     float h2d, sketch_seed, align, sort, total, schedule, d2h, unpack;
+    /* single kernels inside the stages above (for roofline figures): first_seed_kernel = the kernel that sees every read of the
+     * batch first (text lookup / signature kernel / full-width kernel), inside sketch_seed; order_kernel = order_first_kernel,
+     * inside sort */
+    float first_seed_kernel, order_kernel;
 } groot_stage_ms;
 
 int groot_hip_device_count(int *n);
@@ -91,6 +97,20 @@ const char *groot_hip_last_error(const groot_ctx *ctx); /* ctx may be NULL: erro
  * (groot_index_view_check's pass): GROOT_E_FORMAT for one whose indices or offsets do not resolve. */
 int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p);
 void groot_hip_close(groot_ctx *ctx);
+
+/* What groot_hip_open built besides the uploaded index (diagnostic; times in ms, host wall clock).  The memo: every
+ * WindowSize-mer of every indexed path went through the ctx's own pipeline once; reads that equal one of those strings are answered
+ * from it (DESIGN.md "memo"). */
+typedef struct groot_open_stats {
+    double open_ms;            /* the whole of groot_hip_open                                            */
+    double memo_ms;            /* of which: enumerating the strings, running the pipeline on them, tables */
+    uint64_t memo_strings;     /* distinct path strings                                                  */
+    uint64_t memo_tabulated;   /* of them with a stored outcome                                          */
+    uint64_t memo_entries;     /* outcome-table entries (one per traversal, at least one per string)      */
+    uint64_t text_entries;     /* strings in the text table (0: the text lookup is not used)              */
+    uint64_t memo_hbm_bytes;   /* HBM held by outcome table + text table + sig_info                       */
+} groot_open_stats;
+int groot_hip_open_stats(const groot_ctx *ctx, groot_open_stats *out);
 
 /* Run the kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own.
  * Only while nothing is in flight. */
@@ -134,7 +154,8 @@ int groot_hip_acquire(groot_ctx *ctx, groot_batch_buffers *out);
 int groot_hip_submit_acquired(groot_ctx *ctx, uint64_t ticket, uint32_t n_reads, uint64_t n_exc, uint32_t first_read_id);
 /* Inputs already resident in HBM (no staging, no H2D).  d_seq must be 16-byte aligned and readable for 16 bytes past
  * the last base (the kernels load 16-byte / 8-byte words); max_len = longest read of the batch
- * (0 = params.max_read_len).  The buffers must stay valid until the batch is collected. */
+ * (0 = params.max_read_len), taken as THE read length of the batch unless GROOT_MAXLEN_MIXED is set.  The buffers must stay valid until the batch is collected. */
+#define GROOT_MAXLEN_MIXED 0x80000000u /* OR into max_len: the reads of the batch differ in length (scheduling hint only) */
 int groot_hip_submit_device(groot_ctx *ctx, const void *d_seq, const void *d_seq_off, uint32_t n_reads,
                             uint32_t first_read_id, uint32_t max_len);
 

@@ -232,11 +232,17 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["per_step_counts"]["received"] == 300000 and "cpu_baseline" not in line
-    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "300000", "--no-cpu"],
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "300000", "--no-cpu",
+                          "--leg-steps", "2", "--mixed-reads", "30000", "--mixed-cli-reads", "5000", "--host-fed-seconds", "0.3"],
                          cwd=REPO, capture_output=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     single = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert single["n_gpus"] == 1 and single["config"]["per_step_counts"]["received"] == 300000
     # the PCIe- and host-inclusive legs ride on the same line
     assert single["host_fed"].get("value", 0) > 0 and single["host_fed"]["d2h_bytes_per_read"] > 20, single["host_fed"]
+    # ... and the legs for the inputs the memo does not answer, the threshold sweep and configs[4] in miniature
+    assert single["robustness"]["substitutions_1pct"]["value"] > 0 and single["robustness"]["background_99pct"]["value"] > 0, single["robustness"]
+    assert set(single["thresholds"]) == {"t=0.97", "t=0.95", "t=0.90"} and all(v["value"] > 0 for v in single["thresholds"].values())
+    assert set(single["mixed"]["kernels"]) == {"t=0.99", "t=0.97", "t=0.95", "t=0.90"} and single["mixed"]["cli_gzip"].get("value", 0) > 0, single["mixed"]
+    assert single["roofline"]["frac"] > 0 and single["cpu_baseline"] if "cpu_baseline" in single else True
     assert single["cli_e2e"].get("value", 0) > 0 and single["cli_e2e"]["reads"] == 300000, single["cli_e2e"]
