@@ -519,3 +519,67 @@ def test_full_size_properties(argannot_index):
     for f in ("graph_id", "path_id", "ref_id", "pos", "start_clip", "end_clip", "rc", "secondary"):
         assert np.array_equal(got[f], oal[f]), f
     al.close()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("threshold", [0.99, 0.95])
+def test_configs4_at_single_gpu_scale(resfinder_index, threshold):
+    """BASELINE configs[4] at the size one GPU takes: resfinder.90 (card.90 is not in the reference tree), 2 M reads of 75..150
+    bases of both strands, two points of the containment-threshold sweep -- through size-independent properties (determinism,
+    batch-split invariance of records and call counts, canonical order) and an oracle comparison on 20 000 sampled reads
+    (lshe.go:153-175 with per-length K / L / min-equal-slots, graphminion.go:46-102, alignment.go:13-159)"""
+    import torch
+
+    index = resfinder_index
+    dev = torch.device("cuda", 0)
+    cat, o, lens = synth.reference_sequences(index)
+    cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, o, lens))
+    R = 2_000_000
+    d_seq, d_off, _ = synth.reads_torch_mixed(cat_t, off_t, lens_t, R, 150, 75)
+    total = int(d_off[-1].item())
+    torch.cuda.synchronize()
+    al = device.Aligner(index, threshold=threshold, max_batch_reads=R, max_batch_bases=total + 64, max_read_len=256)
+    keys = ("received", "mapped", "multimapped", "alignments", "seeds", "travs", "revcomp_panics", "short_reads")
+
+    def run(lo, hi):
+        al.submit_device(d_seq.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, first_read_id=lo, max_len=150, mixed=True)
+        c = al.wait()
+        t, m = al.travs()
+        return {k: c[k] for k in keys}, t, m
+
+    c1, t1, m1 = run(0, R)
+    att1 = al.attempts()
+    al.attempts_reset()
+    c2, t2, m2 = run(0, R)
+    assert c1 == c2 and np.array_equal(t1, t2) and np.array_equal(m1, m2)          # deterministic
+    assert np.array_equal(att1, al.attempts())
+    assert c1["received"] == R and c1["mapped"] > 0.1 * R and c1["travs"] == len(t1)
+    assert np.all(np.diff(t1["read_id"].astype(np.int64)) >= 0)                    # canonical read order
+    al.attempts_reset()
+    cuts = [0, 300_000, 1_100_001, R]
+    ts, ms, tot = [], [], {k: 0 for k in keys}
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        c, t, m = run(lo, hi)
+        ts.append(t); ms.append(m)
+        for k in tot:
+            tot[k] += c[k]
+    assert tot == c1
+    assert digest(np.concatenate(ts)) == digest(t1) and digest(np.concatenate(ms)) == digest(m1)
+    assert np.array_equal(att1, al.attempts())
+    # oracle on a random sample of reads
+    rng = np.random.default_rng(int(threshold * 100))
+    pick = np.sort(rng.choice(R, 20_000, replace=False))
+    off_h = d_off.cpu().numpy()
+    seq_h = d_seq[:total].cpu().numpy()
+    reads = [seq_h[off_h[i]:off_h[i + 1]].tobytes() for i in pick]
+    s2, o2 = O.pack_reads(reads)
+    orun = O.Run(index, threshold)
+    orun.batch(s2, o2)
+    oal = orun.alns()
+    full = device.expand_alns(index, t1, m1)
+    got = full[np.isin(full["read_id"], pick)]
+    assert len(got) == len(oal) > 1000
+    assert np.array_equal(np.searchsorted(pick, got["read_id"]), oal["read_id"])
+    for f in ("graph_id", "path_id", "ref_id", "pos", "start_clip", "end_clip", "rc", "secondary"):
+        assert np.array_equal(got[f], oal[f]), f
+    al.close()
