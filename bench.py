@@ -410,6 +410,9 @@ def cli_e2e(index, d_seq, n_reads, bam_level):
         wall = time.perf_counter() - t0
         if p.returncode != 0:
             return {"error": (p.stderr or p.stdout)[-400:]}
+        if os.environ.get("GROOT_BAM_STATS"):
+            for ln in [x for x in p.stderr.splitlines() if "groot bam" in x][-4:]:
+                log(ln)
         st = json.load(open(stats))
         out = {"value": n_reads / wall / 1e6, "unit": "Mreads/s", "reads": n_reads, "wall_s": wall, "fastq_bytes": fq_bytes,
                "bam_bytes": os.path.getsize(bam), "bam_level": bam_level, "stream_value": n_reads / st["stream_s"] / 1e6,
@@ -435,8 +438,8 @@ def main():
     ap.add_argument("--leg-steps", type=int, default=10)
     ap.add_argument("--mixed-reads", type=int, default=2_000_000)
     ap.add_argument("--mixed-cli-reads", type=int, default=1_000_000)
-    ap.add_argument("--cli-reads", type=int, default=2_000_000)
-    ap.add_argument("--cli-bam-level", type=int, default=1)
+    ap.add_argument("--cli-reads", type=int, default=10_000_000)
+    ap.add_argument("--cli-bam-level", type=int, default=-2, help="-2 = structural BGZF (include/groot_host.h), -1..9 = zlib")
     ap.add_argument("--no-align", action="store_true", help="diagnostic: --noAlign mode (weights only, no BAM records)")
     ap.add_argument("--background", type=float, default=0.0,
                     help="diagnostic: fraction of reads replaced by uniform random ACGT (metagenome-like input, SURVEY 8d)")

@@ -96,7 +96,7 @@ void usage()
             "                  [--gpu 0]      (sketch the graph windows on that GPU instead of the host)\n"
             "                  [--writeGob]   (also write the reference's groot.gg + groot.lshe: experimental, unpinned against a Go-written file)\n"
             "  groot-hip align -i <indexDir> -f <fastq>[,<fastq>...] [-t 0.99] [-c 1.0] [-g <graphDir>] [--noAlign] [-p N] [--log F]\n"
-            "                  [--gpu 0 | --gpus N] [--batch 1048576] [--maxReadLen 512] [--bam out.bam] [--bamLevel -1..9] [--stats f.json]\n"
+            "                  [--gpu 0 | --gpus N] [--batch 1048576] [--maxReadLen 512] [--bam out.bam] [--bamLevel -2..9] [--stats f.json]\n"
             "                  (BAM goes to stdout unless --bam; --gpus N shards the reads over N GPUs, index replicated)\n"
             "  groot-hip report [--bamFile x.bam] [-c 0.97] [--lowCov] [--log F]      (BAM from stdin unless --bamFile)\n",
             groot_host_version());

@@ -7,8 +7,10 @@
 // BAM specification for the same field values: next_refID=-1, next_pos=-1 (no mate), tlen=0, no aux tags,
 // bin = reg2bin(pos, end).
 #include "host_common.hpp"
+#include "bgzf_struct.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <ctime>
 #include <thread>
@@ -32,10 +34,12 @@ struct groot_bam {
 };
 
 static const size_t kBgzfBlock = 0xff00;   // max uncompressed payload per block
+static const int kBamStructural = -2;      // groot_bam_set_level: members written from the records' structure (bgzf_struct.hpp)
 
 // one BGZF member for data[0..n) into out; returns its size or a negative error
 static long compress_block(const uint8_t *data, size_t n, std::vector<uint8_t> &out, int level = Z_DEFAULT_COMPRESSION)
 {
+    if (level == kBamStructural) level = 1;                // (what has no record structure -- header, odd pieces -- goes through zlib)
     out.resize(18 + compressBound((uLong)n) + 8);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -160,7 +164,7 @@ struct Nt16 {
 };
 
 // appends the BAM encoding of recs[i0, i1) to buf
-static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i1, std::vector<uint8_t> &buf)
+static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i1, std::vector<uint8_t> &buf, std::vector<uint32_t> *starts = nullptr)
 {
     static const Nt16 nt;
     const uint8_t *nt16 = nt.t;
@@ -179,6 +183,7 @@ static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i
         const uint32_t l_name = r.name_len + 1;
         const uint32_t body = 32 + l_name + 4 * nc + (r.seq_len + 1) / 2 + r.seq_len;
         const size_t at = buf.size();
+        if (starts) starts->push_back((uint32_t)at);
         buf.resize(at + 4 + body);
         uint8_t *p = buf.data() + at;
         auto w32 = [&](uint32_t v) { memcpy(p, &v, 4); p += 4; };
@@ -314,16 +319,23 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
     std::vector<uint64_t> nrec(n_chunks, 0);
     std::atomic<size_t> next{0};
     const int level = b->level;
+    static const bool bam_stats = getenv("GROOT_BAM_STATS") != nullptr;
+    std::atomic<uint64_t> ns_build{0}, ns_format{0}, ns_encode{0};
+    auto now_ns = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const uint64_t t_begin = now_ns();
     auto work = [&]() {
+        uint64_t tb = 0, tf = 0, te = 0;
         std::vector<uint8_t> raw, blk, rcs, rcq, padq;
+        std::vector<uint32_t> starts, rel;                       // record starts in raw (structural BGZF only)
         std::vector<groot_aln_record> recs;
         for (;;) {
             const size_t c = next.fetch_add(1);
-            if (c >= n_chunks) break;
-            raw.clear();
+            if (c >= n_chunks) { ns_build += tb; ns_format += tf; ns_encode += te; break; }
+            raw.clear(); starts.clear();
             const uint64_t t0 = c * kChunk, t1 = std::min<uint64_t>(n_trav, t0 + kChunk);
             uint64_t moff = mask_ckpt ? mask_ckpt[c] : 0;        // compact path sets: a checkpoint per chunk (kChunk = 256 traversals)
             for (uint64_t t = t0; t < t1; t++) {
+                const uint64_t q0 = bam_stats ? now_ns() : 0;
                 const groot_trav &tr = travs[t];
                 ReadRef rd;
                 if (!read(tr.read_id, rd) || tr.node >= ix->n_nodes || tr.graph_id >= ix->n_graphs) { errs[c] = GROOT_E_INVALID; break; }
@@ -350,14 +362,18 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                 const uint32_t gw = mask_ckpt ? std::max<uint32_t>(1, (ix->graph_path_off[tr.graph_id + 1] - ix->graph_path_off[tr.graph_id] + 63) / 64) : pw;
                 const uint64_t *mk = mask_ckpt ? masks + moff : masks + t * pw;
                 moff += gw;
+                uint32_t jn = np0;                                   // the node's (path, position) pairs ascend by path: walked along with the set bits
                 for (uint32_t w = 0; w < gw; w++) {
                     uint64_t m = mk[w];
                     while (m) {
                         const uint32_t p = w * 64 + (uint32_t)__builtin_ctzll(m);
                         m &= m - 1;
                         uint32_t pos = 0;
-                        for (uint32_t j = np0; j < np1; j++)
-                            if (ix->np_path[j] == p) { pos = ix->np_pos[j] + tr.offset; break; }   // alignment.go:296
+                        while (jn < np1 && ix->np_path[jn] < p) jn++;
+                        if (jn < np1 && ix->np_path[jn] == p) pos = ix->np_pos[jn] + tr.offset;     // alignment.go:296
+                        else
+                            for (uint32_t j = np0; j < np1; j++)           // (pairs not in path order: look through all of them)
+                                if (ix->np_path[j] == p) { pos = ix->np_pos[j] + tr.offset; break; }
                         groot_aln_record rec;
                         rec.name = rd.name;
                         rec.name_len = rd.name_len;
@@ -374,9 +390,39 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                 }
                 if (errs[c]) break;
                 nrec[c] += recs.size();
-                format_records(recs.data(), 0, recs.size(), raw);   // rcs/rcq/padq stay valid until here
+                const uint64_t q1 = bam_stats ? now_ns() : 0;
+                tb += q1 - q0;
+                format_records(recs.data(), 0, recs.size(), raw, level == kBamStructural ? &starts : nullptr);   // rcs/rcq/padq stay valid until here
+                if (bam_stats) tf += now_ns() - q1;
             }
             if (errs[c]) continue;
+            const uint64_t q2 = bam_stats ? now_ns() : 0;
+            if (level == kBamStructural) {
+                // members end at record boundaries; each is written from what the records have in common (bgzf_struct.hpp).  A piece
+                // that cannot be (a record of 32 KB or more) goes through zlib -1 like everything else used to.
+                size_t r0 = 0;
+                while (r0 < starts.size()) {
+                    size_t r1 = r0 + 1;
+                    const size_t a = starts[r0];
+                    while (r1 < starts.size() && (r1 + 1 < starts.size() ? starts[r1 + 1] : raw.size()) - a <= kBgzfBlock) r1++;
+                    const size_t e = r1 < starts.size() ? starts[r1] : raw.size();
+                    bool ok = e - a <= kBgzfBlock;
+                    if (ok) {
+                        rel.resize(r1 - r0);
+                        for (size_t x = r0; x < r1; x++) rel[x - r0] = starts[x] - (uint32_t)a;
+                        ok = bgzf_member_structural(raw.data() + a, e - a, rel.data(), rel.size(), outs[c]);
+                    }
+                    if (!ok)
+                        for (size_t o = a; o < e; o += kBgzfBlock) {
+                            const long sz = compress_block(raw.data() + o, std::min(kBgzfBlock, e - o), blk, 1);
+                            if (sz < 0) { errs[c] = (int)sz; break; }
+                            outs[c].insert(outs[c].end(), blk.begin(), blk.begin() + sz);
+                        }
+                    r0 = r1;
+                }
+                if (bam_stats) te += now_ns() - q2;
+                continue;
+            }
             for (size_t o = 0; o < raw.size(); o += kBgzfBlock) {   // records may span BGZF blocks
                 const long sz = compress_block(raw.data() + o, std::min(kBgzfBlock, raw.size() - o), blk, level);
                 if (sz < 0) { errs[c] = (int)sz; break; }
@@ -389,6 +435,7 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    const uint64_t t_par = now_ns();
     uint64_t total = 0;
     for (size_t c = 0; c < n_chunks; c++) {
         if (errs[c]) return set_error(errs[c], "could not build the BAM records of traversal chunk %zu", c);
@@ -413,6 +460,9 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
         }
         b->bytes_out += bytes;
     }
+    if (bam_stats)
+        fprintf(stderr, "[groot bam] %llu records: threads %u, parallel part %.1f ms (summed over threads: records %.1f, format %.1f, encode %.1f ms), write %.1f ms\n",
+                (unsigned long long)total, nt, (t_par - t_begin) / 1e6, ns_build.load() / 1e6, ns_format.load() / 1e6, ns_encode.load() / 1e6, (now_ns() - t_par) / 1e6);
     if (n_records) *n_records = total;
     return GROOT_OK;
 }
@@ -457,7 +507,7 @@ int groot_bam_write_batch(groot_bam *b, const groot_index_view *ix, const groot_
 int groot_bam_set_level(groot_bam *b, int level)
 {
     if (!b) return set_error(GROOT_E_INVALID, "null argument");
-    if (level < -1 || level > 9) return set_error(GROOT_E_INVALID, "BGZF compression level %d not in [-1, 9]", level);
+    if (level < -2 || level > 9) return set_error(GROOT_E_INVALID, "BGZF compression level %d not in [-2, 9]", level);
     b->level = level;
     return GROOT_OK;
 }

@@ -322,6 +322,20 @@ def test_bam_fast_path_equals_record_path(small_index, tmp_path):
     host._check(H.groot_bam_close(h))
     assert nrec.value == len(al)
     assert read_bam(slow) == read_bam(fast)
+    # level -2: members written from the records' structure (bgzf_struct.hpp: back-references to the previous record of the same
+    # size, fixed Huffman codes, carry-less-multiplication CRC) -- the inflated stream is byte for byte the zlib path's
+    import gzip
+
+    struct = str(tmp_path / "struct.bam")
+    host._check(H.groot_bam_open(struct.encode(), C.byref(small_index.view), b"2020-01-01T00:00:00Z", C.byref(h)))
+    host._check(H.groot_bam_set_threads(h, C.c_uint32(3)))
+    host._check(H.groot_bam_set_level(h, C.c_int(-2)))
+    host._check(H.groot_bam_write_travs(h, C.byref(small_index.view), C.byref(rb), tr.ctypes.data_as(C.c_void_p), _ffi.as_ptr(mk, C.c_uint64),
+                                        C.c_uint64(len(tr)), C.byref(nrec)))
+    host._check(H.groot_bam_close(h))
+    assert gzip.open(struct).read() == gzip.open(fast).read()
+    assert read_bam(struct) == read_bam(fast)
+    assert os.path.getsize(struct) < 0.8 * len(gzip.open(fast).read())        # still a compressed file (random qualities here: literals)
 
 
 def test_pack_reads():
