@@ -1466,10 +1466,17 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     static const char kBase[4] = {'A', 'C', 'T', 'G'};
     // one batch: strings ids[0..m) through the pipeline; incr_cap call-count windows and up to seed_rows seed windows kept per string
     auto run = [&](const size_t *ids, uint32_t m, uint32_t incr_cap, bool second_pass) -> int {
-        for (uint32_t j = 0; j < m; j++) {
-            const uint32_t *pwd = &set.words[ids[j] * tw];
-            uint8_t *dst = &seqs[(size_t)j * w];
-            for (uint32_t x = 0; x < w; x++) dst[x] = (uint8_t)kBase[(pwd[x >> 4] >> (2 * (x & 15))) & 3u];
+        {
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, granted_cpus()), m / 4096));
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
+                for (uint32_t j = (uint32_t)((uint64_t)m * t / nt); j < (uint32_t)((uint64_t)m * (t + 1) / nt); j++) {
+                    const uint32_t *pwd = &set.words[ids[j] * tw];
+                    uint8_t *dst = &seqs[(size_t)j * w];
+                    for (uint32_t x = 0; x < w; x++) dst[x] = (uint8_t)kBase[(pwd[x >> 4] >> (2 * (x & 15))) & 3u];
+                }
+            });
+            for (auto &x : th) x.join();
         }
         c->incr_cap = incr_cap;
         HIP_TRY(c, c->incr_cnt.reserve(m));
@@ -1582,9 +1589,12 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     if (!c->out_entries) return GROOT_OK;
     // ---- 3. sig_info of the window-text strings (the signature kernel's way into the table): they are path strings ----
     {
+        const unsigned nt = std::min(32u, granted_cpus());
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
         uint32_t buf[16];
         std::vector<uint32_t> pk;
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = t; i < n; i += nt) {                  // (the set is only read here)
             if (!tlen[i]) continue;
             for (uint32_t row = 0; row < 2; row++) {
                 const uint8_t *src = &text[(size_t)i * 2 * kTextMax + row * kTextMax];
@@ -1597,6 +1607,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                 }
             }
         }
+        });
+        for (auto &x : th) x.join();
     }
     lap("sig_info");
     tab.resize(tab.size() + 16, 0);
@@ -1616,21 +1628,18 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
         for (size_t j = 0; j < NS; j++) ns += in_text[j];
         uint32_t cap = 1024;
         while (cap < 2 * ns) cap <<= 1;
-        std::vector<uint32_t> tt((size_t)cap * 16, 0);
-        const uint32_t twk = tw <= 8 ? 8 : 14;             // (the kernel instance hashes its whole register row; dwords past the string are zero)
-        uint32_t rec[16];
-        for (size_t j = 0; j < NS; j++) {
-            if (!in_text[j]) continue;
-            memset(rec, 0, sizeof rec);
-            memcpy(rec + 2, &set.words[j * tw], (size_t)tw * 4);
-            const uint64_t h = StringSet::hash(rec + 2, twk);
-            uint32_t slot = (uint32_t)h & (cap - 1);
-            while (tt[(size_t)slot * 16 + 1] != 0) slot = (slot + 1) & (cap - 1);
-            rec[0] = (uint32_t)(h >> 32); rec[1] = sinfo[j];
-            memcpy(&tt[(size_t)slot * 16], rec, 64);
-        }
+        // filled on the device: the strings are uploaded as they sit in the set, every thread claims a slot for its string with a
+        // compare-and-swap on the entry's sig_info word (0 = free) and writes tag and bases behind it
+        DevBuf<uint32_t> d_words, d_info;
+        for (size_t j = 0; j < NS; j++) if (!in_text[j]) sinfo[j] = 0;      // (sinfo is not needed past this point)
+        HIP_TRY(c, upload(d_words, set.words.data(), NS * tw));
+        HIP_TRY(c, upload(d_info, sinfo.data(), NS));
         HIP_TRY(c, c->text_tab.alloc((size_t)cap * 4));
-        HIP_TRY(c, hipMemcpy(c->text_tab.p, tt.data(), (size_t)cap * 64, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemsetAsync(c->text_tab.p, 0, (size_t)cap * 64, c->stream));
+        hipLaunchKernelGGL(text_table_fill_kernel, dim3((unsigned)((NS + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_words.p, d_info.p, (uint32_t)NS, tw,
+                           tw <= 8 ? 8u : 14u, reinterpret_cast<uint32_t *>(c->text_tab.p), cap - 1);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->dix.text_tab = c->text_tab.p;
         c->dix.text_mask = cap - 1;
         c->text_entries = ns;
@@ -1958,19 +1967,31 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         c->dix.exact_mask = cap - 1;
     }
     lap("exact table");
-    {   // LSH forest band tables: per band the low-32 hash values of its max_k slots, sorted
+    // LSH forest band tables: per band the low-32 hash values of its max_k slots, sorted.  Host work only (sorts), so it runs on
+    // its own threads while the main thread goes on building what the window-sized strings of the signature index / memo need
+    // first; joined and uploaded before anything can take the LSH-Forest branch (finish_lsh below).
+    struct LshHost {
+        std::vector<uint32_t> keys, ids, run;
+        std::vector<ExactEntry> tab;
+        std::vector<uint8_t> sig;
+        std::thread job;
+        ~LshHost() { if (job.joinable()) job.join(); }
+    } lsh;
+    {
         const uint32_t mk = v->max_k, lmax = c->l_max;
-        std::vector<uint32_t> keys((size_t)lmax * n * mk), ids((size_t)lmax * n);
+        lsh.keys.assign((size_t)lmax * n * mk, 0); lsh.ids.assign((size_t)lmax * n, 0);
         // hash tables over the distinct K-prefixes of every band: the query finds the first matching row with one or two
         // probes instead of a binary search of ~log2(n) dependent loads
         uint32_t bits = 4;
         while ((1ull << bits) < 2 * (uint64_t)n) bits++;
         c->band_hash_bits = bits;
         const uint32_t cap = 1u << bits;
-        std::vector<ExactEntry> tab((size_t)lmax * mk * cap, ExactEntry{0, kEmpty});
-        std::vector<uint8_t> sig((size_t)lmax * n * 32, 0);
-        std::vector<uint32_t> run((size_t)lmax * mk * n, 0);
+        lsh.tab.assign((size_t)lmax * mk * cap, ExactEntry{0, kEmpty});
+        lsh.sig.assign((size_t)lmax * n * 32, 0);
+        lsh.run.assign((size_t)lmax * mk * n, 0);
         const uint32_t sl = std::min<uint32_t>(s, 32);
+        lsh.job = std::thread([&lsh, v, n, s, mk, lmax, bits, cap, sl]() {
+        auto &keys = lsh.keys; auto &ids = lsh.ids; auto &tab = lsh.tab; auto &sig = lsh.sig; auto &run = lsh.run;
         auto band = [&](uint32_t b) {                            // the bands are independent: one thread each
             std::vector<uint32_t> order(n);
             std::iota(order.begin(), order.end(), 0u);
@@ -2020,12 +2041,21 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                 th.emplace_back([&]() { for (uint32_t b; (b = next.fetch_add(1)) < lmax;) band(b); });
             for (auto &x : th) x.join();
         }
-        HIP_TRY(c, upload(c->band_keys, keys.data(), keys.size()));
-        HIP_TRY(c, upload(c->band_ids, ids.data(), ids.size()));
-        HIP_TRY(c, upload(c->band_hash, tab.data(), tab.size()));
-        HIP_TRY(c, upload(c->band_sig, sig.data(), sig.size(), 32));
-        HIP_TRY(c, upload(c->band_run, run.data(), run.size()));
+        });
     }
+    auto finish_lsh = [&]() -> int {
+        if (lsh.job.joinable()) lsh.job.join();
+        if (c->band_keys.p) return GROOT_OK;
+        HIP_TRY(c, upload(c->band_keys, lsh.keys.data(), lsh.keys.size()));
+        HIP_TRY(c, upload(c->band_ids, lsh.ids.data(), lsh.ids.size()));
+        HIP_TRY(c, upload(c->band_hash, lsh.tab.data(), lsh.tab.size()));
+        HIP_TRY(c, upload(c->band_sig, lsh.sig.data(), lsh.sig.size(), 32));
+        HIP_TRY(c, upload(c->band_run, lsh.run.data(), lsh.run.size()));
+        c->dix.band_keys = c->band_keys.p; c->dix.band_ids = c->band_ids.p; c->dix.band_hash = c->band_hash.p;
+        c->dix.band_sig = c->band_sig.p; c->dix.band_run = c->band_run.p;
+        lsh.keys = {}; lsh.ids = {}; lsh.run = {}; lsh.tab = {}; lsh.sig = {};
+        return GROOT_OK;
+    };
     lap("LSH forest tables");
     {   // per kmerCount: (K, L) of the partitions (all have Upper = NumWindowKmers) and min #equal slots
         std::vector<uint8_t> qk(c->max_q + 1, 0), ql(c->max_q + 1, 0);
@@ -2098,7 +2128,13 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));
     HIP_TRY(c, hipDeviceSynchronize());
     lap("work buffers");
+    // WindowSize-mers on the every-slot-equal branch of Query never touch the LSH-Forest tables: the signature index and the memo
+    // (both run window-sized strings through the kernels) are built while the band tables are still being sorted
+    const uint32_t q_w = v->window_size >= v->kmer_size ? v->window_size - v->kmer_size + 1 : 0;
+    const bool w_exact = q_w && q_w < c->h_q_min_eq.size() && c->h_q_min_eq[q_w] == s;
+    if (!w_exact) { if (int rc = finish_lsh()) return rc; lap("LSH forest tables (waited for)"); }
     if (int rc = build_signature_index(c, v, sketch_class)) return rc;
+    if (int rc = finish_lsh()) return rc;
     lap("signature index");
     return GROOT_OK;
 }

@@ -979,6 +979,25 @@ __host__ __device__ __forceinline__ uint64_t text_hash_step(uint64_t h, uint32_t
     return h ^ (h >> 29);
 }
 #define GROOT_TEXT_HASH_INIT 0xD6E8FEB86659FD93ULL
+// fills the text table at open: string j (tw dwords, 2 bits per base) with a non-zero sig_info word claims the first free slot of its
+// probe sequence (compare-and-swap on the entry's info word) and writes tag and bases; hashed over twk dwords, as the lookup does
+__global__ __launch_bounds__(kBlock) void text_table_fill_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ info, uint32_t n, uint32_t tw,
+                                                                 uint32_t twk, uint32_t *tab, uint32_t mask)
+{
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n || !info[j]) return;
+    const uint32_t *wd = words + (size_t)j * tw;
+    uint64_t h = GROOT_TEXT_HASH_INIT;
+    for (uint32_t x = 0; x < twk; x++) h = text_hash_step(h, x < tw ? wd[x] : 0u);
+    for (uint32_t slot = (uint32_t)h & mask;; slot = (slot + 1) & mask) {
+        uint32_t *e = tab + (size_t)slot * 16;
+        if (atomicCAS(e + 1, 0u, info[j]) != 0u) continue;
+        e[0] = (uint32_t)(h >> 32);
+        for (uint32_t x = 0; x < tw; x++) e[2 + x] = wd[x];
+        return;
+    }
+}
+
 template <int TW>
 __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
 {
