@@ -107,7 +107,6 @@ constexpr uint32_t kOutTab = 0x80000000u;                  // sig_info: the stri
 constexpr uint32_t kOutMaxTrav = 4095, kOutIdxBits = 25, kOutTravShift = 27, kOutTravLong = 15;
 constexpr uint32_t kOutNoRec = 1u << 25;                   // sig_info: the string has seed windows (or none) but AlignRead reports nothing for it: one entry, no record
 constexpr uint32_t kOutAllSeeds = 1u << 26;                // sig_info: ... and IncrementSubPath is called exactly once for each of the read's seed windows
-constexpr uint32_t kTodo = 0xFFFFFFFEu;                    // SeedArgs::tab_idx: text_lookup_kernel leaves the read to the full-width kernel
 constexpr uint32_t kTabSeedsHere = 0x40000000u;            // SeedArgs::tab_idx: text_lookup_kernel answered the read; order_first_kernel writes its seeds too
 constexpr uint32_t kTabCounted = 0x80000000u;              // SeedArgs::tab_idx: the seed stage has counted the read's IncrementSubPath calls
 // (entries are padded to a power of two of at least 64 bytes: a gather touches one 64-byte sector, never two)
@@ -213,6 +212,7 @@ struct SeedArgs {
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
     uint32_t *tab_idx;           // [n_reads] first OutEntry (| kTabCounted) of reads whose outcome is tabulated, kEmpty for the others; or null: no table
     uint32_t *tab_hist;          // [n_windows] IncrementSubPath calls of tabulated reads counted by the seed stage in this batch; or null
+    uint32_t *dfs_list, *dfs_count;   // reads with a scheduling key, appended by the seed epilogue (processing order of the align stage when few are left); or null
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM

@@ -147,6 +147,7 @@ struct groot_ctx {
     DevBuf<uint8_t> win_text, win_nodes;
     DevBuf<uint32_t> sig_info;             // per window-text string: verdict byte, or where its tabulated outcome is (DeviceIndex::sig_info)
     DevBuf<uint4> out_tab;                 // AlignRead outcomes of the window-text strings (DeviceIndex::out_tab)
+    std::vector<uint32_t> h_out_tab;       // the host's copy (groot_hip_read_seeds: seed windows of reads the text lookup answered)
     uint64_t out_strings = 0, out_tabulated = 0, out_entries = 0;   // strings that confirm reads / of them tabulated / table entries
     double out_build_ms = 0, open_ms = 0;
     uint32_t incr_cap = kIncrCap;
@@ -593,10 +594,6 @@ static int grow_attempts(groot_ctx *c, uint32_t rows)
     return GROOT_OK;
 }
 
-struct IsTodo {     // reads text_lookup_kernel left to the full-width kernel
-    const uint32_t *tab_idx;
-    __host__ __device__ bool operator()(uint32_t r) const { return tab_idx[r] == kTodo; }
-};
 struct HasKey {     // reads the seed stage left for the align stage's graph walk carry a scheduling key
     const uint32_t *key;
     __host__ __device__ bool operator()(uint32_t r) const { return key[r] != kEmpty; }
@@ -647,6 +644,8 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     // Which kernel sees the batch first?  When the outcome table answered most of the latest batch, the text lookup (no hashing at
     // all; what it does not find goes through the full-width kernel, read by read); else the signature kernel as before.
     // (the share is only known exactly while the lookup runs: every eighth batch tries it again)
+    static const double list_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
+    const bool list_mode = c->dfs_frac < list_below;       // few reads need the graph walk (the latest batch says so)
     const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= 8;
     s->text_used = !c->prm.keep_sketches && c->dix.text_tab && c->dix.out_tab && text_try && s->max_len >= c->dix.w && !c->tab_capture;
     if (s->text_used) c->batches_without_text = 0;
@@ -657,21 +656,15 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;
         a.list_stride_dw = (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
         const size_t lds = kTextBad + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
+        HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
+        if (list_mode) {       // the reads left for the graph walk are a subset of the lookup's misses: the list pass appends them itself
+            a.dfs_list = c->perm.p; a.dfs_count = c->perm_count.p;
+            HIP_TRY(c, hipMemsetAsync(c->perm_count.p, 0, sizeof(uint32_t), c->stream));
+        }
         if (c->dix.w <= 128) hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a);
         else hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a);
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
-        {   // the reads it marked, as a list
-            size_t tb = 0;
-            IsTodo pred{c->tab_idx.p};
-            rocprim::counting_iterator<uint32_t> ids(0u);
-            HIP_TRY(c, rocprim::select(nullptr, tb, ids, c->todo_list.p, c->todo_count.p, (size_t)s->n_reads, pred, c->stream));
-            if (tb > c->sort_tmp.n) {
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                HIP_TRY(c, c->sort_tmp.alloc(tb + tb / 4));
-            }
-            HIP_TRY(c, rocprim::select(c->sort_tmp.p, tb, ids, c->todo_list.p, c->todo_count.p, (size_t)s->n_reads, pred, c->stream));
-        }
         launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
     } else if (s->sig_used) {
         // signature kernel first; what it cannot decide goes through the full-width kernel, read by read
@@ -696,8 +689,8 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
                            c->attempts_ptr, c->q_row.p, c->dix.w - c->k + 1, c->n_windows, s->d_ctr.p, update_weights ? 1u : 0u);
         HIP_TRY(c, hipGetLastError());
     }
-    static const double list_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
-    if (c->dfs_frac < list_below) {
+    if (list_mode && a.dfs_list) return GROOT_OK;           // (the processing order was written by the seed stage)
+    if (list_mode) {
         // Few reads need the graph walk (the latest batch says so; most are answered from the outcome table or have no seeds): sorting
         // ten million keys to order a few of them costs more than their order saves.  The processing order is then simply the reads
         // with a key, ascending -- one stream compaction (0.05 instead of 0.45 ms per 10 M reads).  Processing order only.
@@ -1614,6 +1607,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     tab.resize(tab.size() + 16, 0);
     HIP_TRY(c, c->out_tab.alloc(c->out_entries * sq + 4));
     HIP_TRY(c, hipMemcpy(c->out_tab.p, tab.data(), (c->out_entries * sq + 4) * sizeof(uint4), hipMemcpyHostToDevice));
+    c->h_out_tab = std::move(tab);
     HIP_TRY(c, hipMemcpy(c->sig_info.p, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, c->tab_idx.alloc(c->prm.max_batch_reads));
     HIP_TRY(c, c->tab_hist.alloc(c->n_windows));
@@ -2485,12 +2479,27 @@ int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *
         HIP_TRY(c, hipMemcpy(cnt.data(), c->seed_count.p, (size_t)R * 4, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(win.data(), c->seed_win.p, (size_t)c->seed_slots * R * 4, hipMemcpyDeviceToHost));   // [slot][R], R = this batch
     }
+    // reads the text lookup answered have their seed windows in the outcome table, not in the seed slots
+    std::vector<uint32_t> tidx;
+    if (R && c->dix.out_tab && !c->h_out_tab.empty()) {
+        tidx.resize(R);
+        HIP_TRY(c, hipMemcpy(tidx.data(), c->tab_idx.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+    }
+    const size_t ed = (size_t)c->dix.out_stride_q * 4;       // dwords per entry
     uint64_t total = 0;
     std::vector<uint32_t> tmp;
     for (uint32_t r = 0; r < R; r++) {
-        const uint32_t m = std::min(cnt[r] & 0x7FFFFFFFu, c->seed_slots);
         tmp.clear();
-        for (uint32_t j = 0; j < m; j++) tmp.push_back(win[(size_t)j * R + r]);
+        if (!tidx.empty() && tidx[r] != kEmpty && (tidx[r] & kTabSeedsHere)) {
+            const uint32_t *e0 = &c->h_out_tab[(size_t)(tidx[r] & ((1u << kOutIdxBits) - 1u)) * ed];
+            const uint32_t n_ent = std::max(e0[3] >> 16, 1u) + (e0[2] >> 20);
+            for (uint32_t e = 0; e < n_ent; e++)
+                for (uint32_t x = 0; x < kOutSeedDw; x++)
+                    if (e0[e * ed + ed - kOutSeedDw + x] != kEmpty) tmp.push_back(e0[e * ed + ed - kOutSeedDw + x]);
+        } else {
+            const uint32_t m = std::min(cnt[r] & 0x7FFFFFFFu, c->seed_slots);
+            for (uint32_t j = 0; j < m; j++) tmp.push_back(win[(size_t)j * R + r]);
+        }
         std::sort(tmp.begin(), tmp.end());
         for (uint32_t w : tmp) {
             if (out && total < cap) out[total] = groot_seed{s->first_read_id + r, w};

@@ -272,6 +272,15 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
             }
         }
         a.sort_key[r] = key;
+        if (a.dfs_list && key != kEmpty) {                    // (few reads are left for the walk: their list is made right here)
+            const uint64_t active = __ballot(1);
+            const unsigned lane = __lane_id();
+            const int leader = __ffsll((unsigned long long)active) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(a.dfs_count, (uint32_t)__popcll(active));
+            base = __shfl(base, leader);
+            a.dfs_list[base + __popcll(active & ((1ULL << lane) - 1ULL))] = r;
+        }
     }
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
@@ -1031,9 +1040,12 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     }
     __syncthreads();
     const uint32_t r = r0 + tid;
-    if (r >= a.n_reads) return;
+    const bool valid = r < a.n_reads;
+    uint32_t info = 0;
+    uint32_t len = 0;
+    if (valid) {
     const uint64_t o0 = a.seq_off[r];
-    const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
+    len = (uint32_t)(a.seq_off[r + 1] - o0);
     bool mine = in_lds && len == ix.w;
     if (mine) {
         // groups of 4 bases the read touches (a neighbour's byte in a shared group can send the read to the list: conservative)
@@ -1045,8 +1057,7 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
             if (bits) mine = false;
         }
     }
-    // (no list atomics here: one counter for all wavefronts would cost more than this kernel; a stream compaction of the marks follows)
-    if (!mine) { a.tab_idx[r] = kTodo; return; }
+    if (mine) {
     const uint32_t P = 2u * (uint32_t)(o0 - base16);       // bit position of base 0 in `codes`
     const uint32_t n_full = len >> 4, tail_mask = (1u << (2 * (len & 15))) - 1u;
     uint32_t rdw[TW];
@@ -1059,7 +1070,6 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     }
     const uint32_t tag = (uint32_t)(h >> 32);
     const uint4 *tab = ix.text_tab;
-    uint32_t info = 0;
     for (uint32_t slot = (uint32_t)h & ix.text_mask;; slot = (slot + 1) & ix.text_mask) {
         const uint4 *e = tab + (size_t)slot * 4;
         constexpr int NQ = (2 + TW + 3) / 4;               // 16-byte words of an entry that hold something
@@ -1079,8 +1089,25 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
         for (int j = 0; j < TW; j++) diff |= ed[2 + j] ^ rdw[j];
         if (!diff) { info = ed[1]; break; }
     }
-    if (!info) { a.tab_idx[r] = kTodo; return; }
-    // the read's whole outcome is tabulated; order_first_kernel writes its seeds, its records and its call counts from the table
+    }
+    }
+    // ---- the reads this kernel leaves to the full-width kernel, as a list: counted per workgroup (ballots, one LDS atomic per
+    // wavefront), ONE global atomic per workgroup that has any.  (One per wavefront on a single counter cost 1.1 ms per 10 M reads
+    // when every wavefront had a miss; a separate stream compaction of per-read marks 0.1 ms.)
+    __shared__ uint32_t blk_cnt, blk_base;
+    if (tid == 0) blk_cnt = 0;
+    __syncthreads();
+    const bool miss = valid && !info;
+    const unsigned long long mb = __ballot(miss);
+    uint32_t wave_base = 0;
+    if ((tid & 63) == 0 && mb) wave_base = atomicAdd(&blk_cnt, (uint32_t)__popcll(mb));
+    wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base);
+    __syncthreads();
+    if (tid == 0 && blk_cnt) blk_base = atomicAdd(a.todo_count, blk_cnt);
+    __syncthreads();
+    if (miss) a.todo_list[blk_base + wave_base + (uint32_t)__popcll(mb & ((1ULL << (tid & 63)) - 1ULL))] = r;
+    if (!valid || !info) return;
+    // the read's whole outcome is tabulated; order_first_kernel writes its records and its call counts from the table
     const uint32_t q = len - ix.k + 1;
     if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;
     a.sort_key[r] = kEmpty;
@@ -2004,12 +2031,8 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
                 if (x.x != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.x], 1u);
                 if (x.y != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.y], 1u);
             }
-            if (seeds_here) {
-                if (sd.x != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.x; ns++; }
-                if (sd.y != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.y; ns++; }
-                if (sd.z != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.z; ns++; }
-                if (sd.w != kEmpty) { if (ns < t.seed_slots) t.seed_win[(size_t)ns * n + r] = sd.w; ns++; }
-            }
+            if (seeds_here)                                // (groot_hip_read_seeds takes the windows themselves from the host's copy of the table)
+                ns += (sd.x != kEmpty) + (sd.y != kEmpty) + (sd.z != kEmpty) + (sd.w != kEmpty);
             if (j == 0) { mapped += (h.w >> 9) & 1u; multimapped += (h.w >> 8) & 1u; }
             if (j < nt) {                                  // one sam.Record per path of the traversal (alignment.go:114-156)
                 alns += __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
@@ -2032,7 +2055,7 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
                 for (uint32_t w = 3; w < pw_out; w++) mo[w] = (uint64_t)ew[2 * w] | ((uint64_t)ew[2 * w + 1] << 32);
             }
         }
-        if (seeds_here) { t.seed_count[r] = ns; seeds += ns; }
+        if (seeds_here) seeds += ns;
     } else if (ti == kEmpty && cnt[r] != 0) {
         const uint32_t i = off[r];
         if (i >= cap) atomicOr(&ctr->flags, kFlagTravOverflow);
