@@ -745,7 +745,11 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.ovf_cap = c->ovf_cap;
     a.stk_hdr = c->stk_hdr.p;
     a.stk_mask = c->stk_mask.p;
-    const uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
+    uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
+    // (few reads left for the walk -- the latest batch says so: half the persistent grid starts and drains 0.05 ms sooner and the
+    // slowest read, not the number of wavefronts, sets the duration anyway)
+    static const double sparse_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
+    if (c->dfs_frac < sparse_below && !getenv("GROOT_ALIGN_GRID_PER_CU")) blocks = std::max(1u, blocks / 2);
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB

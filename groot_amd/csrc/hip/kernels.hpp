@@ -360,8 +360,11 @@ __device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint3
 // cmd/index.go:45-49): the minima then live in an array indexed at run time (private memory), which is correct and slow;
 // the sizes people use have compiled instances.
 constexpr int kGenericMaxS = 256;      // largest sketch the run-time-sized instance handles
+// (the S running minima are 2 S registers: at GROOT_SEED_WAVES waves per SIMD (~100 VGPRs) sketch sizes above 30 spilled them --
+// 20 ms per 2 M reads at S = 64.  Larger sketches get fewer, larger waves: 3 per SIMD up to S = 48, 2 beyond)
+constexpr int seed_waves(int S) { return S == 0 ? 1 : (S <= 30 ? GROOT_SEED_WAVES : (S <= 48 ? 3 : 2)); }
 template <int S, int MAXK, bool DUMP, int M5, bool LIST = false>
-__global__ __launch_bounds__(kBlock, S ? GROOT_SEED_WAVES : 1) void sketch_seed_kernel(SeedArgs a)
+__global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(SeedArgs a)
 {
     constexpr int SM = S ? S : kGenericMaxS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

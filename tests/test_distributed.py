@@ -14,6 +14,23 @@ import torch.multiprocessing as mp
 from conftest import REPO
 
 
+COUNT_KEYS = ("received", "mapped", "multimapped", "alignments", "seeds")
+
+
+def shard_range(n_reads, rank, world):
+    """contiguous, balanced [lo, hi) of reads for `rank` (what bench.py and the CLI do with batches)"""
+    base, rem = divmod(n_reads, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_counts(dist, counts):
+    """sum the boss counters (boss.go:24-27) over ranks"""
+    t = torch.tensor([int(counts[k]) for k in COUNT_KEYS], dtype=torch.int64)
+    dist.all_reduce(t)
+    return {k: int(v) for k, v in zip(COUNT_KEYS, t.tolist())}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -27,12 +44,12 @@ def _worker(rank, world, port, msa_files, n_reads, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from groot_amd import host, multi, synth
+    from groot_amd import host, synth
     from oracle import oracle_py as O
 
     index = host.Index.from_msa_files(msa_files)          # replicated index
     cat, off, lens = synth.reference_sequences(index)
-    lo, hi = multi.shard_range(n_reads, rank, world)
+    lo, hi = shard_range(n_reads, rank, world)
     seq, so, _ = synth.reads_np(cat, off, lens, hi - lo, 100, first=lo)
     run = O.Run(index)
     run.batch(seq, so, first_read_id=lo)
@@ -41,11 +58,11 @@ def _worker(rank, world, port, msa_files, n_reads, out_dir):
     full = np.zeros((n_q, index.view.n_windows), dtype=np.int64)
     full[: att.shape[0]] = att
     t = torch.from_numpy(full)
-    multi.reduce_attempts(dist, t)
-    counts = multi.reduce_counts(dist, run.counts())
+    dist.all_reduce(t)                                    # the one exchange: the call-count table
+    counts = reduce_counts(dist, run.counts())
     if rank == 0:
         np.save(os.path.join(out_dir, "att.npy"), t.numpy())
-        np.save(os.path.join(out_dir, "counts.npy"), np.array([counts[k] for k in multi.COUNT_KEYS]))
+        np.save(os.path.join(out_dir, "counts.npy"), np.array([counts[k] for k in COUNT_KEYS]))
     al = run.alns()
     np.save(os.path.join(out_dir, f"alns{rank}.npy"), al)
     dist.barrier()
@@ -53,10 +70,8 @@ def _worker(rank, world, port, msa_files, n_reads, out_dir):
 
 
 def test_shard_range_covers_everything():
-    from groot_amd import multi
-
     for n, w in [(10, 3), (7, 8), (0, 2), (100, 4)]:
-        spans = [multi.shard_range(n, r, w) for r in range(w)]
+        spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
@@ -64,7 +79,7 @@ def test_shard_range_covers_everything():
 
 @pytest.mark.timeout(300)
 def test_two_ranks_equal_one(msa_dir, tmp_path):
-    from groot_amd import device, host, multi, synth
+    from groot_amd import device, host, synth
     from oracle import oracle_py as O
 
     files = host.msa_files(msa_dir)[:24]
@@ -80,7 +95,7 @@ def test_two_ranks_equal_one(msa_dir, tmp_path):
     assert np.array_equal(got[: att.shape[0]], att) and not got[att.shape[0]:].any()
     counts = np.load(os.path.join(tmp_path, "counts.npy"))
     c1 = run.counts()
-    assert counts.tolist() == [c1[k] for k in multi.COUNT_KEYS]
+    assert counts.tolist() == [c1[k] for k in COUNT_KEYS]
     # weights from the reduced table = single-process canonical weights (independent of the GPU count)
     kf, kt = device.weights(index, got.astype(np.uint32))
     kf1, kt1 = run.weights(order=1)
