@@ -250,6 +250,7 @@ struct AlignArgs {
     // ([n_reads][kIncrCap], count in incr_cnt[r] bits 0..30, bit 31 = the read touched more than one graph); null otherwise
     uint32_t *incr_cnt, *incr_win;
     uint32_t incr_cap;           // slots per read in incr_win
+    uint32_t head_lanes;         // lanes per round in the head of the processing order (the longest walks); 0 = as everywhere else
     uint32_t round_lanes;        // lanes a wavefront fills per round; 0 = 64, fewer when the batch leaves the align stage little to do (see the kernel)
     uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;

@@ -763,6 +763,8 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
     }
     if (const char *e = getenv("GROOT_ROUND_LANES")) a.round_lanes = (uint32_t)std::max(1, std::min(64, atoi(e)));   // experiments
+    a.head_lanes = s->mixed_len ? 8u : 0u;
+    if (const char *e = getenv("GROOT_HEAD_LANES")) a.head_lanes = (uint32_t)std::max(0, std::min(64, atoi(e)));   // experiments
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors

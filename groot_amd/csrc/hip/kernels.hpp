@@ -1352,25 +1352,38 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
     // (odd on purpose: with an even count the two-round chunks behind the head start at multiples of 128 slots and the kernel is
     // 6 % slower -- measured both ways, cause not established)
     const uint32_t head_rounds = GROOT_SMALL_CHUNK_SHARE(n_rounds) | 1u;
-    uint32_t chunk_len = 0;                                // slots in the current chunk (wave-uniform)
-    bool head_done = head_rounds == 0;                     // wave-uniform
-    auto take_chunk = [&]() -> uint32_t {
-        uint32_t c = 0;
+    // The head of the order holds the longest walks.  When the reads of a batch do not march in step (a.head_lanes != 0: mixed
+    // read lengths) a round of 64 of them lasts as long as their steps laid end to end -- one such round was a quarter of the
+    // launch --, so the head is handed out in rounds of a.head_lanes reads; the tail keeps full rounds.
+    const uint32_t Uh = a.head_lanes ? min(a.head_lanes, U) : U;
+    const uint32_t head_slots = min(head_rounds * U, n_todo);
+    const uint32_t head_small = (head_slots + Uh - 1u) / Uh;
+    uint32_t chunk_len = 0, chunk_base = 0;                // slots in the current chunk, its first slot (wave-uniform)
+    bool head_done = head_small == 0;                      // wave-uniform
+    auto take_chunk = [&]() {
+        uint32_t c = 0, tail = 0;
         if ((threadIdx.x & 63) == 0) {
-            uint32_t u = 1;
             if (!head_done) c = atomicAdd(a.ovf_cnt + kOvfShards, 1u);
-            if (head_done || c >= head_rounds) {
-                u = kWaveChunk / 64u;
-                c = head_rounds + atomicAdd(a.ovf_cnt + kOvfShards + 1, u);
+            if (head_done || c >= head_small) {
+                tail = 1;
+                c = atomicAdd(a.ovf_cnt + kOvfShards + 1, kWaveChunk / 64u);
             }
-            c |= u << 28;
         }
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-        chunk_len = (c >> 28) * U;
-        if (chunk_len > U) head_done = true;
-        return c & 0x0FFFFFFFu;
+        tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail);
+        if (tail) {
+            head_done = true;
+            // (saturating: past the end the base only has to be >= n_todo)
+            const unsigned long long b = (unsigned long long)head_slots + (unsigned long long)c * U;
+            chunk_base = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
+            chunk_len = (kWaveChunk / 64u) * U;
+        } else {
+            chunk_base = c * Uh;
+            chunk_len = min(Uh, head_slots - chunk_base);
+        }
     };
-    uint32_t chunk_j = take_chunk(), chunk_pos = 0;        // wave-uniform cursor: first round of the chunk, slots used
+    take_chunk();
+    uint32_t chunk_pos = 0;                                // slots of the chunk already handed out (wave-uniform)
     uint32_t slot = 0, r = 0;
     // ---- read ----
     bool have_read = false;
@@ -1516,7 +1529,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             // orientation class), so lanes that start together do near-identical work and share phases.
             const unsigned long long bw = __ballot(phase == PH_WAIT);
             const int cw = __popcll(bw);
-            if (cw >= (int)((64u - U) + a.refill * U / 64u) || (cw && !(bf | bs | bd))) {
+            const uint32_t Uc = max(1u, min(chunk_len, min(U, 64u)));   // lanes a round of the current chunk fills
+            if (cw >= (int)((64u - Uc) + max(1u, a.refill * Uc / 64u)) || (cw && !(bf | bs | bd))) {
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
                 if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
@@ -1524,7 +1538,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
 #elif defined(GROOT_WORK_COUNTERS)
                 wc_round0 = wc_iter;
 #endif
-                const uint64_t base = (uint64_t)chunk_j * U;
+                const uint64_t base = chunk_base;
                 if (base >= n_todo) {                          // this wave's share is used up
                     if (phase == PH_WAIT) phase = PH_DONE;
                 } else {
@@ -1538,7 +1552,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                         }
                     }
                     chunk_pos += min((uint32_t)cw, room);
-                    if (chunk_pos >= chunk_len) { chunk_pos = 0; chunk_j = take_chunk(); }
+                    if (chunk_pos >= chunk_len) { chunk_pos = 0; take_chunk(); }
                 }
                 continue;
             }
