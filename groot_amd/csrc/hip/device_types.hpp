@@ -212,6 +212,10 @@ struct SeedArgs {
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
     uint32_t *tab_idx;           // [n_reads] first OutEntry (| kTabCounted) of reads whose outcome is tabulated, kEmpty for the others; or null: no table
     uint32_t *tab_hist;          // [n_windows] IncrementSubPath calls of tabulated reads counted by the seed stage in this batch; or null
+    // reads on the LSH-Forest branch of Query, handed by the hashing kernels to lsh_query_kernel: read | byte > 'T' << 31, and their
+    // sketches ([position in the list][s] u64); null: every lane walks its own rows
+    uint32_t *lsh_list, *lsh_count;
+    uint64_t *lsh_sketch;
     uint32_t *dfs_list, *dfs_count;   // reads with a scheduling key, appended by the seed epilogue (processing order of the align stage when few are left); or null
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]

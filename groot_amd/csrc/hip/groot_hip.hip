@@ -180,6 +180,8 @@ struct groot_ctx {
     uint32_t seed_slots = 0;
     DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, perm_count, todo_list, todo_count;
     DevBuf<unsigned long long> seed_shards;
+    DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch + their sketches, for lsh_query_kernel (absent: per-lane row walks)
+    DevBuf<uint64_t> lsh_sketch;
     DevBuf<char> sort_tmp;
     DevBuf<ReadRec> read_rec;
     DevBuf<uint64_t> sketches;
@@ -649,6 +651,10 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= 8;
     s->text_used = !c->prm.keep_sketches && c->dix.text_tab && c->dix.out_tab && text_try && s->max_len >= c->dix.w && !c->tab_capture;
     if (s->text_used) c->batches_without_text = 0;
+    if (c->lsh_list.p && !c->prm.keep_sketches) {
+        a.lsh_list = c->lsh_list.p; a.lsh_count = c->lsh_count.p; a.lsh_sketch = c->lsh_sketch.p;
+        HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, sizeof(uint32_t), c->stream));
+    }
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[7], c->stream));
     if (s->text_used) {
         a.todo_list = c->todo_list.p;
@@ -678,6 +684,10 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     } else {
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
+    }
+    if (a.lsh_list) {       // the reads the hashing kernels found on the LSH-Forest branch: their queries, a wavefront per 64 of them
+        const size_t lds = (size_t)(kBlock / 64) * lsh_wave_lds_dw(c->l_max) * sizeof(uint32_t);
+        hipLaunchKernelGGL(lsh_query_kernel, dim3(std::min<uint32_t>(grid.x, 1024u)), dim3(kBlock), lds, c->stream, a);
     }
     HIP_TRY(c, hipGetLastError());
     if (c->profiling && !s->text_used) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));   // (signature kernel + its list pass / the full-width kernel)
@@ -2122,6 +2132,15 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
     HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
+    // lsh_query_kernel (the rows of a wavefront's reads dealt over its lanes) is parity-green and SLOWER than the per-lane walk on
+    // every workload measured (2.46 vs ~0.8 ms for 720 000 mixed-length reads at t = 0.95: the rows of a lane are consecutive 32-byte
+    // records, four to a cache line, which a lane walks at ~0.3 us per row; a dealt row costs a bisection, a cold line and LDS
+    // traffic, ~3 us per step of 64).  Opt-in for experiments: GROOT_LSH_KERNEL=1.
+    if (c->l_max <= kLshMaxBands && getenv("GROOT_LSH_KERNEL")) {
+        HIP_TRY(c, c->lsh_list.alloc(R));
+        HIP_TRY(c, c->lsh_count.alloc(1));
+        HIP_TRY(c, c->lsh_sketch.alloc((size_t)R * s));
+    }
     HIP_TRY(c, c->todo_list.alloc(R));
     HIP_TRY(c, c->todo_count.alloc(1));
     HIP_TRY(c, c->seed_shards.alloc((size_t)kSeedShards * kSeedShardStride));

@@ -536,6 +536,22 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             for (int i = 0; i < s_; i++) same &= ws[i] == m[i];
             if (same) hit(e.id);
         }
+    } else if (min_eq < (uint32_t)s_ && a.lsh_list) {
+        // General LSH Forest query, deferred: the sketch goes to lsh_query_kernel, which deals the rows of equal band prefix of a
+        // wavefront's 64 reads over its lanes (here every lane would walk its own rows -- a few to a few hundred -- while the
+        // others wait: 8 % of the lane slots doing work)
+        const uint64_t active = __ballot(1);
+        const unsigned lane = __lane_id();
+        const int leader = __ffsll((unsigned long long)active) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(a.lsh_count, (uint32_t)__popcll(active));
+        base = __shfl(base, leader);
+        const uint32_t pos = base + __popcll(active & ((1ULL << lane) - 1ULL));
+        a.lsh_list[pos] = r | (high ? 0x80000000u : 0u);
+        uint64_t *sk = a.lsh_sketch + (size_t)pos * s_;
+#pragma unroll
+        for (int i = 0; i < s_; i++) sk[i] = m[i];
+        return;
     } else if (min_eq < (uint32_t)s_) {
         // General LSH Forest query: bands b < L, prefix of K hash values (low 32 bits) per band;
         // a window found through band b is skipped if an earlier band already returned it.
@@ -991,6 +1007,183 @@ __host__ __device__ __forceinline__ uint64_t text_hash_step(uint64_t h, uint32_t
     return h ^ (h >> 29);
 }
 #define GROOT_TEXT_HASH_INIT 0xD6E8FEB86659FD93ULL
+// ---------------------------------------------------------------------------------------------
+// K2, LSH-Forest branch, wave-cooperative: lsh_query_kernel
+// ---------------------------------------------------------------------------------------------
+// ContainmentIndex.Query for reads whose Containment > t needs fewer than all slots equal (lshe.go:153-175: lshensemble's forest
+// query with K hash values per band over L bands, then the exact containment test).  A read's candidate rows -- the rows of equal
+// K-prefix in each of its L sorted band tables -- number a few to a few hundred; walked per lane, a wavefront loops until its
+// slowest lane is through.  Here the hashing kernel hands over the sketches (SeedArgs::lsh_list / lsh_sketch) and a wavefront
+// takes 64 of them at a time:
+//   A  per lane: the first row and the run length of its prefix in every band (hash table over the prefixes), its signature bytes
+//   B  prefix sum of the run lengths over the lanes: T rows in all
+//   C  the T rows dealt over the lanes, 64 per step (owner by bisection of the prefix sums in LDS): the 32-byte row signature
+//      against the OWNER's signature bytes (LDS) -- ballot + popcount append the survivors to a queue in LDS
+//   D  every lane verifies its own survivors against its 64-bit sketch (exact #equal slots, not returned by an earlier band) and
+//      writes its seed windows; then the epilogue every seed kernel ends with.
+// Same rows, same tests, same order of hits per read as the per-lane branch of sketch_seed_kernel.
+constexpr uint32_t kLshQueue = 512;            // survivors a wavefront collects before its lanes verify them
+constexpr uint32_t kLshMaxBands = 16;          // bands per read this kernel handles (sketch size / maxK; `groot index` default: 5)
+__host__ __device__ inline uint32_t lsh_wave_lds_dw(uint32_t lb) { return 64 * 8 + 65 + 64 + 64 * lb + 64 * (lb + 1) + 64 + 64 + 2 * kLshQueue; }
+__global__ __launch_bounds__(kBlock) void lsh_query_kernel(SeedArgs a)
+{
+    extern __shared__ uint32_t lsh_lds[];
+    const DeviceIndex &ix = a.ix;
+    const uint32_t S = ix.s, maxk = ix.max_k, LB = ix.l_max, n = ix.n_windows;
+    const uint32_t sl = S < 32 ? S : 32, nd = (sl + 3) >> 2;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *W = lsh_lds + (size_t)wave * lsh_wave_lds_dw(LB);
+    uint32_t *rs = W;                          // [64][8] signature bytes of the lanes' sketches
+    uint32_t *lbase = rs + 64 * 8;             // [65] exclusive prefix of the lanes' row counts
+    uint32_t *lmin = lbase + 65;               // [64] min #equal slots per lane
+    uint32_t *blo = lmin + 64;                 // [64][LB] first row per band
+    uint32_t *bcum = blo + 64 * LB;            // [64][LB + 1] rows before band b
+    uint32_t *qcnt = bcum + 64 * (LB + 1);     // [64] survivors per owner in the queue
+    uint32_t *qfirst = qcnt + 64;              // [64] first of them
+    uint32_t *queue = qfirst + 64;             // [kLshQueue][2]: owner | band << 8, window
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const uint32_t n_list = *a.lsh_count;
+    for (uint32_t base = (blockIdx.x * (kBlock / 64) + wave) * 64; base < n_list; base += gridDim.x * kBlock) {
+        const uint32_t li = base + lane;
+        const bool valid = li < n_list;
+        // ---- A ----
+        uint32_t r = 0, high = 0, len = 0, q = 0, K = 0, L = 0, min_eq = S + 1, rows = 0;
+        uint64_t o0 = 0;
+        const uint64_t *sk = a.lsh_sketch + (size_t)(valid ? li : 0) * S;
+        for (uint32_t i = 0; i < 8; i++) rs[lane * 8 + i] = 0;
+        if (valid) {
+            const uint32_t e = a.lsh_list[li];
+            r = e & 0x7FFFFFFFu; high = e >> 31;
+            o0 = a.seq_off[r];
+            len = (uint32_t)(a.seq_off[r + 1] - o0);
+            q = len - ix.k + 1;
+            K = ix.q_k[q]; L = min((uint32_t)ix.q_l[q], LB); min_eq = ix.q_min_eq[q];
+#pragma unroll
+            for (uint32_t wd = 0; wd < 8; wd++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++)
+                    if (4 * wd + i < sl) v |= sig8(sk[4 * wd + i]) << (8 * i);
+                rs[lane * 8 + wd] = v;
+            }
+        }
+        lmin[lane] = min_eq;
+        for (uint32_t b = 0; b < LB; b++) {
+            uint32_t lo = n, run = 0;
+            if (valid && b < L && K >= 1) {
+                const uint32_t *keys = ix.band_keys + (size_t)b * n * maxk;
+                uint64_t hk = GROOT_SKETCH_HASH_INIT;
+                for (uint32_t j = 0; j < K; j++) hk = sketch_hash_step(hk, (uint32_t)sk[b * maxk + j]);
+                const ExactEntry *tab = ix.band_hash + (((size_t)b * maxk + (K - 1)) << ix.band_hash_bits);
+                const uint32_t hmask = (1u << ix.band_hash_bits) - 1u, tag = (uint32_t)(hk >> 32);
+                for (uint32_t slot = (uint32_t)hk & hmask;; slot = (slot + 1) & hmask) {
+                    const ExactEntry e = tab[slot];
+                    if (e.id == kEmpty) break;
+                    if (e.tag != tag) continue;
+                    bool same = true;
+                    for (uint32_t j = 0; j < K; j++) same &= keys[(size_t)e.id * maxk + j] == (uint32_t)sk[b * maxk + j];
+                    if (same) { lo = e.id; break; }
+                }
+                if (lo < n) run = ix.band_run[((size_t)b * maxk + (K - 1)) * n + lo];
+            }
+            blo[lane * LB + b] = lo;
+            bcum[lane * (LB + 1) + b] = rows;
+            rows += run;
+        }
+        bcum[lane * (LB + 1) + LB] = rows;
+        // ---- B ----
+        uint32_t incl = rows;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += v;
+        }
+        lbase[lane] = incl - rows;
+        const uint32_t T = __shfl(incl, 63);
+        if (lane == 0) lbase[64] = T;
+        qcnt[lane] = 0; qfirst[lane] = kEmpty;
+        wave_sync();
+        // per-lane results
+        uint32_t n_hits = 0, min_win = kEmpty, max_win = 0, prev_id = 0;
+        uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;
+        bool asc = true;
+        auto hit = [&](uint32_t id) {
+            if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
+            if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
+            asc &= n_hits == 0 || id > prev_id;
+            prev_id = id;
+            n_hits++;
+            min_win = min(min_win, id);
+            max_win = max(max_win, id);
+        };
+        uint32_t qn = 0;                                    // survivors in the queue (wave-uniform)
+        auto verify = [&]() {                               // ---- D ----
+            wave_sync();
+            const uint32_t c = qcnt[lane], f = qfirst[lane];
+            for (uint32_t j = 0; j < c; j++) {
+                const uint32_t tagw = queue[2 * (f + j)], id = queue[2 * (f + j) + 1];
+                const uint32_t b = tagw >> 8;
+                const uint64_t *ws = ix.win_sketch + (size_t)id * S;
+                uint32_t eq = 0;
+                bool earlier = false;
+                for (uint32_t bb = 0; bb < LB; bb++) {
+                    bool pm = true;
+                    for (uint32_t j2 = 0; j2 < maxk; j2++) {
+                        const uint64_t wv = ws[bb * maxk + j2], mv = sk[bb * maxk + j2];
+                        eq += wv == mv;
+                        if (j2 < K) pm &= (uint32_t)wv == (uint32_t)mv;
+                    }
+                    if (bb < b && pm) earlier = true;
+                }
+                for (uint32_t i = LB * maxk; i < S; i++) eq += ws[i] == sk[i];
+                if (!earlier && eq >= min_eq) hit(id);
+            }
+            wave_sync();
+            qcnt[lane] = 0; qfirst[lane] = kEmpty;
+            qn = 0;
+            wave_sync();
+        };
+        // ---- C ----
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            bool pass = false;
+            uint32_t owner = 0, band = 0, id = 0;
+            if (t < T) {
+                uint32_t lo = 0, hi = 64;                   // last lane whose base <= t (bases of lanes without rows repeat: take the last)
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lbase[mid] <= t) lo = mid; else hi = mid; }
+                owner = lo;
+                const uint32_t local = t - lbase[owner];
+                const uint32_t *bc = bcum + owner * (LB + 1);
+                while (band + 1 < LB && bc[band + 1] <= local) band++;
+                const uint32_t e = blo[owner * LB + band] + (local - bc[band]);
+                const uint4 *sg = reinterpret_cast<const uint4 *>(ix.band_sig + ((size_t)band * n + e) * 32);
+                const uint4 sa = sg[0], sb = sg[1];
+                const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+                uint32_t same = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    if (i >= nd) break;
+                    const uint32_t x = ws8[i] ^ rs[owner * 8 + i];
+                    same += __popc((x - 0x01010101u) & ~x & 0x80808080u);
+                }
+                pass = same - (4u * nd - sl) + (S - sl) >= lmin[owner];
+                if (pass) id = ix.band_ids[(size_t)band * n + e];
+            }
+            const unsigned long long pm = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = qn + (uint32_t)__popcll(pm & ((1ULL << lane) - 1ULL));
+                queue[2 * pos] = owner | (band << 8);
+                queue[2 * pos + 1] = id;
+                atomicAdd(&qcnt[owner], 1u);
+                atomicMin(&qfirst[owner], pos);
+            }
+            qn += (uint32_t)__popcll(pm);
+            if (qn + 64 > kLshQueue) verify();
+        }
+        verify();
+        if (valid) seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0, false, 0, 0, nullptr, asc, max_win);
+    }
+}
+
 // fills the text table at open: string j (tw dwords, 2 bits per base) with a non-zero sig_info word claims the first free slot of its
 // probe sequence (compare-and-swap on the entry's info word) and writes tag and bases; hashed over twk dwords, as the lookup does
 __global__ __launch_bounds__(kBlock) void text_table_fill_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ info, uint32_t n, uint32_t tw,
@@ -1046,10 +1239,20 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     const bool valid = r < a.n_reads;
     uint32_t info = 0;
     uint32_t len = 0;
+    bool no_seeds = false;
     if (valid) {
     const uint64_t o0 = a.seq_off[r];
     len = (uint32_t)(a.seq_off[r + 1] - o0);
-    bool mine = in_lds && len == ix.w;
+    {
+        // more k-mers than Containment > t allows at any number of equal slots (reads well beyond the window size): the query cannot
+        // return a window whatever the sketch is -- answered here, as both hashing kernels do, instead of travelling through the list
+        const uint32_t q = len - ix.k + 1;
+        if (len >= ix.k && len <= a.max_read_len && ix.max_q && (q > ix.max_q || ix.q_min_eq[q] > ix.s)) {
+            seed_epilogue(a, r, o0, len, q, 0, kEmpty, kEmpty, kEmpty, kEmpty, kEmpty, false);
+            no_seeds = true;
+        }
+    }
+    bool mine = !no_seeds && in_lds && len == ix.w;
     if (mine) {
         // groups of 4 bases the read touches (a neighbour's byte in a shared group can send the read to the list: conservative)
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 2, c1 = (uint32_t)(o0 - base16 + len - 1) >> 2;
@@ -1100,7 +1303,7 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     __shared__ uint32_t blk_cnt, blk_base;
     if (tid == 0) blk_cnt = 0;
     __syncthreads();
-    const bool miss = valid && !info;
+    const bool miss = valid && !info && !no_seeds;
     const unsigned long long mb = __ballot(miss);
     uint32_t wave_base = 0;
     if ((tid & 63) == 0 && mb) wave_base = atomicAdd(&blk_cnt, (uint32_t)__popcll(mb));
@@ -1109,7 +1312,7 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
     if (tid == 0 && blk_cnt) blk_base = atomicAdd(a.todo_count, blk_cnt);
     __syncthreads();
     if (miss) a.todo_list[blk_base + wave_base + (uint32_t)__popcll(mb & ((1ULL << (tid & 63)) - 1ULL))] = r;
-    if (!valid || !info) return;
+    if (!valid || !info || no_seeds) return;
     // the read's whole outcome is tabulated; order_first_kernel writes its records and its call counts from the table
     const uint32_t q = len - ix.k + 1;
     if (a.q_seen && ix.q_row[q] == kEmpty) a.q_seen[q] = 1u;

@@ -583,3 +583,20 @@ def test_configs4_at_single_gpu_scale(resfinder_index, threshold):
     for f in ("graph_id", "path_id", "ref_id", "pos", "start_clip", "end_clip", "rc", "secondary"):
         assert np.array_equal(got[f], oal[f]), f
     al.close()
+
+
+@pytest.mark.parametrize("threshold", [0.97, 0.90])
+def test_wave_cooperative_lsh_query_kernel(resfinder_index, threshold, monkeypatch):
+    """lsh_query_kernel (opt-in, GROOT_LSH_KERNEL=1: the hashing kernels hand the sketches of reads on the LSH-Forest branch to a kernel
+    that deals the rows of equal band prefix of 64 reads over the lanes of a wavefront -- ballot + popcount on the signature filter,
+    owners verify their survivors) returns what the per-lane walk returns and what the oracle returns (lshe.go:153-175)"""
+    global KEEP_SKETCHES
+    KEEP_SKETCHES = False                                  # (with sketches kept the full-width kernel answers alone)
+    monkeypatch.setenv("GROOT_LSH_KERNEL", "1")
+    index = resfinder_index
+    cat, o, lens = synth.reference_sequences(index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 12000, 150, first=777, min_len=60)
+    al, counts, run = run_both(index, seq, off, threshold=threshold)
+    assert_same(al, counts, run, index)
+    assert counts["seeds"] > counts["mapped"] > 1000
+    al.close()
