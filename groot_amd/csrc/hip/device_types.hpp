@@ -117,6 +117,16 @@ __host__ __device__ inline uint32_t out_stride_q(uint32_t pw)
     return q;
 }
 
+// Text-table entry (64 bytes): [0] tag  [1] sig_info word  [2, 2 + tw) the string at 2 bits per base, zero-padded  [2 + tw, 2 + tw + xw) the
+// string's bytes other than ACGT, in ascending position: (position + 1) << 8 | byte, two per dword, low half first, the rest 0 --
+// their 2-bit codes in the string are 0.  xw = the dwords left in the 16-byte word the string ends in, or a whole one.
+// tw = text_key_dwords(dwords the WindowSize bases take): the widths text_lookup_kernel is built for.
+__host__ __device__ constexpr uint32_t text_key_dwords(uint32_t dw) { return dw <= 7 ? 7u : dw <= 8 ? 8u : 14u; }
+__host__ __device__ constexpr uint32_t text_exc_dwords(uint32_t tw)
+{
+    return tw > 14 ? 0u : ((2 + tw) % 4 ? 4 - (2 + tw) % 4 : (tw <= 10 ? 4u : 0u));
+}
+
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
 

@@ -667,8 +667,11 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
             a.dfs_list = c->perm.p; a.dfs_count = c->perm_count.p;
             HIP_TRY(c, hipMemsetAsync(c->perm_count.p, 0, sizeof(uint32_t), c->stream));
         }
-        if (c->dix.w <= 128) hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a);
-        else hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a);
+        switch (text_key_dwords((c->dix.w + 15) / 16)) {
+        case 7: hipLaunchKernelGGL((text_lookup_kernel<7>), grid, dim3(kBlock), lds, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a); break;
+        default: hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a); break;
+        }
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
         launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
@@ -1411,15 +1414,23 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     const uint32_t chunk = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(c->prm.max_batch_reads, 1u << 20), c->prm.max_batch_bases / w);
     if (!chunk) return GROOT_OK;
     // ---- 1. the strings: every WindowSize-mer of every path, both strands, each once ----
-    StringSet set;
+    // (the text table serves reads of exactly WindowSize bases whose kmerCount puts Query on the every-slot-equal branch)
+    const uint32_t q_w = w - c->k + 1;
+    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && !getenv("GROOT_NO_TEXT_TABLE");
+    // strings with a few bytes other than ACGT (a path through an N): bases with code 0 at those positions, then the bytes and their
+    // positions as the text table keeps them (device_types.hpp text_exc_dwords) -- only the text lookup can find these
+    const uint32_t twk = text_key_dwords(tw);               // dwords of bases in a text-table entry (zero-padded)
+    const uint32_t xw = text_ok ? text_exc_dwords(twk) : 0;
+    StringSet set, xset;
     {
         uint64_t expect = 0;
         for (uint32_t p = 0; p < v->n_paths; p++) expect += v->path_len[p] >= w ? 2 * (uint64_t)(v->path_len[p] - w + 1) : 0;
         set.init(tw, (size_t)std::min<uint64_t>(expect, 1ull << 30));
-        std::vector<uint8_t> seq;
+        xset.init(twk + xw, 4096);
+        std::vector<uint8_t> seq, strand[2];
         std::vector<uint32_t> pk[2];
         std::vector<uint32_t> bad_before[2];                // number of bytes other than ACGT before position i
-        uint32_t buf[16];
+        uint32_t buf[16 + 4];
         for (uint32_t g = 0; g < v->n_graphs; g++)
             for (uint32_t lp = 0; lp < v->graph_path_off[g + 1] - v->graph_path_off[g]; lp++) {
                 seq.clear();
@@ -1432,32 +1443,42 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                 for (int st = 0; st < 2; st++) {
                     pk[st].assign(L / 16 + tw + 3, 0);
                     bad_before[st].assign(L + 1, 0);
+                    strand[st].resize(L);
                     for (size_t i = 0; i < L; i++) {
-                        uint8_t b = st ? seq[L - 1 - i] : seq[i];
+                        uint8_t b = st ? seq[L - 1 - i] : seq[i];       // (reverse strand: ACGT complemented, any other byte as it is)
                         const bool acgt = b == 'A' || b == 'C' || b == 'G' || b == 'T';
                         if (st && acgt) b = b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A';
+                        strand[st][i] = b;
                         bad_before[st][i + 1] = bad_before[st][i] + (acgt ? 0 : 1);
                         if (acgt) pk[st][i >> 4] |= (uint32_t)((b >> 1) & 3u) << (2 * (i & 15));
                     }
                     for (size_t i = 0; i + w <= L; i++) {
-                        if (bad_before[st][i + w] != bad_before[st][i]) continue;
+                        const uint32_t nb = bad_before[st][i + w] - bad_before[st][i];
+                        if (nb > 2 * xw) continue;
                         pack_at(pk[st], i, w, tw, buf);
-                        (void)set.find(buf, true);
+                        if (!nb) { (void)set.find(buf, true); continue; }
+                        for (uint32_t x = tw; x < twk + xw; x++) buf[x] = 0;
+                        for (uint32_t x = 0, np = 0; x < w; x++)
+                            if (bad_before[st][i + x + 1] != bad_before[st][i + x]) {
+                                buf[twk + (np >> 1)] |= (((x + 1) << 8) | strand[st][i + x]) << (16 * (np & 1));
+                                np++;
+                            }
+                        (void)xset.find(buf, true);
                     }
                 }
             }
     }
     lap("path strings");
-    const size_t NS = set.n;
-    if (!NS) return GROOT_OK;
+    const size_t NS = set.n, NX = xset.n, NT = NS + NX;     // string ids: the ACGT strings, then the ones with exceptions
+    if (!NT) return GROOT_OK;
     // ---- 2. the pipeline, once per string ----
     DevBuf<uint8_t> d_seq;
     DevBuf<uint64_t> d_off;
     HIP_TRY(c, d_seq.alloc((size_t)chunk * w + 64));
     HIP_TRY(c, d_off.alloc((size_t)chunk + 1));
     std::vector<uint32_t> tab;                              // entries, sq * 4 dwords each
-    std::vector<uint32_t> sinfo(NS, 0);                     // sig_info word per string (0 = not tabulated)
-    std::vector<uint8_t> in_text(NS, 0);                    // ... and it may go into the text table
+    std::vector<uint32_t> sinfo(NT, 0);                     // sig_info word per string (0 = not tabulated)
+    std::vector<uint8_t> in_text(NT, 0);                    // ... and it may go into the text table
     std::vector<uint8_t> seqs((size_t)chunk * w);
     std::vector<uint64_t> offs((size_t)chunk + 1);
     for (uint32_t i = 0; i <= chunk; i++) offs[i] = (uint64_t)i * w;
@@ -1466,10 +1487,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     std::vector<uint64_t> masks;
     std::vector<uint32_t> icnt, iwin, nseeds, seedw;
     std::vector<size_t> big;                                // strings with more calls / seeds than the first pass keeps: second pass
-    // (the text table serves reads of exactly WindowSize bases whose kmerCount puts Query on the every-slot-equal branch)
-    const uint32_t q_w = w - c->k + 1;
-    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && !getenv("GROOT_NO_TEXT_TABLE");
-    c->out_strings = NS; c->out_tabulated = c->out_entries = 0;
+    c->out_strings = NT; c->out_tabulated = c->out_entries = 0;
     int rc_all = GROOT_OK;
     c->tab_capture = true;
     static const char kBase[4] = {'A', 'C', 'T', 'G'};
@@ -1480,9 +1498,14 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
                 for (uint32_t j = (uint32_t)((uint64_t)m * t / nt); j < (uint32_t)((uint64_t)m * (t + 1) / nt); j++) {
-                    const uint32_t *pwd = &set.words[ids[j] * tw];
+                    const uint32_t *pwd = ids[j] < NS ? &set.words[ids[j] * tw] : &xset.words[(ids[j] - NS) * (twk + xw)];
                     uint8_t *dst = &seqs[(size_t)j * w];
                     for (uint32_t x = 0; x < w; x++) dst[x] = (uint8_t)kBase[(pwd[x >> 4] >> (2 * (x & 15))) & 3u];
+                    if (ids[j] >= NS)
+                        for (uint32_t np = 0; np < 2 * xw; np++) {
+                            const uint32_t pair = (pwd[twk + (np >> 1)] >> (16 * (np & 1))) & 0xFFFFu;
+                            if (pair) dst[(pair >> 8) - 1] = (uint8_t)pair;
+                        }
                 }
             });
             for (auto &x : th) x.join();
@@ -1569,8 +1592,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     };
     {
         std::vector<size_t> ids(chunk);
-        for (size_t s0 = 0; s0 < NS && !rc_all; s0 += chunk) {
-            const uint32_t m = (uint32_t)std::min<size_t>(chunk, NS - s0);
+        for (size_t s0 = 0; s0 < NT && !rc_all; s0 += chunk) {
+            const uint32_t m = (uint32_t)std::min<size_t>(chunk, NT - s0);
             std::iota(ids.begin(), ids.begin() + m, s0);
             rc_all = run(ids.data(), m, kIncrCap, false);
         }
@@ -1635,19 +1658,22 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     // branch of Query produced its seeds)
     if (text_ok) {
         size_t ns = 0;
-        for (size_t j = 0; j < NS; j++) ns += in_text[j];
+        for (size_t j = 0; j < NT; j++) ns += in_text[j];
         uint32_t cap = 1024;
         while (cap < 2 * ns) cap <<= 1;
         // filled on the device: the strings are uploaded as they sit in the set, every thread claims a slot for its string with a
         // compare-and-swap on the entry's sig_info word (0 = free) and writes tag and bases behind it
-        DevBuf<uint32_t> d_words, d_info;
-        for (size_t j = 0; j < NS; j++) if (!in_text[j]) sinfo[j] = 0;      // (sinfo is not needed past this point)
+        DevBuf<uint32_t> d_words, d_xwords, d_info;
+        for (size_t j = 0; j < NT; j++) if (!in_text[j]) sinfo[j] = 0;      // (sinfo is not needed past this point)
         HIP_TRY(c, upload(d_words, set.words.data(), NS * tw));
-        HIP_TRY(c, upload(d_info, sinfo.data(), NS));
+        HIP_TRY(c, upload(d_xwords, xset.words.data(), NX * (twk + xw)));
+        HIP_TRY(c, upload(d_info, sinfo.data(), NT));
         HIP_TRY(c, c->text_tab.alloc((size_t)cap * 4));
         HIP_TRY(c, hipMemsetAsync(c->text_tab.p, 0, (size_t)cap * 64, c->stream));
-        hipLaunchKernelGGL(text_table_fill_kernel, dim3((unsigned)((NS + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_words.p, d_info.p, (uint32_t)NS, tw,
-                           tw <= 8 ? 8u : 14u, reinterpret_cast<uint32_t *>(c->text_tab.p), cap - 1);
+        if (NS) hipLaunchKernelGGL(text_table_fill_kernel, dim3((unsigned)((NS + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_words.p, d_info.p, (uint32_t)NS, tw,
+                                   tw, twk, reinterpret_cast<uint32_t *>(c->text_tab.p), cap - 1);
+        if (NX) hipLaunchKernelGGL(text_table_fill_kernel, dim3((unsigned)((NX + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, d_xwords.p, d_info.p + NS, (uint32_t)NX, twk,
+                                   twk + xw, twk, reinterpret_cast<uint32_t *>(c->text_tab.p), cap - 1);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->dix.text_tab = c->text_tab.p;

@@ -998,8 +998,10 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
 // so ContainmentIndex.Query returns the window's sketch class for it (lshe.go:153-175 at a threshold that needs every slot equal),
 // and the outcome table holds what the graphMinion loop does with it.  The strings with a tabulated outcome whose IncrementSubPath
 // calls are exactly their seed windows sit in a hash table keyed by the TEXT (2 bits per base): one probe, one 64-byte entry holding
-// the text itself -- equality is decided on the bases, never on the hash.  Everything else (no entry: reads with errors, reads
-// from elsewhere, other lengths, bytes other than ACGT) goes onto the list of sketch_seed_kernel<..., LIST>, which hashes it.
+// the text itself -- equality is decided on the bases, never on the hash.  A path string with a few bytes other than ACGT (an N
+// in an indexed sequence) has an entry too: those bytes and their positions follow the bases (device_types.hpp text_exc_dwords)
+// and are compared like them.  Everything else (no entry: reads with errors, reads from elsewhere, other lengths) goes onto the
+// list of sketch_seed_kernel<..., LIST>, which hashes it.
 //   entry (64 bytes): [0] tag  [1] DeviceIndex::sig_info word of the string (0 = free slot)  [2..] the string, 16 bases per dword
 __host__ __device__ __forceinline__ uint64_t text_hash_step(uint64_t h, uint32_t dw)
 {
@@ -1184,21 +1186,22 @@ __global__ __launch_bounds__(kBlock) void lsh_query_kernel(SeedArgs a)
     }
 }
 
-// fills the text table at open: string j (tw dwords, 2 bits per base) with a non-zero sig_info word claims the first free slot of its
-// probe sequence (compare-and-swap on the entry's info word) and writes tag and bases; hashed over twk dwords, as the lookup does
+// fills the text table at open: string j (tw dwords at 2 bits per base, then its bytes other than ACGT: device_types.hpp
+// text_exc_dwords) with a non-zero sig_info word claims the first free slot of its probe sequence (compare-and-swap on the entry's
+// info word) and writes tag, bases and exceptions; hashed over the bases, twk dwords of them, as the lookup does
 __global__ __launch_bounds__(kBlock) void text_table_fill_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ info, uint32_t n, uint32_t tw,
-                                                                 uint32_t twk, uint32_t *tab, uint32_t mask)
+                                                                 uint32_t stride, uint32_t twk, uint32_t *tab, uint32_t mask)
 {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= n || !info[j]) return;
-    const uint32_t *wd = words + (size_t)j * tw;
+    const uint32_t *wd = words + (size_t)j * stride;        // tw dwords of bases, then stride - tw dwords of bytes other than ACGT
     uint64_t h = GROOT_TEXT_HASH_INIT;
     for (uint32_t x = 0; x < twk; x++) h = text_hash_step(h, x < tw ? wd[x] : 0u);
     for (uint32_t slot = (uint32_t)h & mask;; slot = (slot + 1) & mask) {
         uint32_t *e = tab + (size_t)slot * 16;
         if (atomicCAS(e + 1, 0u, info[j]) != 0u) continue;
         e[0] = (uint32_t)(h >> 32);
-        for (uint32_t x = 0; x < tw; x++) e[2 + x] = wd[x];
+        for (uint32_t x = 0; x < stride; x++) e[2 + x] = wd[x];
         return;
     }
 }
@@ -1207,6 +1210,7 @@ template <int TW>
 __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
 {
     static_assert(TW >= 1 && TW <= 14, "a 64-byte entry holds 224 bases");
+    constexpr int XW = (int)text_exc_dwords(TW);           // dwords of (position, byte) pairs behind the bases
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: one bit per 4 bases of the span (set: a byte other than ACGT among them), then one dword of codes per 16 bases
     uint32_t *badbits = reinterpret_cast<uint32_t *>(smem);
@@ -1253,32 +1257,61 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
         }
     }
     bool mine = !no_seeds && in_lds && len == ix.w;
+    bool exc = false;
     if (mine) {
-        // groups of 4 bases the read touches (a neighbour's byte in a shared group can send the read to the list: conservative)
+        // groups of 4 bases the read touches: a byte other than ACGT in one of them?
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 2, c1 = (uint32_t)(o0 - base16 + len - 1) >> 2;
         for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
             uint32_t bits = badbits[w];
             if (w == c0 >> 5) bits &= ~0u << (c0 & 31);
             if (w == c1 >> 5) bits &= ~0u >> (31 - (c1 & 31));
-            if (bits) mine = false;
+            if (bits) exc = true;
         }
+        if (exc && XW == 0) mine = false;
     }
     if (mine) {
     const uint32_t P = 2u * (uint32_t)(o0 - base16);       // bit position of base 0 in `codes`
     const uint32_t n_full = len >> 4, tail_mask = (1u << (2 * (len & 15))) - 1u;
     uint32_t rdw[TW];
-    uint64_t h = GROOT_TEXT_HASH_INIT;
+    uint32_t xdw[XW ? XW : 1] = {};
 #pragma unroll
     for (int j = 0; j < TW; j++) {
         const uint32_t mask = (uint32_t)j < n_full ? ~0u : ((uint32_t)j == n_full ? tail_mask : 0u);
         rdw[j] = __builtin_amdgcn_alignbit(codes[(P >> 5) + j + 1], codes[(P >> 5) + j], P & 31) & mask;
-        h = text_hash_step(h, rdw[j]);
     }
+    if (XW != 0 && exc) {
+        // a group of 4 bases with a byte other than ACGT in it (a read in thousands): the bytes themselves, from the read in HBM --
+        // position and byte go into the key as they sit in the entry, the 2-bit code of the position is 0
+        const uint32_t rel0 = (uint32_t)(o0 - base16);
+        const uint32_t c0 = rel0 >> 2, c1 = (rel0 + len - 1) >> 2;
+        uint32_t np = 0;
+        for (uint32_t g = c0; g <= c1 && mine; g++) {
+            if (!((badbits[g >> 5] >> (g & 31)) & 1u)) continue;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(a.seq + base16 + 4ull * g);
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t b = (v >> (8 * j)) & 0xFFu;
+                const uint32_t at = 4 * g + j;
+                if (at < rel0 || at >= rel0 + len || b == 'A' || b == 'C' || b == 'G' || b == 'T') continue;
+                if (np >= 2u * XW) { mine = false; break; }
+                const uint32_t pos = at - rel0;
+                const uint32_t pair = ((pos + 1) << 8) | b;
+#pragma unroll
+                for (int x = 0; x < XW; x++) if ((np >> 1) == (uint32_t)x) xdw[x] |= pair << (16 * (np & 1));
+#pragma unroll
+                for (int x = 0; x < TW; x++) if ((pos >> 4) == (uint32_t)x) rdw[x] &= ~(3u << (2 * (pos & 15)));
+                np++;
+            }
+        }
+    }
+    if (mine) {
+    uint64_t h = GROOT_TEXT_HASH_INIT;
+#pragma unroll
+    for (int j = 0; j < TW; j++) h = text_hash_step(h, rdw[j]);
     const uint32_t tag = (uint32_t)(h >> 32);
     const uint4 *tab = ix.text_tab;
     for (uint32_t slot = (uint32_t)h & ix.text_mask;; slot = (slot + 1) & ix.text_mask) {
         const uint4 *e = tab + (size_t)slot * 4;
-        constexpr int NQ = (2 + TW + 3) / 4;               // 16-byte words of an entry that hold something
+        constexpr int NQ = (2 + TW + XW + 3) / 4;          // 16-byte words of an entry that hold something
         uint32_t ed[4 * NQ];
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
@@ -1293,7 +1326,10 @@ __global__ __launch_bounds__(kBlock) void text_lookup_kernel(SeedArgs a)
         uint32_t diff = 0;
 #pragma unroll
         for (int j = 0; j < TW; j++) diff |= ed[2 + j] ^ rdw[j];
+#pragma unroll
+        for (int j = 0; j < XW; j++) diff |= ed[2 + TW + j] ^ xdw[j];
         if (!diff) { info = ed[1]; break; }
+    }
     }
     }
     }

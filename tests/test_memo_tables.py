@@ -96,3 +96,40 @@ def test_small_index_and_small_buffers(small_index, monkeypatch):
     for seq, off in (perfect_batch(index, 3000, 0), mixed_batch(index, 3000, seed=8), perfect_batch(index, 3000, 7000)):
         _, att = check_batch(al, index, seq, off, att)
     al.close()
+
+
+def test_reads_through_an_N_of_an_indexed_sequence(argannot_index, monkeypatch):
+    """a path string with a few bytes other than ACGT has a text-table entry too (bases with code 0 at those positions, then the
+    bytes and their positions: device_types.hpp text_exc_dwords): error-free reads sampled across an N of an indexed sequence are
+    answered by the lookup, with the oracle's seeds / records / counters / call counts; the same reads with the N somewhere
+    else, or another byte in its place, are not in the table and take the hashing path -- same equality"""
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+        monkeypatch.delenv(v, raising=False)
+    index = argannot_index
+    cat, o, lens = synth.reference_sequences(index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 400000, 100)
+    reads = seq[: 400000 * 100].reshape(-1, 100)
+    with_n = reads[(reads == ord("N")).any(axis=1)]
+    assert len(with_n) >= 100, "the sample holds too few reads through an N: enlarge it"
+    clean = reads[:4000]
+    batch = np.concatenate([with_n, clean])
+    np.random.default_rng(5).shuffle(batch, axis=0)
+    off = np.arange(len(batch) + 1, dtype=np.uint64) * 100
+    al = device.Aligner(index, max_batch_reads=8192, max_read_len=128)
+    att = np.zeros((0, index.view.n_windows), dtype=np.uint32)
+    counts = None
+    for _ in range(3):                                     # (the ctx picks the text lookup from the second batch on)
+        counts, att = check_batch(al, index, batch.reshape(-1).copy(), off, att)
+    assert counts["full_sketch_reads"] == 0, counts
+    # the N moved by one base / replaced by another byte: no entry, the hashing path answers
+    moved = with_n.copy()
+    for row in moved:
+        p = int(np.flatnonzero(row == ord("N"))[0])
+        row[p], row[(p + 1) % 100] = row[(p + 1) % 100], row[p]
+    other = with_n.copy()
+    other[other == ord("N")] = ord("R")
+    batch2 = np.concatenate([moved, other, clean])
+    off2 = np.arange(len(batch2) + 1, dtype=np.uint64) * 100
+    counts, att = check_batch(al, index, batch2.reshape(-1).copy(), off2, att)
+    assert counts["full_sketch_reads"] >= len(other)
+    al.close()
