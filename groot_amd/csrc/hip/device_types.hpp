@@ -95,7 +95,7 @@ static_assert(sizeof(groot_ctrav) == 12, "packed traversal record is 12 bytes");
 // produce for a read that IS bases [o, o + WindowSize) of a window text row -- every such read is the same string with the same seed
 // windows, so the outcome is a function of (window, row, o) and the ctx works it out once, at open, by running the align stage itself
 // on the string.  One entry per traversal record:
-//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | mapped << 9 | traversals of the string << 16 (first entry)
+//   [0] node  [1] offset  [2] graph  [3] flags (GROOT_TRAV_*, bits 0..7) | multimapped << 8 | mapped << 9 (first entry) | seed windows in this entry << 10 | traversals of the string << 16 (first entry)
 //       (entries with node = kEmpty carry no record: calls, seeds and counters of a string without traversals, or calls and seeds
 //       beyond what the traversal entries hold; their number sits in bits 20..31 of [2] of the string's first entry)
 //   [4],[5] windows whose IncrementSubPath the read triggers (kEmpty = none; a string's calls are spread over its entries)

@@ -1567,8 +1567,13 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                     if (e == 0) tab[b + 3] |= ((icnt[j] >> 31) ? 0x100u : 0u) | (nsd ? 0x200u : 0u) | (cnt << 16);
                     tab[b + 4] = 2 * e < ni ? iwin[(size_t)j * incr_cap + 2 * e] : kEmpty;
                     tab[b + 5] = 2 * e + 1 < ni ? iwin[(size_t)j * incr_cap + 2 * e + 1] : kEmpty;
-                    for (uint32_t x = 0; x < kOutSeedDw; x++)
-                        tab[b + sq * 4 - kOutSeedDw + x] = seeds_fit && kOutSeedDw * e + x < nsd ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
+                    uint32_t here = 0;                      // seed windows in this entry: bits 10..12 of [3]
+                    for (uint32_t x = 0; x < kOutSeedDw; x++) {
+                        const bool has = seeds_fit && kOutSeedDw * e + x < nsd;
+                        tab[b + sq * 4 - kOutSeedDw + x] = has ? seedw[(size_t)(kOutSeedDw * e + x) * m + j] : kEmpty;
+                        here += has;
+                    }
+                    tab[b + 3] |= here << 10;
                     for (uint32_t x = 0; x < pw; x++) {
                         tab[b + kOutHdrDw + 2 * x] = e < cnt ? (uint32_t)masks[(t0 + e) * pw + x] : 0u;
                         tab[b + kOutHdrDw + 2 * x + 1] = e < cnt ? (uint32_t)(masks[(t0 + e) * pw + x] >> 32) : 0u;

@@ -2282,13 +2282,11 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             if (j == 0) { n_ent += h.z >> 20; h.z &= 0xFFFFFu; }
             const uint4 x = e[1];                          // two call-count windows, first path word
             const uint4 y = pw_out > 1 ? e[2] : make_uint4(0, 0, 0, 0);   // path words 1, 2
-            const uint4 sd = e[t.stride_q - 1];            // seed windows (the four loads of one entry are in flight together)
             if (count_here) {
                 if (x.x != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.x], 1u);
                 if (x.y != kEmpty) atomicAdd(&t.attempts[(size_t)row * t.n_windows + x.y], 1u);
             }
-            if (seeds_here)                                // (groot_hip_read_seeds takes the windows themselves from the host's copy of the table)
-                ns += (sd.x != kEmpty) + (sd.y != kEmpty) + (sd.z != kEmpty) + (sd.w != kEmpty);
+            if (seeds_here) ns += (h.w >> 10) & 7u;        // seed windows in the entry (groot_hip_read_seeds takes the windows themselves from the host's copy of the table)
             if (j == 0) { mapped += (h.w >> 9) & 1u; multimapped += (h.w >> 8) & 1u; }
             if (j < nt) {                                  // one sam.Record per path of the traversal (alignment.go:114-156)
                 alns += __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
@@ -2301,8 +2299,24 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
             groot_trav tr;
             tr.read_id = t.first_read_id + r; tr.graph_id = h.z; tr.node = h.x; tr.offset = h.y;
             tr.ord = (uint16_t)j; tr.flags = (uint8_t)h.w; tr.reserved = 0;
-            out[i + j] = tr;
             uint64_t *mo = mask_out + (size_t)(i + j) * pw_out;
+            if (!(t.exp & 8u)) {
+                // (the records are written once and read by the copy-out or the next stage of the caller: streaming stores keep
+                // them from pushing the outcome table out of L2 / MALL)
+                static_assert(sizeof(groot_trav) == 20, "record is five dwords");
+                uint32_t tw5[5];
+                __builtin_memcpy(tw5, &tr, 20);
+                uint32_t *po = reinterpret_cast<uint32_t *>(out + i + j);
+#pragma unroll
+                for (int d = 0; d < 5; d++) __builtin_nontemporal_store(tw5[d], po + d);
+                __builtin_nontemporal_store((uint64_t)x.z | ((uint64_t)x.w << 32), mo);
+                if (pw_out > 1) __builtin_nontemporal_store((uint64_t)y.x | ((uint64_t)y.y << 32), mo + 1);
+                if (pw_out > 2) __builtin_nontemporal_store((uint64_t)y.z | ((uint64_t)y.w << 32), mo + 2);
+                const uint32_t *ew = reinterpret_cast<const uint32_t *>(e) + kOutHdrDw;
+                for (uint32_t w = 3; w < pw_out; w++) mo[w] = (uint64_t)ew[2 * w] | ((uint64_t)ew[2 * w + 1] << 32);
+                continue;
+            }
+            out[i + j] = tr;
             mo[0] = (uint64_t)x.z | ((uint64_t)x.w << 32);
             if (pw_out > 1) {
                 mo[1] = (uint64_t)y.x | ((uint64_t)y.y << 32);
