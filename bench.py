@@ -63,21 +63,21 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def load_index():
-    """arg-annot.90, k=31 s=21 w=100 x=8 y=4 (cmd/index.go:45-49 defaults), cached under build/"""
+def load_index(db="arg-annot.90"):
+    """arg-annot.90 (or resfinder.90), k=31 s=21 w=100 x=8 y=4 (cmd/index.go:45-49 defaults), cached under build/"""
     from groot_amd import host
 
-    cache = host.index_cache_path("arg-annot.90.k31.s21.w100")
+    cache = host.index_cache_path(db + ".k31.s21.w100")
     if os.path.exists(cache):
         try:
             return host.Index.load(cache), cache
         except Exception:
             pass
     with tempfile.TemporaryDirectory() as td:
-        with tarfile.open(os.path.join(REPO, "tests", "golden", "data", "arg-annot.90.tar.gz")) as tf:
+        with tarfile.open(os.path.join(REPO, "tests", "golden", "data", db + ".tar.gz")) as tf:
             members = [m for m in tf.getmembers() if os.path.basename(m.name).startswith("cluster") and m.name.endswith(".msa")]
             tf.extractall(td, members=members)
-        index = host.Index.from_msa_dir(os.path.join(td, "arg-annot.90"))
+        index = host.Index.from_msa_dir(os.path.join(td, db))
     try:
         tmp = cache + ".%d.tmp" % os.getpid()
         index.save(tmp)
@@ -211,24 +211,7 @@ def mixed_leg(local_rank, n_reads, steps, cli_reads, bam_level):
 
     from groot_amd import device, host, synth
 
-    cache = host.index_cache_path("resfinder.90.k31.s21.w100")
-    index = None
-    if os.path.exists(cache):
-        try:
-            index = host.Index.load(cache)
-        except Exception:
-            index = None
-    if index is None:
-        with tempfile.TemporaryDirectory() as td:
-            with tarfile.open(os.path.join(REPO, "tests", "golden", "data", "resfinder.90.tar.gz")) as tf:
-                members = [m for m in tf.getmembers() if os.path.basename(m.name).startswith("cluster") and m.name.endswith(".msa")]
-                tf.extractall(td, members=members)
-            index = host.Index.from_msa_dir(os.path.join(td, "resfinder.90"))
-        try:
-            index.save(cache + ".tmp")
-            os.replace(cache + ".tmp", cache)
-        except Exception:
-            pass
+    index, _ = load_index("resfinder.90")
     dev = torch.device("cuda", local_rank)
     cat, off, lens = synth.reference_sequences(index)
     cat_t, off_t, lens_t = (torch.from_numpy(x).to(dev) for x in (cat, off, lens))

@@ -81,6 +81,12 @@ static_assert(sizeof(ReadRec) == 32, "read record is two 16-byte words");
 constexpr uint32_t kRecCountMask = 0x00FFFFFFu;
 constexpr uint32_t kRecNo12F = 1u << 24, kRecNo3F = 1u << 25, kRecNo4F = 1u << 26;   // R = F << 3
 constexpr uint32_t kRecAscending = 1u << 30;                // cnt_flags: the read's seed windows were written in ascending order
+constexpr uint32_t kLongListCap = 1u << 16, kSortSeedsMax = 1024;   // sort_seed_lists_kernel: reads per batch, seed windows per read
+// A read with more than kSplitMin seed windows is handled by several lanes of the align stage: its ascending window list is cut at
+// graph boundaries into items of at least kSplitMin windows (graphminion.go:46-102 treats the graphs of a read independently of
+// each other; only the order of the records and the per-read counters tie them together, and those are put right afterwards).
+constexpr uint32_t kSplitMin = 8, kSplitMaxItems = 256;
+constexpr uint32_t kRecSplit = 1u << 23;                    // cnt_flags: the read's first item ends at the count in bits 0..22; the rest are AlignArgs::vitem entries
 constexpr uint32_t kPrefixWords = 256;   // words per window in DeviceIndex::win_prefix
 
 // a traversal record on its way to the host: what cannot be derived there (graph = graph of the node, ord = position among
@@ -227,6 +233,7 @@ struct SeedArgs {
     uint32_t *lsh_list, *lsh_count;
     uint64_t *lsh_sketch;
     uint32_t *dfs_list, *dfs_count;   // reads with a scheduling key, appended by the seed epilogue (processing order of the align stage when few are left); or null
+    uint32_t *long_list, *long_count; // reads with more than four seed windows that were not found in ascending order (sort_seed_lists_kernel); up to kLongListCap
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
@@ -266,6 +273,12 @@ struct AlignArgs {
     uint32_t incr_cap;           // slots per read in incr_win
     uint32_t head_lanes;         // lanes per round in the head of the processing order (the longest walks); 0 = as everywhere else
     uint32_t round_lanes;        // lanes a wavefront fills per round; 0 = 64, fewer when the batch leaves the align stage little to do (see the kernel)
+    // items of split reads (kSplitMin): {read, first seed position, end position, records of the read's earlier items}; they come
+    // first in the processing order (slot j < min(*vcount, vcap) is item j), and item j writes its count / first record to
+    // slot n_reads + j of trav_cnt / trav_first / mask_first and labels its overflow records with read n_reads + j
+    const uint4 *vitem;
+    const uint32_t *vcount;
+    uint32_t vcap;
     uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;
 };

@@ -179,6 +179,10 @@ struct groot_ctx {
     // shared work buffers (compute stream only)
     uint32_t seed_slots = 0;
     DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, perm_count, todo_list, todo_count;
+    DevBuf<uint32_t> long_list, long_count;              // SeedArgs::long_list
+    DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
+    DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
+    uint32_t vcap = 0;
     DevBuf<unsigned long long> seed_shards;
     DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch + their sketches, for lsh_query_kernel (absent: per-lane row walks)
     DevBuf<uint64_t> lsh_sketch;
@@ -623,6 +627,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.trav_cnt = c->trav_cnt.p;
     a.shards = c->seed_shards.p;
     a.ctr = s->d_ctr.p;
+    a.long_list = c->long_list.p; a.long_count = c->long_count.p;
     if (c->dix.out_tab) {                                   // reads the signature kernel finds in the outcome table say so here
         a.tab_idx = c->tab_idx.p;
         a.tab_hist = getenv("GROOT_EXP_NOHIST") ? nullptr : c->tab_hist.p;
@@ -655,6 +660,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.lsh_list = c->lsh_list.p; a.lsh_count = c->lsh_count.p; a.lsh_sketch = c->lsh_sketch.p;
         HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, sizeof(uint32_t), c->stream));
     }
+    HIP_TRY(c, hipMemsetAsync(c->vcount.p, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[7], c->stream));
     if (s->text_used) {
         a.todo_list = c->todo_list.p;
@@ -694,9 +700,20 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     }
     HIP_TRY(c, hipGetLastError());
     if (c->profiling && !s->text_used) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));   // (signature kernel + its list pass / the full-width kernel)
+    // seed lists of more than four windows that are not ascending (LSH-Forest hits come in band order): sorted, a wavefront per read
+    // ... and the longest ones cut into items that different lanes of the align stage take
+    {
+        SplitArgs sa{};
+        sa.list = c->long_list.p; sa.count = c->long_count.p; sa.seed_count = c->seed_count.p; sa.seed_win = c->seed_win.p;
+        sa.n_reads = s->n_reads; sa.seed_slots = c->seed_slots; sa.read_rec = c->read_rec.p; sa.win_rec = c->dix.win_rec;
+        sa.split = c->vcap && !c->tab_capture && !c->prm.no_exact_align;
+        sa.vitem = c->vitem.p; sa.vcount = c->vcount.p; sa.vcap = c->vcap; sa.split_list = c->split_list.p;
+        sa.ctr = s->d_ctr.p; sa.update_weights = update_weights ? 1 : 0;
+        hipLaunchKernelGGL(sort_seed_lists_kernel, dim3(512), dim3(kBlock), 0, c->stream, sa);
+    }
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(64), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
-                       c->max_q, s->d_ctr.p, c->seed_shards.p);
+                       c->max_q, s->d_ctr.p, c->seed_shards.p, c->long_count.p);
     if (a.tab_hist) {
         hipLaunchKernelGGL(fold_tab_hist_kernel, dim3(std::min<uint32_t>((c->n_windows + kBlock - 1) / kBlock, 1024u)), dim3(kBlock), 0, c->stream, c->tab_hist.p,
                            c->attempts_ptr, c->q_row.p, c->dix.w - c->k + 1, c->n_windows, s->d_ctr.p, update_weights ? 1u : 0u);
@@ -756,6 +773,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.ovf_mask = c->ovf_mask.p;
     a.ovf_cnt = c->ovf_cnt.p;
     a.ovf_cap = c->ovf_cap;
+    if (c->vcap) { a.vitem = c->vitem.p; a.vcount = c->vcount.p; a.vcap = c->vcap; }
     a.stk_hdr = c->stk_hdr.p;
     a.stk_mask = c->stk_mask.p;
     uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
@@ -791,6 +809,8 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     const uint32_t n = s->n_reads;
     size_t tmp_bytes = 0;
+    // split reads: their items' counts become the read's count, every item learns where its records go in the read's run
+    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(kLongListCap / kBlock), dim3(kBlock), 0, c->stream, c->split_list.p, c->vcount.p, c->vitem.p, c->trav_cnt.p, n, s->d_ctr.p);
     HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
     if (tmp_bytes > c->scan_tmp.n) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -812,9 +832,11 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
                        c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw,
                        c->pw_view, s->d_ctr.p, ot);
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[10], c->stream));
+    if (c->vcap) hipLaunchKernelGGL(order_split_kernel, dim3(std::min<uint32_t>((c->vcap + kBlock - 1) / kBlock, 256u)), dim3(kBlock), 0, c->stream, c->vitem.p, c->vcount.p, c->vcap, c->trav_cnt.p,
+                                    c->trav_off.p, c->trav_first.p, c->mask_first.p, n, s->first_read_id, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
     hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->stream,
                        c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, s->first_read_id, s->d_trav.p,
-                       s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
+                       s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p, c->vitem.p, n);
     HIP_TRY(c, hipGetLastError());
     if (!c->prm.results_on_device) {
         // compact path sets for the copy-out (kernels.hpp): words per traversal, their exclusive scan, the copy
@@ -2141,6 +2163,9 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, c->sort_key_out.alloc(R));
     HIP_TRY(c, c->perm.alloc(R));
     HIP_TRY(c, c->perm_count.alloc(4));
+    HIP_TRY(c, c->long_list.alloc(kLongListCap));
+    HIP_TRY(c, c->long_count.alloc(4));
+    HIP_TRY(c, hipMemset(c->long_count.p, 0, 4 * sizeof(uint32_t)));
     {
         std::vector<uint32_t> iota(R);
         std::iota(iota.begin(), iota.end(), 0u);
@@ -2148,9 +2173,15 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     }
     if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
     if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
-    HIP_TRY(c, c->trav_first.alloc(R));
-    HIP_TRY(c, c->mask_first.alloc((size_t)R * c->pw));
-    HIP_TRY(c, c->trav_cnt.alloc(R));
+    // (+ vcap slots behind the reads: the items of split reads, AlignArgs::vitem)
+    c->vcap = getenv("GROOT_NO_SPLIT") ? 0u : std::max<uint32_t>(4096, R / 4);
+    HIP_TRY(c, c->trav_first.alloc((size_t)R + c->vcap));
+    HIP_TRY(c, c->mask_first.alloc(((size_t)R + c->vcap) * c->pw));
+    HIP_TRY(c, c->trav_cnt.alloc((size_t)R + c->vcap));
+    HIP_TRY(c, c->vitem.alloc(std::max<uint32_t>(c->vcap, 1)));
+    HIP_TRY(c, c->split_list.alloc(kLongListCap));
+    HIP_TRY(c, c->vcount.alloc(4));
+    HIP_TRY(c, hipMemset(c->vcount.p, 0, 4 * sizeof(uint32_t)));
     HIP_TRY(c, c->trav_off.alloc(R));
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
     if (int rc = alloc_ovf(c, getenv("GROOT_TEST_SMALL_BUFFERS") ? 2u : std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;

@@ -283,8 +283,12 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
         }
     }
     if (a.read_rec) {
+        if (n_hits > kSplitMin && a.long_list) {              // (a read in a hundred; shorter lists are searched as they are)
+            const uint32_t at = atomicAdd(a.long_count, 1u);
+            if (at < kLongListCap) a.long_list[at] = r;
+        }
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | verdicts | (asc ? kRecAscending : 0u) | (high ? 0x80000000u : 0u));
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecSplit - 1u) | verdicts | (asc ? kRecAscending : 0u) | (high ? 0x80000000u : 0u));
         // (more than four seeds: the smallest and the largest window instead of the first two -- the align stage starts at the
         // smallest and knows when nothing is left without looking through the list)
         rq[1] = n_hits > 4 ? make_uint4(min_win, max_win, s2, s3) : make_uint4(s0, s1, s2, s3);
@@ -305,7 +309,7 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
     }
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecCountMask) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u) | (asc ? kRecAscending : 0u));
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecSplit - 1u) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u) | (asc ? kRecAscending : 0u));
         rq[1] = n_hits > 4 ? make_uint4(min_win, max_win, s2, s3) : make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);
@@ -1384,15 +1388,141 @@ __global__ __launch_bounds__(kBlock) void patch_reads_kernel(const uint64_t *__r
     if (i < n) seq[pos[i]] = byte[i];
 }
 
+// The align stage handles a read's seed windows in ascending order (graphminion.go:46-102 ranges over them in the canonical order
+// of the windows), one after the other in ONE lane: a read of a sequence that two hundred graphs share keeps its lane -- and the
+// launch -- busy for two hundred walks (resfinder.90, reads of 75..150 bases: 0.8 % of the reads bring more than 16 windows; the
+// align stage takes 4.7 ms per 2 M reads with them and 2.7 ms without).  Such reads are rare and prepared here, a wavefront per
+// read: the list sorted (rank by counting, in LDS; LSH-Forest hits come in band order), then cut at graph boundaries into items
+// of at least kSplitMin windows that different lanes of align_kernel take (AlignArgs::vitem).
+struct SplitArgs {
+    const uint32_t *list, *count;          // SeedArgs::long_list
+    const uint32_t *seed_count;
+    uint32_t *seed_win;
+    uint32_t n_reads, seed_slots;
+    ReadRec *read_rec;
+    const WinRec *win_rec;
+    uint32_t split;                        // 0: sort only (capture pass of groot_hip_open, no_exact_align)
+    uint4 *vitem;                          // [vcap]
+    uint32_t *vcount;                      // [0] items, [1] split reads
+    uint32_t vcap;
+    uint4 *split_list;                     // [kLongListCap] {read, first item, items, -}
+    DeviceCounters *ctr;
+    uint32_t update_weights;
+};
+__global__ __launch_bounds__(kBlock) void sort_seed_lists_kernel(SplitArgs a)
+{
+    __shared__ uint32_t lds[(kBlock / 64) * (2 * kSortSeedsMax + kSplitMaxItems + 4)];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *raw = lds + wave * (2 * kSortSeedsMax + kSplitMaxItems + 4);   // the list as found; then the graph of every sorted window
+    uint32_t *sorted = raw + kSortSeedsMax;
+    uint32_t *seg = sorted + kSortSeedsMax;                                   // [kSplitMaxItems] end positions, then [0..3] scalars
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const uint32_t n = min(*a.count, kLongListCap);
+    for (uint32_t i = blockIdx.x * (kBlock / 64) + wave; i < n; i += gridDim.x * (kBlock / 64)) {
+        const uint32_t r = a.list[i];
+        const uint32_t full = a.seed_count[r] & 0x7FFFFFFFu;
+        const uint32_t cnt = min(full, a.seed_slots);
+        if (full > a.seed_slots || cnt > kSortSeedsMax) continue;        // (more seeds than slots: the batch is redone anyway)
+        for (uint32_t j = lane; j < cnt; j += 64) raw[j] = a.seed_win[(size_t)j * a.n_reads + r];
+        wave_sync();
+        for (uint32_t j = lane; j < cnt; j += 64) {
+            const uint32_t v = raw[j];
+            uint32_t rank = 0;
+            for (uint32_t x = 0; x < cnt; x++) { const uint32_t o = raw[x]; rank += (o < v || (o == v && x < j)) ? 1u : 0u; }
+            sorted[rank] = v;
+            a.seed_win[(size_t)rank * a.n_reads + r] = v;
+        }
+        wave_sync();
+        uint32_t flags = kRecAscending;
+        if (a.split && cnt > kSplitMin) {
+            for (uint32_t j = lane; j < cnt; j += 64) raw[j] = a.win_rec[sorted[j]].graph;
+            wave_sync();
+            if (lane == 0) {
+                const uint32_t target = max(kSplitMin, (cnt + kSplitMaxItems - 1) / kSplitMaxItems);
+                uint32_t lo = 0, x = 0, ns = 0, graphs = 0;
+                while (x < cnt) {
+                    const uint32_t g = raw[x];
+                    while (x < cnt && raw[x] == g) x++;
+                    graphs++;
+                    if (x - lo >= target || x == cnt) { seg[ns++] = x; lo = x; }
+                }
+                // (a short last item joins the one before it)
+                if (ns > 1 && seg[ns - 1] - seg[ns - 2] < kSplitMin / 2) { seg[ns - 2] = seg[ns - 1]; ns--; }
+                uint32_t j0 = kEmpty;
+                if (ns > 1) {
+                    j0 = atomicAdd(&a.vcount[0], ns - 1);
+                    if (j0 > a.vcap || ns - 1 > a.vcap - j0) {                 // no room: the slots taken stay empty, the read stays whole
+                        for (uint32_t j = j0; j < min(j0 + ns - 1, a.vcap); j++) a.vitem[j] = make_uint4(kEmpty, 0, 0, 0);
+                        j0 = kEmpty;
+                    }
+                }
+                seg[kSplitMaxItems] = ns; seg[kSplitMaxItems + 1] = j0; seg[kSplitMaxItems + 2] = graphs;
+            }
+            wave_sync();
+            const uint32_t ns = seg[kSplitMaxItems], j0 = seg[kSplitMaxItems + 1];
+            if (ns > 1 && j0 != kEmpty) {
+                for (uint32_t k = 1 + lane; k < ns; k += 64) a.vitem[j0 + k - 1] = make_uint4(r, seg[k - 1], seg[k], 0);
+                if (lane == 0) {
+                    const uint32_t si = atomicAdd(&a.vcount[1], 1u);      // (at most one per entry of the list: si < kLongListCap)
+                    a.split_list[si] = make_uint4(r, j0, ns - 1, 0);
+                    if (a.update_weights && seg[kSplitMaxItems + 2] > 1) atomicAdd(&a.ctr->multimapped, 1ull);   // boss.go:195-200
+                    uint32_t &cf = a.read_rec[r].cnt_flags;
+                    cf = (cf & ~kRecCountMask) | seg[0] | kRecSplit;
+                }
+            }
+            wave_sync();
+        }
+        if (lane == 0) a.read_rec[r].cnt_flags |= flags;
+    }
+}
+
+// after the align stage: the records of a split read's items follow each other in the read's (read, ord) run -- every item learns
+// how many records the read's earlier items made, the read's count becomes the sum
+__global__ __launch_bounds__(kBlock) void split_fix_kernel(const uint4 *__restrict__ split_list, const uint32_t *__restrict__ vcount, uint4 *__restrict__ vitem,
+                                                           uint32_t *__restrict__ trav_cnt, uint32_t n_reads, DeviceCounters *ctr)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= min(vcount[1], kLongListCap)) return;
+    const uint4 sl = split_list[i];
+    uint32_t base = trav_cnt[sl.x];
+    for (uint32_t j = sl.y; j < sl.y + sl.z; j++) {
+        vitem[j].w = base;
+        base += trav_cnt[n_reads + j];
+    }
+    if (base > 0xFFFFu) atomicOr(&ctr->flags, kFlagOrdOverflow);
+    trav_cnt[sl.x] = base;
+}
+
+// ... and the first record of every item goes to its place (the later ones: order_ovf_kernel)
+__global__ __launch_bounds__(kBlock) void order_split_kernel(const uint4 *__restrict__ vitem, const uint32_t *__restrict__ vcount, uint32_t vcap,
+                                                             const uint32_t *__restrict__ trav_cnt, const uint32_t *__restrict__ off, const groot_trav *__restrict__ first,
+                                                             const uint64_t *__restrict__ mask_first, uint32_t n_reads, uint32_t first_read_id, groot_trav *__restrict__ out,
+                                                             uint64_t *__restrict__ mask_out, uint32_t cap, uint32_t pw_in, uint32_t pw_out, DeviceCounters *ctr)
+{
+    const uint32_t nv = min(vcount[0], vcap);
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < nv; j += gridDim.x * kBlock) {
+        const uint4 vi = vitem[j];
+        if (vi.x == kEmpty || trav_cnt[n_reads + j] == 0) continue;
+        const uint32_t i = off[vi.x] + vi.w;
+        if (i >= cap) { atomicOr(&ctr->flags, kFlagTravOverflow); continue; }
+        groot_trav t = first[n_reads + j];
+        t.read_id = first_read_id + vi.x;
+        t.ord = (uint16_t)vi.w;
+        out[i] = t;
+        for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = mask_first[(size_t)(n_reads + j) * pw_in + w];
+    }
+}
+
 // One row of the call-count table per kmerCount that occurs among seeded reads (IncrementSubPath's numKmers,
 // graphminion.go:60-67): rows are handed out in ascending kmerCount order within a batch, after the seed stage and before
 // the align stage.  More kmerCounts than rows: kFlagQOverflow, the align stage does nothing, the host grows the table
 // and re-runs the batch.
 __global__ __launch_bounds__(64) void assign_q_rows_kernel(uint32_t *q_seen, uint32_t *q_row, uint32_t *q_of_row, uint32_t *n_rows, uint32_t cap,
-                                                            uint32_t max_q, DeviceCounters *ctr, unsigned long long *shards)
+                                                            uint32_t max_q, DeviceCounters *ctr, unsigned long long *shards, uint32_t *long_count)
 {
     // one wavefront: lane i folds shard i of the seed kernels' counters, then the kmerCounts are taken 64 at a time
     if (blockIdx.x) return;
+    if (!threadIdx.x) *long_count = 0;                      // (sort_seed_lists_kernel ran just before: ready for the next batch)
     const uint32_t lane = threadIdx.x;
     {
         unsigned long long seeds = 0, most = 0, seeded = 0, tabbed = 0;
@@ -1579,7 +1709,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
     // them, cursor 1 hands out the rest kWaveChunk slots at a time.  (Only atomics touch the cursors: an atomic LOAD at
     // agent scope in this loop halves the kernel's speed.)
     // reads without seeds sort last and have nothing to do here (the seed stage zeroed their traversal counts)
-    const uint32_t n_todo = a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads)) : a.n_reads;   // (scalar: it bounds every refill)
+    // (items of split reads come first: slot j < nv is AlignArgs::vitem[j], slot nv + i is position i of the processing order)
+    const uint32_t nv = a.vitem ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)*a.vcount), a.vcap) : 0u;
+    const uint32_t n_todo = nv + (a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads)) : a.n_reads);   // (scalar: it bounds every refill)
     // Lanes per round.  A round lasts as long as its slowest read, so when there are fewer reads than 64 per resident wavefront
     // (most of the batch was answered from the outcome table: what is left are the hard reads) the rounds are made smaller
     // and spread over all wavefronts: the launch then ends with the slowest read instead of the slowest sum of rounds.
@@ -1816,28 +1948,42 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
 #endif
             if (!have_read) {
                 GROOT_EV(3);
-                r = a.perm ? a.perm[slot] : slot;             // reads in (first seed window, orientation) order
+                const bool virt = slot < nv;                   // an item of a split read: seed positions [vlo, vhi) of its ascending list
+                uint32_t vlo = 0, vhi = 0;
+                if (virt) {
+                    const uint4 vi = a.vitem[slot];
+                    r = vi.x; vlo = vi.y; vhi = vi.z;
+                    if (r == kEmpty) { phase = PH_WAIT; continue; }   // (found no room: its read is handled whole)
+                } else {
+                    const uint32_t so = slot - nv;
+                    r = a.perm ? a.perm[so] : so;              // reads in (first seed window, orientation) order
+                }
                 uint4 ra, rb;                                     // one 32-byte record per read
                 load32(a.read_rec + r, ra, rb);                  // (gathering the records into processing order first costs more than this dependent trip)
                 const uint32_t sc = ra.w;
-                cnt = min(sc & kRecCountMask, a.seed_slots);   // overflow already flagged; batch is re-run
+                cnt = min(sc & (kRecSplit - 1u), a.seed_slots);   // overflow already flagged; batch is re-run
                 cls = a.perm ? (sc >> 24) & 0x3Fu : 0x80u;     // bit 7: no verdicts without the seed stage's sort keys
                 if (sc & kRecAscending) cls |= 0x100u;         // bit 8: the read's seed list is in ascending window order
+                // bit 9: the windows come from the list, not from the read record; bit 10: an item (mapped / multimapped are counted
+                // with the read's first item); bit 11: a split read (multimapped was counted when it was split)
+                if (sc & kRecSplit) cls |= 0xA00u;
+                if (virt) { cnt = min(vhi, a.seed_slots); cls = 0x80u | 0x100u | 0x200u | 0x400u; }
                 if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
                 high_byte = sc >> 31;
                 len = ra.z;
                 p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
                 sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
-                if (cnt > 4 && (cls & 0x100u)) sd0 = 0;        // (ascending list: sd0 is the position in it; else sd0 / sd1 = smallest / largest window)
+                if (cls & 0x200u) sd0 = vlo;                   // (ascending list: sd0 is the position in it; else sd0 / sd1 = smallest / largest window)
+                else if (cnt > 4 && (cls & 0x100u)) sd0 = 0;
                 GROOT_SUBT(0);
                 if (LDSR && 2 + 4 * ((len + 27) >> 4) > a.lds_stride_dw) {   // longer than the max_len the batch was submitted with
                     atomicOr(&a.ctr->flags, kFlagLongRead);
-                    a.trav_cnt[r] = 0;
+                    a.trav_cnt[(cls & 0x400u) ? a.n_reads + slot : r] = 0;
                     phase = PH_WAIT;
                     continue;
                 }
                 qrow = ix.q_row[len - ix.k + 1];              // graphminion.go:60 kmerCount -> its row of the call-count table
-                read_id = a.first_read_id + r;
+                read_id = a.first_read_id + ((cls & 0x400u) ? a.n_reads + slot : r);   // (an item labels its records with its own slot: order_ovf_kernel)
                 n_graphs = 0; ord = 0; last = -1;
                 done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
                 have_read = true;
@@ -1862,7 +2008,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
             GROOT_SUBT(1);
             // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
             uint32_t nw = kEmpty;
-            if (cnt <= 4) {                                   // the seeds travel in the read record
+            if (cnt <= 4 && !(cls & 0x200u)) {                // the seeds travel in the read record
                 if ((long long)sd0 > last && sd0 < nw) nw = sd0;
                 if (cnt > 1 && (long long)sd1 > last && sd1 < nw) nw = sd1;
                 if (cnt > 2 && (long long)sd2 > last && sd2 < nw) nw = sd2;
@@ -1901,15 +2047,15 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                     if (sl < 60) a.ctr->dbg[129 + sl] = (unsigned long long)r | ((unsigned long long)(wc_iter - wc_round0) << 32);
                 }
 #endif
-                a.trav_cnt[r] = ord;
-                mapped++;                                     // boss.go:195-200
-                if (n_graphs > 1) multimapped++;
+                a.trav_cnt[(cls & 0x400u) ? a.n_reads + slot : r] = ord;
+                if (!(cls & 0x400u)) mapped++;                // boss.go:195-200
+                if (!(cls & 0xC00u) && n_graphs > 1) multimapped++;
                 if (a.incr_cnt && n_graphs > 1) a.incr_cnt[r] |= 0x80000000u;   // (capture pass of groot_hip_open; the lane owns the read)
                 have_read = false;
                 phase = PH_WAIT;
                 continue;
             }
-            cls = (cls & 0xBFu) | ((last < 0 && !(cls & 0x80u)) ? 0x40u : 0u);   // bit 6: w is the read's first seed window
+            cls = (cls & ~0x40u) | ((last < 0 && !(cls & 0x80u)) ? 0x40u : 0u);   // bit 6: w is the read's first seed window
             w = nw; last = nw;
             uint4 wa, wb;                                     // the whole lshe.Key in one 32-byte load
             load32(ix.win_rec + w, wa, wb);
@@ -2068,9 +2214,10 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALI
                             t.flags = (uint8_t)(tflags | (emitted == 0 ? GROOT_TRAV_FIRST : 0));
                             t.reserved = 0;
                             if (ord == 0) {                    // the common case: no allocation at all
-                                a.trav_first[r] = t;
+                                const uint32_t os = (cls & 0x400u) ? a.n_reads + slot : r;
+                                a.trav_first[os] = t;
 #pragma unroll
-                                for (int i = 0; i < PW; i++) a.mask_first[(size_t)r * PW + i] = mask[i];
+                                for (int i = 0; i < PW; i++) a.mask_first[(size_t)os * PW + i] = mask[i];
                             } else {
                                 const uint32_t shard = blockIdx.x & (kOvfShards - 1);
                                 const uint32_t slot = atomicAdd(&a.ovf_cnt[shard], 1u);
@@ -2353,14 +2500,21 @@ __global__ __launch_bounds__(kBlock) void order_first_kernel(const groot_trav *f
 __global__ __launch_bounds__(kBlock) void order_ovf_kernel(const groot_trav *ovf, const uint64_t *ovf_mask, const uint32_t *ovf_cnt,
                                                          uint32_t ovf_cap, const uint32_t *off, uint32_t first_read_id, groot_trav *out,
                                                          uint64_t *mask_out, uint32_t cap, uint32_t pw_in, uint32_t pw_out,
-                                                         DeviceCounters *ctr)
+                                                         DeviceCounters *ctr, const uint4 *vitem, uint32_t n_reads)
 {
     const uint32_t shard = blockIdx.y;
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= min(ovf_cnt[shard], ovf_cap)) return;
     const size_t o = (size_t)shard * ovf_cap + slot;
-    const groot_trav t = ovf[o];
-    const uint32_t i = off[t.read_id - first_read_id] + t.ord;
+    groot_trav t = ovf[o];
+    uint32_t rid = t.read_id - first_read_id, ord = t.ord;
+    if (rid >= n_reads) {                                  // a record of an item of a split read (AlignArgs::vitem)
+        const uint4 vi = vitem[rid - n_reads];
+        rid = vi.x; ord += vi.w;
+        t.read_id = first_read_id + rid;
+        t.ord = (uint16_t)ord;
+    }
+    const uint32_t i = off[rid] + ord;
     if (i >= cap) { atomicOr(&ctr->flags, kFlagTravOverflow); return; }
     out[i] = t;
     for (uint32_t w = 0; w < pw_out; w++) mask_out[(size_t)i * pw_out + w] = ovf_mask[o * pw_in + w];
