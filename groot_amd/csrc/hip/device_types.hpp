@@ -236,6 +236,8 @@ struct SeedArgs {
     uint32_t *long_list, *long_count; // reads with more than four seed windows that were not found in ascending order (sort_seed_lists_kernel); up to kLongListCap
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
+    uint32_t lsh_defer_rows;     // LSH-Forest branch: a read with more candidate rows than this goes to lsh_query_kernel (0: every read does), lsh_cap = room in lsh_list
+    uint32_t lsh_cap;
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
     DeviceCounters *ctr;
 };

@@ -183,6 +183,7 @@ struct groot_ctx {
     DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
     DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
     uint32_t vcap = 0;
+    uint32_t lsh_defer_rows = 0, lsh_cap = 0;            // SeedArgs::lsh_defer_rows
     DevBuf<unsigned long long> seed_shards;
     DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch + their sketches, for lsh_query_kernel (absent: per-lane row walks)
     DevBuf<uint64_t> lsh_sketch;
@@ -658,6 +659,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     if (s->text_used) c->batches_without_text = 0;
     if (c->lsh_list.p && !c->prm.keep_sketches) {
         a.lsh_list = c->lsh_list.p; a.lsh_count = c->lsh_count.p; a.lsh_sketch = c->lsh_sketch.p;
+        a.lsh_defer_rows = c->lsh_defer_rows; a.lsh_cap = c->lsh_cap;
         HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, sizeof(uint32_t), c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(c->vcount.p, 0, 2 * sizeof(uint32_t), c->stream));
@@ -2198,10 +2200,15 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     // every workload measured (2.46 vs ~0.8 ms for 720 000 mixed-length reads at t = 0.95: the rows of a lane are consecutive 32-byte
     // records, four to a cache line, which a lane walks at ~0.3 us per row; a dealt row costs a bisection, a cold line and LDS
     // traffic, ~3 us per step of 64).  Opt-in for experiments: GROOT_LSH_KERNEL=1.
-    if (c->l_max <= kLshMaxBands && getenv("GROOT_LSH_KERNEL")) {
-        HIP_TRY(c, c->lsh_list.alloc(R));
+    // Handing it only the reads with many candidate rows (GROOT_LSH_DEFER=rows: a lane walking a thousand rows while 63 wait) does
+    // not pay either: resfinder.90, 2 M reads of 75..150 bases, seed stage 2.2 ms without it, 4.3 / 6.4 / 2.2 ms at 64 / 256 / 1024 rows.
+    if (c->l_max <= kLshMaxBands && (getenv("GROOT_LSH_KERNEL") || getenv("GROOT_LSH_DEFER"))) {
+        c->lsh_defer_rows = 0u;
+        if (const char *e = getenv("GROOT_LSH_DEFER")) c->lsh_defer_rows = (uint32_t)std::max(0, atoi(e));
+        c->lsh_cap = c->lsh_defer_rows ? std::max<uint32_t>(4096, R / 8) : R;
+        HIP_TRY(c, c->lsh_list.alloc(c->lsh_cap));
         HIP_TRY(c, c->lsh_count.alloc(1));
-        HIP_TRY(c, c->lsh_sketch.alloc((size_t)R * s));
+        HIP_TRY(c, c->lsh_sketch.alloc((size_t)c->lsh_cap * s));
     }
     HIP_TRY(c, c->todo_list.alloc(R));
     HIP_TRY(c, c->todo_count.alloc(1));

@@ -364,6 +364,7 @@ __device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint3
 // cmd/index.go:45-49): the minima then live in an array indexed at run time (private memory), which is correct and slow;
 // the sizes people use have compiled instances.
 constexpr int kGenericMaxS = 256;      // largest sketch the run-time-sized instance handles
+constexpr int kGenericMaxBands = kGenericMaxS;   // ... and the most bands (sketch size / maxK >= 1)
 // (the S running minima are 2 S registers: at GROOT_SEED_WAVES waves per SIMD (~100 VGPRs) sketch sizes above 30 spilled them --
 // 20 ms per 2 M reads at S = 64.  Larger sketches get fewer, larger waves: 3 per SIMD up to S = 48, 2 beyond)
 constexpr int seed_waves(int S) { return S == 0 ? 1 : (S <= 30 ? GROOT_SEED_WAVES : (S <= 48 ? 3 : 2)); }
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             for (int i = 0; i < s_; i++) same &= ws[i] == m[i];
             if (same) hit(e.id);
         }
-    } else if (min_eq < (uint32_t)s_ && a.lsh_list) {
+    } else if (min_eq < (uint32_t)s_ && a.lsh_list && !a.lsh_defer_rows) {
         // General LSH Forest query, deferred: the sketch goes to lsh_query_kernel, which deals the rows of equal band prefix of a
         // wavefront's 64 reads over its lanes (here every lane would walk its own rows -- a few to a few hundred -- while the
         // others wait: 8 % of the lane slots doing work)
@@ -566,11 +567,18 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
         uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < sl_; i++) rs[i >> 2] |= sig8(m[i]) << (8 * (i & 3));
+        // the rows of equal prefix in every band first: a read with many of them (a sequence that dozens of graphs share) would keep
+        // its lane walking while the other 63 wait -- it goes to lsh_query_kernel, which deals a wavefront's rows over its lanes
+        // (the run-time-sized instance has room for kGenericMaxBands = kGenericMaxS bands)
+        constexpr int LB_ = (S && MAXK) ? (S / MAXK > 0 ? S / MAXK : 1) : kGenericMaxBands;
+        uint32_t b_lo[LB_], b_end[LB_];
+        uint32_t rows = 0;
 #pragma unroll
         for (int b = 0; b < lmax_; b++) {
-            if ((uint32_t)b >= L) break;
+            if (b >= LB_) break;
+            b_lo[b] = n; b_end[b] = n;
+            if ((uint32_t)b >= L) continue;
             const uint32_t *keys = ix.band_keys + (size_t)b * n * maxk_;
-            const uint32_t *ids = ix.band_ids + (size_t)b * n;
             auto cmp = [&](uint32_t e) {      // -1 / 0 / +1 : table entry e vs query prefix
                 const uint32_t *ke = keys + (size_t)e * maxk_;
 #pragma unroll
@@ -596,8 +604,26 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
                     if (e.tag == tag && cmp(e.id) == 0) { lo = e.id; break; }
                 }
             }
+            b_lo[b] = lo;
+            b_end[b] = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
+            rows += b_end[b] - lo;
+        }
+        if (a.lsh_list && rows > a.lsh_defer_rows) {
+            const uint32_t pos = atomicAdd(a.lsh_count, 1u);
+            if (pos < a.lsh_cap) {
+                a.lsh_list[pos] = r | (high ? 0x80000000u : 0u);
+                uint64_t *sk = a.lsh_sketch + (size_t)pos * s_;
+#pragma unroll
+                for (int i = 0; i < s_; i++) sk[i] = m[i];
+                return;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < lmax_; b++) {
+            if ((uint32_t)b >= L || b >= LB_) break;
+            const uint32_t *ids = ix.band_ids + (size_t)b * n;
             const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * 32);
-            const uint32_t e_end = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
+            const uint32_t lo = b_lo[b], e_end = b_end[b];
             for (uint32_t e = lo; e < e_end; e++) {
                 // slots whose signature bytes agree (pad bytes are zero on both sides): an upper bound of the equal slots
                 // (this filter is most of the branch's time -- runs of ~40 rows per band: only the dwords that hold slots, and the
@@ -1048,7 +1074,7 @@ __global__ __launch_bounds__(kBlock) void lsh_query_kernel(SeedArgs a)
     uint32_t *qfirst = qcnt + 64;              // [64] first of them
     uint32_t *queue = qfirst + 64;             // [kLshQueue][2]: owner | band << 8, window
     auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    const uint32_t n_list = *a.lsh_count;
+    const uint32_t n_list = a.lsh_cap ? min(*a.lsh_count, a.lsh_cap) : *a.lsh_count;
     for (uint32_t base = (blockIdx.x * (kBlock / 64) + wave) * 64; base < n_list; base += gridDim.x * kBlock) {
         const uint32_t li = base + lane;
         const bool valid = li < n_list;
