@@ -81,7 +81,7 @@ static_assert(sizeof(ReadRec) == 32, "read record is two 16-byte words");
 constexpr uint32_t kRecCountMask = 0x00FFFFFFu;
 constexpr uint32_t kRecNo12F = 1u << 24, kRecNo3F = 1u << 25, kRecNo4F = 1u << 26;   // R = F << 3
 constexpr uint32_t kRecAscending = 1u << 30;                // cnt_flags: the read's seed windows were written in ascending order
-constexpr uint32_t kLongListCap = 1u << 16, kSortSeedsMax = 1024;   // sort_seed_lists_kernel: reads per batch, seed windows per read
+constexpr uint32_t kLongListCap = 1u << 20, kSortSeedsMax = 512;   // sort_seed_lists_kernel: reads per batch, seed windows per read
 // A read with more than kSplitMin seed windows is handled by several lanes of the align stage: its ascending window list is cut at
 // graph boundaries into items of at least kSplitMin windows (graphminion.go:46-102 treats the graphs of a read independently of
 // each other; only the order of the records and the per-read counters tie them together, and those are put right afterwards).

@@ -711,7 +711,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         sa.split = c->vcap && !c->tab_capture && !c->prm.no_exact_align;
         sa.vitem = c->vitem.p; sa.vcount = c->vcount.p; sa.vcap = c->vcap; sa.split_list = c->split_list.p;
         sa.ctr = s->d_ctr.p; sa.update_weights = update_weights ? 1 : 0;
-        hipLaunchKernelGGL(sort_seed_lists_kernel, dim3(512), dim3(kBlock), 0, c->stream, sa);
+        hipLaunchKernelGGL(sort_seed_lists_kernel, dim3(2048), dim3(kBlock), 0, c->stream, sa);
     }
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(64), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
@@ -812,7 +812,7 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
     const uint32_t n = s->n_reads;
     size_t tmp_bytes = 0;
     // split reads: their items' counts become the read's count, every item learns where its records go in the read's run
-    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(kLongListCap / kBlock), dim3(kBlock), 0, c->stream, c->split_list.p, c->vcount.p, c->vitem.p, c->trav_cnt.p, n, s->d_ctr.p);
+    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(256), dim3(kBlock), 0, c->stream, c->split_list.p, c->vcount.p, c->vitem.p, c->trav_cnt.p, n, s->d_ctr.p);
     HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
     if (tmp_bytes > c->scan_tmp.n) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));

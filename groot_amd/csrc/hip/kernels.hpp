@@ -1507,16 +1507,17 @@ __global__ __launch_bounds__(kBlock) void sort_seed_lists_kernel(SplitArgs a)
 __global__ __launch_bounds__(kBlock) void split_fix_kernel(const uint4 *__restrict__ split_list, const uint32_t *__restrict__ vcount, uint4 *__restrict__ vitem,
                                                            uint32_t *__restrict__ trav_cnt, uint32_t n_reads, DeviceCounters *ctr)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= min(vcount[1], kLongListCap)) return;
-    const uint4 sl = split_list[i];
-    uint32_t base = trav_cnt[sl.x];
-    for (uint32_t j = sl.y; j < sl.y + sl.z; j++) {
-        vitem[j].w = base;
-        base += trav_cnt[n_reads + j];
+    const uint32_t ns = min(vcount[1], kLongListCap);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        const uint4 sl = split_list[i];
+        uint32_t base = trav_cnt[sl.x];
+        for (uint32_t j = sl.y; j < sl.y + sl.z; j++) {
+            vitem[j].w = base;
+            base += trav_cnt[n_reads + j];
+        }
+        if (base > 0xFFFFu) atomicOr(&ctr->flags, kFlagOrdOverflow);
+        trav_cnt[sl.x] = base;
     }
-    if (base > 0xFFFFu) atomicOr(&ctr->flags, kFlagOrdOverflow);
-    trav_cnt[sl.x] = base;
 }
 
 // ... and the first record of every item goes to its place (the later ones: order_ovf_kernel)
