@@ -696,7 +696,9 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     }
-    if (a.lsh_list) {       // the reads the hashing kernels found on the LSH-Forest branch: their queries, a wavefront per 64 of them
+    if (a.lsh_list && a.lsh_defer_rows) {   // the reads with many candidate rows on the LSH-Forest branch: a wavefront per read
+        hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, 2048u)), dim3(kBlock), 0, c->stream, a);
+    } else if (a.lsh_list) {                // (experiments: every read of that branch, a wavefront per 64 of them)
         const size_t lds = (size_t)(kBlock / 64) * lsh_wave_lds_dw(c->l_max) * sizeof(uint32_t);
         hipLaunchKernelGGL(lsh_query_kernel, dim3(std::min<uint32_t>(grid.x, 1024u)), dim3(kBlock), lds, c->stream, a);
     }
@@ -2202,10 +2204,10 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     // traffic, ~3 us per step of 64).  Opt-in for experiments: GROOT_LSH_KERNEL=1.
     // Handing it only the reads with many candidate rows (GROOT_LSH_DEFER=rows: a lane walking a thousand rows while 63 wait) does
     // not pay either: resfinder.90, 2 M reads of 75..150 bases, seed stage 2.2 ms without it, 4.3 / 6.4 / 2.2 ms at 64 / 256 / 1024 rows.
-    if (c->l_max <= kLshMaxBands && (getenv("GROOT_LSH_KERNEL") || getenv("GROOT_LSH_DEFER"))) {
-        c->lsh_defer_rows = 0u;
+    if (c->l_max <= kLshMaxBands && !getenv("GROOT_NO_LSH_KERNEL")) {
+        c->lsh_defer_rows = getenv("GROOT_LSH_KERNEL") ? 0u : 64u;
         if (const char *e = getenv("GROOT_LSH_DEFER")) c->lsh_defer_rows = (uint32_t)std::max(0, atoi(e));
-        c->lsh_cap = c->lsh_defer_rows ? std::max<uint32_t>(4096, R / 8) : R;
+        c->lsh_cap = c->lsh_defer_rows ? std::max<uint32_t>(4096, R / 4) : R;
         HIP_TRY(c, c->lsh_list.alloc(c->lsh_cap));
         HIP_TRY(c, c->lsh_count.alloc(1));
         HIP_TRY(c, c->lsh_sketch.alloc((size_t)c->lsh_cap * s));

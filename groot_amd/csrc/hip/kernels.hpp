@@ -363,6 +363,10 @@ __device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint3
 // S = 0 / MAXK = 0: sketch size and hash functions per band are taken from the index at run time (any `groot index -s / -y`,
 // cmd/index.go:45-49): the minima then live in an array indexed at run time (private memory), which is correct and slow;
 // the sizes people use have compiled instances.
+#ifndef GROOT_LSH_ROWS_AHEAD
+#define GROOT_LSH_ROWS_AHEAD 1   // (2 and 4 rows fetched together cost more in spilled registers than the round trips they save: 587 / 579 vs 633 Mreads/s on the mixed-length leg)
+#endif
+constexpr uint32_t kLshHeavyMaxS = 64;   // lsh_heavy_kernel keeps the read's sketch in LDS
 constexpr int kGenericMaxS = 256;      // largest sketch the run-time-sized instance handles
 constexpr int kGenericMaxBands = kGenericMaxS;   // ... and the most bands (sketch size / maxK >= 1)
 // (the S running minima are 2 S registers: at GROOT_SEED_WAVES waves per SIMD (~100 VGPRs) sketch sizes above 30 spilled them --
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             b_end[b] = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
             rows += b_end[b] - lo;
         }
-        if (a.lsh_list && rows > a.lsh_defer_rows) {
+        if (a.lsh_list && rows > a.lsh_defer_rows && (uint32_t)s_ <= kLshHeavyMaxS) {
             const uint32_t pos = atomicAdd(a.lsh_count, 1u);
             if (pos < a.lsh_cap) {
                 a.lsh_list[pos] = r | (high ? 0x80000000u : 0u);
@@ -624,11 +628,24 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             const uint32_t *ids = ix.band_ids + (size_t)b * n;
             const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * 32);
             const uint32_t lo = b_lo[b], e_end = b_end[b];
-            for (uint32_t e = lo; e < e_end; e++) {
+            // (rows are 32 consecutive bytes each: kRowsAhead of them are fetched together -- the walk is a chain of round trips, 790
+            // load instructions per wavefront and read on mixed-length batches, two thirds of the kernel's time spent waiting)
+            constexpr uint32_t kRowsAhead = GROOT_LSH_ROWS_AHEAD;
+            for (uint32_t e4 = lo; e4 < e_end; e4 += kRowsAhead) {
+            uint4 rowa[kRowsAhead], rowb[kRowsAhead];
+#pragma unroll
+            for (uint32_t i = 0; i < kRowsAhead; i++) {
+                const size_t ee = min(e4 + i, e_end - 1u);
+                rowa[i] = sigs[2 * ee]; rowb[i] = sigs[2 * ee + 1];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kRowsAhead; i++) {
+                const uint32_t e = e4 + i;
+                if (e >= e_end) break;
                 // slots whose signature bytes agree (pad bytes are zero on both sides): an upper bound of the equal slots
                 // (this filter is most of the branch's time -- runs of ~40 rows per band: only the dwords that hold slots, and the
                 // cheap zero-byte test, which may also flag a byte of value 1 above an equal one: an upper bound still)
-                const uint4 sa = sigs[2 * (size_t)e], sb = sigs[2 * (size_t)e + 1];
+                const uint4 sa = rowa[i], sb = rowb[i];
                 const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
                 const int nd = (sl_ + 3) >> 2;
                 uint32_t same = 0;
@@ -657,6 +674,7 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
 #pragma unroll
                 for (int i = lmax_ * maxk_; i < s_; i++) eq += ws[i] == m[i];
                 if (!earlier && eq >= min_eq) hit(id);
+            }
             }
         }
     }
@@ -1213,6 +1231,117 @@ __global__ __launch_bounds__(kBlock) void lsh_query_kernel(SeedArgs a)
         }
         verify();
         if (valid) seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0, false, 0, 0, nullptr, asc, max_win);
+    }
+}
+
+// K2, LSH-Forest branch, the heavy reads: lsh_heavy_kernel -- a WAVEFRONT per read.
+// The hashing kernels look up a read's rows of equal prefix in all bands before walking any of them; a read with more than
+// SeedArgs::lsh_defer_rows of them (a gene family: dozens of alleles times two dozen window offsets) is handed over with its sketch.
+// Here the 64 lanes take the read's rows 64 at a time -- signature filter, then the exact count of equal slots against the sketch
+// in LDS, both by the lane that holds the row -- and append the windows that pass to the read's seed slots (order of arrival: the
+// align stage takes a read's windows in ascending order whatever their order in the list).  Same rows, same tests as the per-lane
+// branch of sketch_seed_kernel (lshe.go:153-175).
+__global__ __launch_bounds__(kBlock) void lsh_heavy_kernel(SeedArgs a)
+{
+    __shared__ uint64_t sk_lds[(kBlock / 64) * kLshHeavyMaxS];
+    __shared__ uint32_t aux_lds[(kBlock / 64) * (2 * kLshMaxBands + 16)];
+    const DeviceIndex &ix = a.ix;
+    const uint32_t S = ix.s, maxk = ix.max_k, LB = ix.l_max, n = ix.n_windows;
+    const uint32_t sl = S < 32 ? S : 32, nd = (sl + 3) >> 2;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *m = sk_lds + wave * kLshHeavyMaxS;
+    uint32_t *blo = aux_lds + wave * (2 * kLshMaxBands + 16);   // [LB] first row per band
+    uint32_t *bcum = blo + kLshMaxBands;                        // [LB + 1] rows before band b
+    uint32_t *sc = bcum + kLshMaxBands + 1;                     // [0] hits [1] min [2] max [4..7] the first four
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const uint32_t n_list = min(*a.lsh_count, a.lsh_cap);
+    for (uint32_t li = blockIdx.x * (kBlock / 64) + wave; li < n_list; li += gridDim.x * (kBlock / 64)) {
+        const uint32_t e0 = a.lsh_list[li];
+        const uint32_t r = e0 & 0x7FFFFFFFu, high = e0 >> 31;
+        const uint64_t o0 = a.seq_off[r];
+        const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
+        const uint32_t q = len - ix.k + 1;
+        const uint32_t K = ix.q_k[q], L = min((uint32_t)ix.q_l[q], LB), min_eq = ix.q_min_eq[q];
+        const uint64_t *sk = a.lsh_sketch + (size_t)li * S;
+        if (lane < S) m[lane] = sk[lane];
+        if (lane < 8) sc[lane] = lane == 1 ? kEmpty : 0u;
+        wave_sync();
+        if (lane < LB) {                                       // lane b: the rows of equal prefix in band b
+            const uint32_t b = lane;
+            uint32_t lo = n, run = 0;
+            if (b < L && K >= 1) {
+                const uint32_t *keys = ix.band_keys + (size_t)b * n * maxk;
+                uint64_t hk = GROOT_SKETCH_HASH_INIT;
+                for (uint32_t j = 0; j < K; j++) hk = sketch_hash_step(hk, (uint32_t)m[b * maxk + j]);
+                const ExactEntry *tab = ix.band_hash + (((size_t)b * maxk + (K - 1)) << ix.band_hash_bits);
+                const uint32_t hmask = (1u << ix.band_hash_bits) - 1u, tag = (uint32_t)(hk >> 32);
+                for (uint32_t slot = (uint32_t)hk & hmask;; slot = (slot + 1) & hmask) {
+                    const ExactEntry e = tab[slot];
+                    if (e.id == kEmpty) break;
+                    if (e.tag != tag) continue;
+                    bool same = true;
+                    for (uint32_t j = 0; j < K; j++) same &= keys[(size_t)e.id * maxk + j] == (uint32_t)m[b * maxk + j];
+                    if (same) { lo = e.id; break; }
+                }
+                if (lo < n) run = ix.band_run[((size_t)b * maxk + (K - 1)) * n + lo];
+            }
+            blo[b] = lo;
+            bcum[b + 1] = run;
+        }
+        if (lane == 0) bcum[0] = 0;
+        wave_sync();
+        if (lane == 0) for (uint32_t b = 0; b < LB; b++) bcum[b + 1] += bcum[b];
+        wave_sync();
+        const uint32_t T = bcum[LB];
+        uint32_t rs[8];
+#pragma unroll
+        for (uint32_t wd = 0; wd < 8; wd++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (4 * wd + i < sl) v |= sig8(m[4 * wd + i]) << (8 * i);
+            rs[wd] = v;
+        }
+        for (uint32_t t = lane; t < T; t += 64) {
+            uint32_t b = 0;
+            while (b + 1 < LB && bcum[b + 1] <= t) b++;
+            const uint32_t e = blo[b] + (t - bcum[b]);
+            const uint4 *sg = reinterpret_cast<const uint4 *>(ix.band_sig + ((size_t)b * n + e) * 32);
+            const uint4 sa = sg[0], sb = sg[1];
+            const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            uint32_t same = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                if (i >= nd) break;
+                const uint32_t x = ws8[i] ^ rs[i];
+                same += __popc((x - 0x01010101u) & ~x & 0x80808080u);
+            }
+            if (same - (4u * nd - sl) + (S - sl) < min_eq) continue;
+            const uint32_t id = ix.band_ids[(size_t)b * n + e];
+            const uint64_t *ws = ix.win_sketch + (size_t)id * S;
+            uint32_t eq = 0;
+            bool earlier = false;
+            for (uint32_t bb = 0; bb < LB; bb++) {
+                bool pm = true;
+                for (uint32_t j = 0; j < maxk; j++) {
+                    const uint64_t wv = ws[bb * maxk + j], mv = m[bb * maxk + j];
+                    eq += wv == mv;
+                    if (j < K) pm &= (uint32_t)wv == (uint32_t)mv;
+                }
+                if (bb < b && pm) earlier = true;
+            }
+            for (uint32_t i = LB * maxk; i < S; i++) eq += ws[i] == m[i];
+            if (earlier || eq < min_eq) continue;
+            const uint32_t pos = atomicAdd(&sc[0], 1u);
+            if (pos < a.seed_slots) a.seed_win[(size_t)pos * a.n_reads + r] = id;
+            if (pos < 4) sc[4 + pos] = id;
+            atomicMin(&sc[1], id);
+            atomicMax(&sc[2], id);
+        }
+        wave_sync();
+        if (lane == 0) seed_epilogue(a, r, o0, len, q, sc[0], sc[1], sc[0] > 0 ? sc[4] : kEmpty, sc[0] > 1 ? sc[5] : kEmpty, sc[0] > 2 ? sc[6] : kEmpty,
+                                     sc[0] > 3 ? sc[7] : kEmpty, high != 0, false, 0, 0, nullptr, false, sc[2]);
+        wave_sync();
     }
 }
 

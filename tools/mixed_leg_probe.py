@@ -12,7 +12,7 @@ from groot_amd import device, host, synth
 t = float(sys.argv[1]) if len(sys.argv) > 1 else 0.99
 mrl = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-R = 2_000_000
+R = int(os.environ.get("READS", 2_000_000))
 index, _ = bench.load_index("resfinder.90")
 dev = torch.device("cuda", 0)
 cat, off, lens = synth.reference_sequences(index)
