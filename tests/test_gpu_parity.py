@@ -600,3 +600,32 @@ def test_wave_cooperative_lsh_query_kernel(resfinder_index, threshold, monkeypat
     assert_same(al, counts, run, index)
     assert counts["seeds"] > counts["mapped"] > 1000
     al.close()
+
+
+@pytest.mark.parametrize("variant", ["default", "no_split", "no_heavy_kernel"])
+def test_reads_with_many_seed_windows(argannot_index, monkeypatch, variant):
+    """reads shorter than the windows at a low threshold bring dozens of seed windows, of several graphs: their lists are sorted and
+    cut at graph boundaries into items that different lanes of the align stage take (device_types.hpp kSplitMin; records and
+    counters put right by split_fix / order_split / order_ovf), and reads with many candidate rows on the LSH-Forest branch get a
+    wavefront each (lsh_heavy_kernel).  Seeds, records in (read, ord) order, counters and call counts equal the oracle's
+    (lshe.go:153-175, graphminion.go:46-102) -- and equal what the ctx produces with either mechanism switched off"""
+    for v in ("GROOT_NO_SPLIT", "GROOT_NO_LSH_KERNEL", "GROOT_LSH_KERNEL", "GROOT_LSH_DEFER"):
+        monkeypatch.delenv(v, raising=False)
+    if variant == "no_split":
+        monkeypatch.setenv("GROOT_NO_SPLIT", "1")
+    if variant == "no_heavy_kernel":
+        monkeypatch.setenv("GROOT_NO_LSH_KERNEL", "1")
+    index = argannot_index
+    cat, o, lens = synth.reference_sequences(index)
+    seq, off, _ = synth.reads_np(cat, o, lens, 12000, 99, min_len=70)
+    al, counts, run = run_both(index, seq, off, threshold=0.9, max_read_len=128)
+    per = np.bincount(run.seeds()["read_id"], minlength=12000)
+    assert (per > 16).sum() >= 20, "the sample holds too few reads with many seed windows: enlarge it"
+    assert_same(al, counts, run, index)
+    # the same batch again, twice: nothing of the first pass lingers (items, lists, counters of the split)
+    before = al.attempts().copy()
+    al.submit(seq, off)
+    c2 = al.wait()
+    assert c2["alignments"] == counts["alignments"] and c2["multimapped"] == counts["multimapped"]
+    assert np.array_equal(al.attempts().astype(np.int64), 2 * before.astype(np.int64))
+    al.close()
