@@ -236,8 +236,11 @@ struct SeedArgs {
     uint32_t *long_list, *long_count; // reads with more than four seed windows that were not found in ascending order (sort_seed_lists_kernel); up to kLongListCap
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
-    uint32_t lsh_defer_rows;     // LSH-Forest branch: a read with more candidate rows than this goes to lsh_query_kernel (0: every read does), lsh_cap = room in lsh_list
-    uint32_t lsh_cap;
+    // LSH-Forest branch (reads whose Containment > t needs fewer than all slots equal): lsh_route 0 = queried in the hashing kernel,
+    // reads with more than lsh_defer_rows candidate rows handed to lsh_heavy_kernel; 1 = every read to lsh_query_kernel (experiment);
+    // 2 = every read to lsh_lane_kernel (its own launch: few registers, rows fetched ahead), which hands the heavy ones on
+    uint32_t lsh_route, lsh_defer_rows, lsh_cap;
+    uint32_t *heavy_list, *heavy_count;   // route 2: positions in lsh_list of the reads lsh_heavy_kernel takes
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
     DeviceCounters *ctr;
 };

@@ -183,7 +183,8 @@ struct groot_ctx {
     DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
     DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
     uint32_t vcap = 0;
-    uint32_t lsh_defer_rows = 0, lsh_cap = 0;            // SeedArgs::lsh_defer_rows
+    uint32_t lsh_route = 0, lsh_defer_rows = 0, lsh_cap = 0;   // SeedArgs::lsh_route
+    DevBuf<uint32_t> heavy_list;
     DevBuf<unsigned long long> seed_shards;
     DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch + their sketches, for lsh_query_kernel (absent: per-lane row walks)
     DevBuf<uint64_t> lsh_sketch;
@@ -659,8 +660,9 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     if (s->text_used) c->batches_without_text = 0;
     if (c->lsh_list.p && !c->prm.keep_sketches) {
         a.lsh_list = c->lsh_list.p; a.lsh_count = c->lsh_count.p; a.lsh_sketch = c->lsh_sketch.p;
-        a.lsh_defer_rows = c->lsh_defer_rows; a.lsh_cap = c->lsh_cap;
-        HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, sizeof(uint32_t), c->stream));
+        a.lsh_route = c->lsh_route; a.lsh_defer_rows = c->lsh_defer_rows; a.lsh_cap = c->lsh_cap;
+        if (c->lsh_route == 2) { a.heavy_list = c->heavy_list.p; a.heavy_count = c->lsh_count.p + 1; }
+        HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, 2 * sizeof(uint32_t), c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(c->vcount.p, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[7], c->stream));
@@ -696,7 +698,12 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     }
-    if (a.lsh_list && a.lsh_defer_rows) {   // the reads with many candidate rows on the LSH-Forest branch: a wavefront per read
+    if (a.lsh_list && a.lsh_route != 1) {
+        // the reads of the LSH-Forest branch: a lane each; those with many candidate rows: a wavefront each
+        if (a.lsh_route == 2) {
+            if (c->l_max <= 8) hipLaunchKernelGGL((lsh_lane_kernel<8>), dim3(std::min<uint32_t>(grid.x, 4096u)), dim3(kBlock), 0, c->stream, a);
+            else hipLaunchKernelGGL((lsh_lane_kernel<16>), dim3(std::min<uint32_t>(grid.x, 4096u)), dim3(kBlock), 0, c->stream, a);
+        }
         hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, 2048u)), dim3(kBlock), 0, c->stream, a);
     } else if (a.lsh_list) {                // (experiments: every read of that branch, a wavefront per 64 of them)
         const size_t lds = (size_t)(kBlock / 64) * lsh_wave_lds_dw(c->l_max) * sizeof(uint32_t);
@@ -2204,12 +2211,19 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     // traffic, ~3 us per step of 64).  Opt-in for experiments: GROOT_LSH_KERNEL=1.
     // Handing it only the reads with many candidate rows (GROOT_LSH_DEFER=rows: a lane walking a thousand rows while 63 wait) does
     // not pay either: resfinder.90, 2 M reads of 75..150 bases, seed stage 2.2 ms without it, 4.3 / 6.4 / 2.2 ms at 64 / 256 / 1024 rows.
+    // Route 0 (default): the hashing kernels query in place and hand the reads with many rows to lsh_heavy_kernel.  Route 2
+    // (GROOT_LSH_ROUTE=2): the hashing kernels only sketch and every read of the branch is queried by lsh_lane_kernel, a launch of its
+    // own without the minima in registers and with rows fetched ahead -- measured slower too (mixed-length batch of 8 M reads, seed
+    // stage 8.1 vs 6.9 ms at t = 0.99, 14.0 vs 11.3 ms at t = 0.90: writing and re-reading the sketches costs more than the walk gains).
     if (c->l_max <= kLshMaxBands && !getenv("GROOT_NO_LSH_KERNEL")) {
-        c->lsh_defer_rows = getenv("GROOT_LSH_KERNEL") ? 0u : 64u;
-        if (const char *e = getenv("GROOT_LSH_DEFER")) c->lsh_defer_rows = (uint32_t)std::max(0, atoi(e));
-        c->lsh_cap = c->lsh_defer_rows ? std::max<uint32_t>(4096, R / 4) : R;
+        c->lsh_route = getenv("GROOT_LSH_KERNEL") ? 1u : 0u;
+        if (const char *e = getenv("GROOT_LSH_ROUTE")) c->lsh_route = (uint32_t)std::max(0, std::min(2, atoi(e)));
+        c->lsh_defer_rows = 64u;
+        if (const char *e = getenv("GROOT_LSH_DEFER")) c->lsh_defer_rows = (uint32_t)std::max(1, atoi(e));
+        c->lsh_cap = c->lsh_route ? R : std::max<uint32_t>(4096, R / 4);
         HIP_TRY(c, c->lsh_list.alloc(c->lsh_cap));
-        HIP_TRY(c, c->lsh_count.alloc(1));
+        HIP_TRY(c, c->heavy_list.alloc(c->lsh_cap));
+        HIP_TRY(c, c->lsh_count.alloc(4));
         HIP_TRY(c, c->lsh_sketch.alloc((size_t)c->lsh_cap * s));
     }
     HIP_TRY(c, c->todo_list.alloc(R));

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             for (int i = 0; i < s_; i++) same &= ws[i] == m[i];
             if (same) hit(e.id);
         }
-    } else if (min_eq < (uint32_t)s_ && a.lsh_list && !a.lsh_defer_rows) {
+    } else if (min_eq < (uint32_t)s_ && a.lsh_list && a.lsh_route != 0) {
         // General LSH Forest query, deferred: the sketch goes to lsh_query_kernel, which deals the rows of equal band prefix of a
         // wavefront's 64 reads over its lanes (here every lane would walk its own rows -- a few to a few hundred -- while the
         // others wait: 8 % of the lane slots doing work)
@@ -1234,6 +1234,126 @@ __global__ __launch_bounds__(kBlock) void lsh_query_kernel(SeedArgs a)
     }
 }
 
+// K2, LSH-Forest branch in a launch of its own: lsh_lane_kernel -- a lane per read, as in sketch_seed_kernel, but without the hashing
+// kernel's registers: the 21 minima are not live here (the sketch sits in HBM, written by the hashing kernel, and is read again
+// only to verify a row that passed the signature filter), so kLaneRowsAhead rows are fetched together without a spill and ten
+// wavefronts per SIMD hide the trips.  Same rows, same tests, same order of hits as the branch in sketch_seed_kernel
+// (lshe.go:153-175); reads with more than lsh_defer_rows rows go on to lsh_heavy_kernel.
+constexpr uint32_t kLaneRowsAhead = 4;
+template <int NB>
+__global__ __launch_bounds__(kBlock) void lsh_lane_kernel(SeedArgs a)
+{
+    static_assert(NB <= (int)kLshMaxBands, "bands");
+    const DeviceIndex &ix = a.ix;
+    const uint32_t S = ix.s, maxk = ix.max_k, LB = min(ix.l_max, (uint32_t)NB), n = ix.n_windows;
+    const uint32_t sl = S < 32 ? S : 32, nd = (sl + 3) >> 2;
+    const uint32_t n_list = min(*a.lsh_count, a.lsh_cap);
+    for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < n_list; li += gridDim.x * kBlock) {
+        const uint32_t e0 = a.lsh_list[li];
+        const uint32_t r = e0 & 0x7FFFFFFFu, high = e0 >> 31;
+        const uint64_t o0 = a.seq_off[r];
+        const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
+        const uint32_t q = len - ix.k + 1;
+        const uint32_t K = ix.q_k[q], L = min((uint32_t)ix.q_l[q], LB), min_eq = ix.q_min_eq[q];
+        const uint64_t *sk = a.lsh_sketch + (size_t)li * S;
+        uint32_t rs[8];
+#pragma unroll
+        for (uint32_t wd = 0; wd < 8; wd++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (4 * wd + i < sl) v |= sig8(sk[4 * wd + i]) << (8 * i);
+            rs[wd] = v;
+        }
+        uint32_t b_lo[NB], b_end[NB];
+        uint32_t rows = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < (uint32_t)NB; b++) {
+            b_lo[b] = n; b_end[b] = n;
+            if (b >= L || K < 1) continue;
+            const uint32_t *keys = ix.band_keys + (size_t)b * n * maxk;
+            uint64_t hk = GROOT_SKETCH_HASH_INIT;
+            for (uint32_t j = 0; j < K; j++) hk = sketch_hash_step(hk, (uint32_t)sk[b * maxk + j]);
+            const ExactEntry *tab = ix.band_hash + (((size_t)b * maxk + (K - 1)) << ix.band_hash_bits);
+            const uint32_t hmask = (1u << ix.band_hash_bits) - 1u, tag = (uint32_t)(hk >> 32);
+            uint32_t lo = n;
+            for (uint32_t slot = (uint32_t)hk & hmask;; slot = (slot + 1) & hmask) {
+                const ExactEntry e = tab[slot];
+                if (e.id == kEmpty) break;
+                if (e.tag != tag) continue;
+                bool same = true;
+                for (uint32_t j = 0; j < K; j++) same &= keys[(size_t)e.id * maxk + j] == (uint32_t)sk[b * maxk + j];
+                if (same) { lo = e.id; break; }
+            }
+            b_lo[b] = lo;
+            b_end[b] = lo < n ? lo + ix.band_run[((size_t)b * maxk + (K - 1)) * n + lo] : n;
+            rows += b_end[b] - lo;
+        }
+        if (a.heavy_list && rows > a.lsh_defer_rows && S <= kLshHeavyMaxS) {
+            const uint32_t pos = atomicAdd(a.heavy_count, 1u);
+            if (pos < a.lsh_cap) { a.heavy_list[pos] = li; continue; }
+        }
+        uint32_t n_hits = 0, min_win = kEmpty, max_win = 0, prev_id = 0;
+        uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;
+        bool asc = true;
+        auto hit = [&](uint32_t id) {
+            if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
+            if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
+            asc &= n_hits == 0 || id > prev_id;
+            prev_id = id;
+            n_hits++;
+            min_win = min(min_win, id);
+            max_win = max(max_win, id);
+        };
+#pragma unroll
+        for (uint32_t b = 0; b < (uint32_t)NB; b++) {
+            if (b >= L) break;
+            const uint32_t *ids = ix.band_ids + (size_t)b * n;
+            const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * 32);
+            const uint32_t lo = b_lo[b], e_end = b_end[b];
+            for (uint32_t e4 = lo; e4 < e_end; e4 += kLaneRowsAhead) {
+                uint4 rowa[kLaneRowsAhead], rowb[kLaneRowsAhead];
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneRowsAhead; i++) {
+                    const size_t ee = min(e4 + i, e_end - 1u);
+                    rowa[i] = sigs[2 * ee]; rowb[i] = sigs[2 * ee + 1];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneRowsAhead; i++) {
+                    const uint32_t e = e4 + i;
+                    if (e >= e_end) break;
+                    const uint4 sa = rowa[i], sb = rowb[i];
+                    const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+                    uint32_t same = 0;
+#pragma unroll
+                    for (uint32_t x8 = 0; x8 < 8; x8++) {
+                        if (x8 >= nd) break;
+                        const uint32_t x = ws8[x8] ^ rs[x8];
+                        same += __popc((x - 0x01010101u) & ~x & 0x80808080u);
+                    }
+                    if (same - (4u * nd - sl) + (S - sl) < min_eq) continue;
+                    const uint32_t id = ids[e];
+                    const uint64_t *ws = ix.win_sketch + (size_t)id * S;
+                    uint32_t eq = 0;
+                    bool earlier = false;
+                    for (uint32_t bb = 0; bb < LB; bb++) {
+                        bool pm = true;
+                        for (uint32_t j = 0; j < maxk; j++) {
+                            const uint64_t wv = ws[bb * maxk + j], mv = sk[bb * maxk + j];
+                            eq += wv == mv;
+                            if (j < K) pm &= (uint32_t)wv == (uint32_t)mv;
+                        }
+                        if (bb < b && pm) earlier = true;
+                    }
+                    for (uint32_t x = LB * maxk; x < S; x++) eq += ws[x] == sk[x];
+                    if (!earlier && eq >= min_eq) hit(id);
+                }
+            }
+        }
+        seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, high != 0, false, 0, 0, nullptr, asc, max_win);
+    }
+}
+
 // K2, LSH-Forest branch, the heavy reads: lsh_heavy_kernel -- a WAVEFRONT per read.
 // The hashing kernels look up a read's rows of equal prefix in all bands before walking any of them; a read with more than
 // SeedArgs::lsh_defer_rows of them (a gene family: dozens of alleles times two dozen window offsets) is handed over with its sketch.
@@ -1254,8 +1374,9 @@ __global__ __launch_bounds__(kBlock) void lsh_heavy_kernel(SeedArgs a)
     uint32_t *bcum = blo + kLshMaxBands;                        // [LB + 1] rows before band b
     uint32_t *sc = bcum + kLshMaxBands + 1;                     // [0] hits [1] min [2] max [4..7] the first four
     auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    const uint32_t n_list = min(*a.lsh_count, a.lsh_cap);
-    for (uint32_t li = blockIdx.x * (kBlock / 64) + wave; li < n_list; li += gridDim.x * (kBlock / 64)) {
+    const uint32_t n_list = a.heavy_list ? min(*a.heavy_count, a.lsh_cap) : min(*a.lsh_count, a.lsh_cap);
+    for (uint32_t hi = blockIdx.x * (kBlock / 64) + wave; hi < n_list; hi += gridDim.x * (kBlock / 64)) {
+        const uint32_t li = a.heavy_list ? a.heavy_list[hi] : hi;
         const uint32_t e0 = a.lsh_list[li];
         const uint32_t r = e0 & 0x7FFFFFFFu, high = e0 >> 31;
         const uint64_t o0 = a.seq_off[r];
