@@ -609,6 +609,15 @@ struct HasKey {     // reads the seed stage left for the align stage's graph wal
 #ifndef GROOT_SPAN_BITS
 #define GROOT_SPAN_BITS 6
 #endif
+// The list pass copies each read into its lane's LDS slice while five workgroups per CU still fit (reads up to ~104 bases: 1.77 vs 1.57
+// Greads/s on 100-base reads with errors); for longer reads it reads the bases from HBM -- the copy would cost the fifth wavefront
+// per SIMD and a dependent trip (seed stage of 8 M reads of 75..150 bases: 7.0 ms with the copy, 5.9 ms without).
+static uint32_t list_lds_stride(uint32_t stride_dw)
+{
+    static const char *force = getenv("GROOT_LIST_LDS");
+    if (force) return atoi(force) && (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
+    return kLdsReads + (uint64_t)kBlock * stride_dw * 4 <= 32 * 1024 ? stride_dw : 0;
+}
 static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     SeedArgs a{};
@@ -642,6 +651,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
+    static const uint32_t list_blocks = getenv("GROOT_LIST_GRID") ? (uint32_t)std::max(1, atoi(getenv("GROOT_LIST_GRID"))) : 1280u;   // workgroups of the list pass (grid-stride; 5 per CU)
     // a batch of one read length that is not on the exact-table branch (lower thresholds, reads shorter than the windows) would
     // send every read through the list: the full-width kernel alone is 25-30 % faster then (tools/threshold_probe.py)
     bool sig_useful = true;
@@ -670,7 +680,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
         const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;
-        a.list_stride_dw = (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
+        a.list_stride_dw = list_lds_stride(stride_dw);
         const size_t lds = kTextBad + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
         if (list_mode) {       // the reads left for the graph walk are a subset of the lookup's misses: the list pass appends them itself
@@ -684,16 +694,16 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         }
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
-        launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
+        launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
     } else if (s->sig_used) {
         // signature kernel first; what it cannot decide goes through the full-width kernel, read by read
         a.todo_list = c->todo_list.p;
         a.todo_count = c->todo_count.p;
         const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;     // the LIST pass copies each read into its lane's LDS slice
-        a.list_stride_dw = (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
+        a.list_stride_dw = list_lds_stride(stride_dw);
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
         const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;   // (+: the kernel reads whole register rows past a read)
-        launch_sig(c->s, a, s->max_len, grid, lds, dim3(std::min<uint32_t>(grid.x, 1024)), c->stream);
+        launch_sig(c->s, a, s->max_len, grid, lds, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
     } else {
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
