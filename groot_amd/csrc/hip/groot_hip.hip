@@ -808,7 +808,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     {
         // 8 zero bytes, then the read in whole 16-byte pieces up to 12 bytes past its end; odd dword stride = no bank conflicts
         const uint32_t stride = (2 + 4 * ((s->max_len + 27) / 16)) | 1u;
-        a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
+        a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 && !getenv("GROOT_ALIGN_NO_LDS") ? stride : 0;
     }
     if (c->tab_capture) {
         a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p; a.incr_cap = c->incr_cap;
