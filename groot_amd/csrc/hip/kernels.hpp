@@ -820,6 +820,8 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         *reinterpret_cast<uint4 *>(tab + 256 + 16 + 64 * tid) = ei;
     }
     if (tid < 128) badbits[tid] = 0;
+    __shared__ uint32_t list_cnt, list_base;               // the reads this workgroup leaves to the list pass
+    if (tid == 0) list_cnt = 0;
     // ---- stage this block's reads as 2-bit codes: one contiguous span, 16 bases per lane per load ----
     const uint32_t r0 = blockIdx.x * kBlock;
     const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
@@ -863,7 +865,25 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
             if (bits) fast = false;
         }
     }
-    if (!fast) { todo_push(a, r); return; }
+    {
+        // the reads left to the list pass (other lengths, bytes other than ACGT, the LSH-Forest branch): counted per workgroup -- one
+        // LDS atomic per wavefront, ONE global atomic per workgroup.  (One global atomic per wavefront on the single counter cost
+        // 0.9 of the kernel's 1.9 ms on 8 M mixed-length reads, where every wavefront has such reads: ~7 ns each.)  Every thread
+        // still here takes part; wavefronts that have left do not count at the barrier.
+        const unsigned long long here = __ballot(1), mb = __ballot(!fast);
+        const unsigned lane = tid & 63u;
+        const int leader = __ffsll(here) - 1;
+        uint32_t wave_base = 0;
+        if ((int)lane == leader && mb) wave_base = atomicAdd(&list_cnt, (uint32_t)__popcll(mb));
+        wave_base = __shfl(wave_base, leader);
+        __syncthreads();
+        if ((int)lane == leader && mb && wave_base == 0) list_base = atomicAdd(a.todo_count, list_cnt);
+        __syncthreads();
+        if (!fast) {
+            a.todo_list[list_base + wave_base + (uint32_t)__popcll(mb & ((1ULL << lane) - 1ULL))] = r;
+            return;
+        }
+    }
 
     // ---- top 32 bits of the running minima (khf.go:35-55) ----
     uint32_t m[S];
