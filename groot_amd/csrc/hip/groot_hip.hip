@@ -155,7 +155,7 @@ struct groot_ctx {
     DevBuf<uint32_t> tab_idx, tab_hist, incr_cnt, incr_win;
     DevBuf<uint4> text_tab;                // text_lookup_kernel: strings with a tabulated outcome, keyed by their bases
     uint64_t text_entries = 0;
-    uint32_t batches_without_text = 0;
+    uint32_t batches_without_text = 0, text_retry_gap = 8;   // the lookup is tried again after this many batches without it; the gap doubles (up to 256) while it keeps missing
     double text_hit_frac = 1.0;            // share of the latest batch's reads the outcome table answered: picks the first kernel of the seed stage
     std::vector<uint16_t> h_q_min_eq;      // host copy of DeviceIndex::q_min_eq: which seed kernel a batch of one read length gets
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
@@ -662,10 +662,10 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     s->sig_used = c->dix.sig && !c->prm.keep_sketches && sig_useful;
     // Which kernel sees the batch first?  When the outcome table answered most of the latest batch, the text lookup (no hashing at
     // all; what it does not find goes through the full-width kernel, read by read); else the signature kernel as before.
-    // (the share is only known exactly while the lookup runs: every eighth batch tries it again)
+    // (the share is only known exactly while the lookup runs: it is tried again after 8, 16, ... 256 batches)
     static const double list_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
     const bool list_mode = c->dfs_frac < list_below;       // few reads need the graph walk (the latest batch says so)
-    const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= 8;
+    const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= c->text_retry_gap;
     s->text_used = !c->prm.keep_sketches && c->dix.text_tab && c->dix.out_tab && text_try && s->max_len >= c->dix.w && !c->tab_capture;
     if (s->text_used) c->batches_without_text = 0;
     if (c->lsh_list.p && !c->prm.keep_sketches) {
@@ -1193,8 +1193,12 @@ static int finish_counters(groot_ctx *c, Slot *s)
     // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
     if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
     if (s->n_reads && !c->tab_capture) c->dfs_frac = (double)h.seeded_reads / (double)s->n_reads;
-    if (s->n_reads && !c->tab_capture && c->dix.text_tab)
+    if (s->n_reads && !c->tab_capture && c->dix.text_tab) {
         c->text_hit_frac = s->text_used ? 1.0 - (double)h.todo_reads / (double)s->n_reads : (double)h.tab_reads / (double)s->n_reads;
+        // (a batch that tried the lookup in vain sent all its reads through the list pass: on a stream the memo cannot answer --
+        // mixed read lengths, another organism -- the next try comes later and later)
+        if (s->text_used) c->text_retry_gap = c->text_hit_frac >= 0.7 ? 8u : std::min(256u, c->text_retry_gap * 2u);
+    }
     s->n_mask_words = s->n_trav ? h.mask_words : 0;
     if (!c->prm.results_on_device && s->n_trav) {
         c->words_per_trav = (double)s->n_mask_words / (double)s->n_trav;

@@ -284,7 +284,12 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
     }
     if (a.read_rec) {
         if (n_hits > kSplitMin && a.long_list) {              // (a read in a hundred; shorter lists are searched as they are)
-            const uint32_t at = atomicAdd(a.long_count, 1u);
+            const unsigned long long here = __ballot(1);      // one atomic for the lanes that are here together
+            const unsigned lane = __lane_id();
+            const int leader = __ffsll(here) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(a.long_count, (uint32_t)__popcll(here));
+            const uint32_t at = __shfl(base, leader) + (uint32_t)__popcll(here & ((1ULL << lane) - 1ULL));
             if (at < kLongListCap) a.long_list[at] = r;
         }
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
@@ -613,7 +618,13 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             rows += b_end[b] - lo;
         }
         if (a.lsh_list && rows > a.lsh_defer_rows && (uint32_t)s_ <= kLshHeavyMaxS) {
-            const uint32_t pos = atomicAdd(a.lsh_count, 1u);
+            // (one atomic for the lanes that are here together: the counter is a single address)
+            const unsigned long long here = __ballot(1);
+            const unsigned lane = __lane_id();
+            const int leader = __ffsll(here) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(a.lsh_count, (uint32_t)__popcll(here));
+            const uint32_t pos = __shfl(base, leader) + (uint32_t)__popcll(here & ((1ULL << lane) - 1ULL));
             if (pos < a.lsh_cap) {
                 a.lsh_list[pos] = r | (high ? 0x80000000u : 0u);
                 uint64_t *sk = a.lsh_sketch + (size_t)pos * s_;
