@@ -818,6 +818,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.head_lanes = s->mixed_len ? 16u : 0u;              // (8: best at 2 M reads before the items of split reads took the head; 16: 2.9 / 5.2 ms at 2 M / 8 M reads, 8 gave 3.05 / 5.6)
     if (const char *e = getenv("GROOT_HEAD_LANES")) a.head_lanes = (uint32_t)std::max(0, std::min(64, atoi(e)));   // experiments
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
+    if (const char *e = getenv("GROOT_REFILL")) a.refill = (uint32_t)std::max(1, std::min(64, atoi(e)));   // experiments
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
     launch_align(c->pw, a, dim3(blocks), c->stream);
