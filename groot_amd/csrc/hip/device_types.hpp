@@ -228,19 +228,16 @@ struct SeedArgs {
     unsigned long long *shards;  // [kSeedShards][kSeedShardStride]: {sum of seeds, largest per-read seed count} per shard of workgroups
     uint32_t *tab_idx;           // [n_reads] first OutEntry (| kTabCounted) of reads whose outcome is tabulated, kEmpty for the others; or null: no table
     uint32_t *tab_hist;          // [n_windows] IncrementSubPath calls of tabulated reads counted by the seed stage in this batch; or null
-    // reads on the LSH-Forest branch of Query, handed by the hashing kernels to lsh_query_kernel: read | byte > 'T' << 31, and their
-    // sketches ([position in the list][s] u64); null: every lane walks its own rows
+    // reads on the LSH-Forest branch of Query whose rows of equal band prefix number more than lsh_defer_rows, handed by the hashing
+    // kernels to lsh_heavy_kernel (a wavefront per read): read | byte > 'T' << 31, and their sketches ([position in the list][s] u64);
+    // null: every lane walks its own rows
     uint32_t *lsh_list, *lsh_count;
     uint64_t *lsh_sketch;
     uint32_t *dfs_list, *dfs_count;   // reads with a scheduling key, appended by the seed epilogue (processing order of the align stage when few are left); or null
     uint32_t *long_list, *long_count; // reads with more than four seed windows that were not found in ascending order (sort_seed_lists_kernel); up to kLongListCap
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
-    // LSH-Forest branch (reads whose Containment > t needs fewer than all slots equal): lsh_route 0 = queried in the hashing kernel,
-    // reads with more than lsh_defer_rows candidate rows handed to lsh_heavy_kernel; 1 = every read to lsh_query_kernel (experiment);
-    // 2 = every read to lsh_lane_kernel (its own launch: few registers, rows fetched ahead), which hands the heavy ones on
-    uint32_t lsh_route, lsh_defer_rows, lsh_cap;
-    uint32_t *heavy_list, *heavy_count;   // route 2: positions in lsh_list of the reads lsh_heavy_kernel takes
+    uint32_t lsh_defer_rows, lsh_cap;
     uint32_t list_stride_dw;     // dwords of LDS per lane of the LIST kernel for its own copy of the read (odd), 0 = read from HBM
     DeviceCounters *ctr;
 };

@@ -22,7 +22,8 @@
 
 #include "../common/cpus.hpp"
 #include "../common/view_check.hpp"
-#include "kernels.hpp"
+#include "kernels_misc.hpp"
+#include "launch.hpp"
 
 using namespace groot;
 
@@ -66,6 +67,22 @@ template <class T> struct PinBuf {
         n = 0;
     }
     ~PinBuf() { release(); }
+};
+
+// The environment switches of the shipped library, read when a ctx is opened (everything else that used to be tunable from the
+// environment was an experiment and went in round 4: DESIGN.md "Removed").  The three NO_* switch a tier of the seed stage off (tests
+// compare the tiers with each other and with the oracle); TEST_SMALL_BUFFERS starts every growable buffer and list too small, so that
+// a test batch walks the grow-and-redo and the fall-back paths; OPEN_STATS prints where groot_hip_open spent its time.
+struct Knobs {
+    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false;
+    static Knobs read()
+    {
+        Knobs k;
+        k.no_outcome_table = getenv("GROOT_NO_OUTCOME_TABLE") != nullptr; k.no_text_table = getenv("GROOT_NO_TEXT_TABLE") != nullptr;
+        k.no_sig = getenv("GROOT_NO_SIG") != nullptr;                     k.force_rccl = getenv("GROOT_FORCE_RCCL") != nullptr;
+        k.small_buffers = getenv("GROOT_TEST_SMALL_BUFFERS") != nullptr;  k.open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
+        return k;
+    }
 };
 
 // One batch in flight.  Inputs and outputs are per slot (copy-in of batch b+1 and copy-out of batch b-1 overlap the
@@ -125,6 +142,7 @@ struct groot_ctx {
     int device = 0;
     std::string err;
     groot_params prm{};
+    Knobs kn;
     uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
     bool profiling = false;
@@ -183,8 +201,7 @@ struct groot_ctx {
     DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
     DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
     uint32_t vcap = 0;
-    uint32_t lsh_route = 0, lsh_defer_rows = 0, lsh_cap = 0;   // SeedArgs::lsh_route
-    DevBuf<uint32_t> heavy_list;
+    uint32_t lsh_defer_rows = 0, lsh_cap = 0;   // SeedArgs::lsh_defer_rows
     DevBuf<unsigned long long> seed_shards;
     DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch + their sketches, for lsh_query_kernel (absent: per-lane row walks)
     DevBuf<uint64_t> lsh_sketch;
@@ -442,110 +459,6 @@ template <int PW> void build_node_records(const groot_index_view *v, std::vector
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
-// kernel dispatch by (sketch size, maxK) and path words
-// ---------------------------------------------------------------------------------------------
-template <int S, int MAXK, int M5> static void launch_seed_sm(const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
-{
-    if (dump) hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, true, M5>), grid, dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((sketch_seed_kernel<S, MAXK, false, M5>), grid, dim3(kBlock), lds, st, a);
-}
-
-static bool seed_supported(uint32_t s, uint32_t max_k)
-{
-    // any `groot index -s / -y` (cmd/index.go:45-49): sizes without a compiled instance run the run-time-sized kernel
-    return s >= 1 && s <= (uint32_t)kGenericMaxS && max_k >= 1 && max_k <= s;
-}
-
-static void launch_seed(uint32_t s, uint32_t max_k, const SeedArgs &a, bool dump, dim3 grid, size_t lds, hipStream_t st)
-{
-    // low 5 bits of k * multiSeed: kernels specialised on it replace the per-slot 64-bit multiplies by adds
-    const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (max_k == 4) {
-        if (s == 21) {   // `groot index` default sketch size, for the common k-mer sizes
-            if (m5 == 6) return launch_seed_sm<21, 4, 6>(a, dump, grid, lds, st);     // k = 31 (default), 63
-            if (m5 == 10) return launch_seed_sm<21, 4, 10>(a, dump, grid, lds, st);   // k = 41
-            if (m5 == 14) return launch_seed_sm<21, 4, 14>(a, dump, grid, lds, st);   // k = 51
-            if (m5 == 2) return launch_seed_sm<21, 4, 2>(a, dump, grid, lds, st);     // k = 21
-        }
-        if (s == 20 && m5 == 6) return launch_seed_sm<20, 4, 6>(a, dump, grid, lds, st);    // travis e2e: -k 31 -s 20
-        if (s == 30 && m5 == 14) return launch_seed_sm<30, 4, 14>(a, dump, grid, lds, st);  // pipeline tests: k = 51, s = 30
-        switch (s) {
-        case 8: return launch_seed_sm<8, 4, -1>(a, dump, grid, lds, st);
-        case 10: return launch_seed_sm<10, 4, -1>(a, dump, grid, lds, st);
-        case 12: return launch_seed_sm<12, 4, -1>(a, dump, grid, lds, st);
-        case 16: return launch_seed_sm<16, 4, -1>(a, dump, grid, lds, st);
-        case 20: return launch_seed_sm<20, 4, -1>(a, dump, grid, lds, st);
-        case 21: return launch_seed_sm<21, 4, -1>(a, dump, grid, lds, st);
-        case 24: return launch_seed_sm<24, 4, -1>(a, dump, grid, lds, st);
-        case 28: return launch_seed_sm<28, 4, -1>(a, dump, grid, lds, st);
-        case 30: return launch_seed_sm<30, 4, -1>(a, dump, grid, lds, st);
-        case 32: return launch_seed_sm<32, 4, -1>(a, dump, grid, lds, st);
-        case 36: return launch_seed_sm<36, 4, -1>(a, dump, grid, lds, st);
-        case 40: return launch_seed_sm<40, 4, -1>(a, dump, grid, lds, st);
-        case 42: return launch_seed_sm<42, 4, -1>(a, dump, grid, lds, st);
-        case 48: return launch_seed_sm<48, 4, -1>(a, dump, grid, lds, st);
-        case 50: return launch_seed_sm<50, 4, -1>(a, dump, grid, lds, st);
-        case 56: return launch_seed_sm<56, 4, -1>(a, dump, grid, lds, st);
-        case 64: return launch_seed_sm<64, 4, -1>(a, dump, grid, lds, st);
-        default: break;
-        }
-    }
-    launch_seed_sm<0, 0, -1>(a, dump, grid, lds, st);   // run-time sketch size / hash functions per band
-}
-
-// sketch_sig_kernel + the list pass of sketch_seed_kernel behind it: instances for the (sketch size, k) pairs that have a
-// strength-reduced sketch_seed_kernel above
-template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
-{
-    // (reads of up to 128 bases: half the registers and instructions in the text comparison)
-    if (max_len <= 128) hipLaunchKernelGGL((sketch_sig_kernel<S, M5, 8>), grid, dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((sketch_sig_kernel<S, M5, (int)kTextMax / 16>), grid, dim3(kBlock), lds, st, a);
-    hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
-}
-template <int S, int M5> static void launch_list_sm(const SeedArgs &a, dim3 list_grid, hipStream_t st)
-{
-    hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
-}
-static void launch_list(uint32_t s, const SeedArgs &a, dim3 list_grid, hipStream_t st)
-{
-    const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (s == 21 && m5 == 6) return launch_list_sm<21, 6>(a, list_grid, st);
-    if (s == 21 && m5 == 10) return launch_list_sm<21, 10>(a, list_grid, st);
-    if (s == 21 && m5 == 14) return launch_list_sm<21, 14>(a, list_grid, st);
-    if (s == 21 && m5 == 2) return launch_list_sm<21, 2>(a, list_grid, st);
-    if (s == 20 && m5 == 6) return launch_list_sm<20, 6>(a, list_grid, st);
-    if (s == 30 && m5 == 14) return launch_list_sm<30, 14>(a, list_grid, st);
-}
-static bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
-{
-    const uint32_t m5 = (uint32_t)(((uint64_t)k * GROOT_MULTI_SEED) & 31u);
-    if (max_k != 4) return false;
-    return (s == 21 && (m5 == 6 || m5 == 10 || m5 == 14 || m5 == 2)) || (s == 20 && m5 == 6) || (s == 30 && m5 == 14);
-}
-static void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
-{
-    const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, max_len, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, max_len, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, max_len, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, max_len, grid, lds, list_grid, st);
-    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, max_len, grid, lds, list_grid, st);
-    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, max_len, grid, lds, list_grid, st);
-}
-
-static void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
-{
-    const size_t lds = a.lds_stride_dw ? (size_t)kBlock * a.lds_stride_dw * 4 + 16 : 0;
-    if (pw == 3) {
-        if (lds) hipLaunchKernelGGL((align_kernel<3, true>), grid, dim3(kBlock), lds, st, a);
-        else hipLaunchKernelGGL((align_kernel<3, false>), grid, dim3(kBlock), 0, st, a);
-    } else if (pw == 11) {
-        if (lds) hipLaunchKernelGGL((align_kernel<11, true>), grid, dim3(kBlock), lds, st, a);
-        else hipLaunchKernelGGL((align_kernel<11, false>), grid, dim3(kBlock), 0, st, a);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // batch execution
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t kMaxLdsReadBytes = 64 * 1024;
@@ -602,6 +515,7 @@ static int grow_attempts(groot_ctx *c, uint32_t rows)
     return GROOT_OK;
 }
 
+constexpr double kSparseBelow = 0.05;   // share of a batch left for the graph walk below which the processing order is a stream compaction and half the persistent grid runs
 struct HasKey {     // reads the seed stage left for the align stage's graph walk carry a scheduling key
     const uint32_t *key;
     __host__ __device__ bool operator()(uint32_t r) const { return key[r] != kEmpty; }
@@ -614,8 +528,6 @@ struct HasKey {     // reads the seed stage left for the align stage's graph wal
 // per SIMD and a dependent trip (seed stage of 8 M reads of 75..150 bases: 7.0 ms with the copy, 5.9 ms without).
 static uint32_t list_lds_stride(uint32_t stride_dw)
 {
-    static const char *force = getenv("GROOT_LIST_LDS");
-    if (force) return atoi(force) && (uint64_t)kBlock * stride_dw * 4 <= 48 * 1024 ? stride_dw : 0;
     return kLdsReads + (uint64_t)kBlock * stride_dw * 4 <= 32 * 1024 ? stride_dw : 0;
 }
 static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
@@ -641,7 +553,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.long_list = c->long_list.p; a.long_count = c->long_count.p;
     if (c->dix.out_tab) {                                   // reads the signature kernel finds in the outcome table say so here
         a.tab_idx = c->tab_idx.p;
-        a.tab_hist = getenv("GROOT_EXP_NOHIST") ? nullptr : c->tab_hist.p;
+        a.tab_hist = c->tab_hist.p;
     }
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
     // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
@@ -651,7 +563,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
     const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
-    static const uint32_t list_blocks = getenv("GROOT_LIST_GRID") ? (uint32_t)std::max(1, atoi(getenv("GROOT_LIST_GRID"))) : 1280u;   // workgroups of the list pass (grid-stride; 5 per CU)
+    const uint32_t list_blocks = 1280u;   // workgroups of the list pass (grid-stride; 5 per CU)
     // a batch of one read length that is not on the exact-table branch (lower thresholds, reads shorter than the windows) would
     // send every read through the list: the full-width kernel alone is 25-30 % faster then (tools/threshold_probe.py)
     bool sig_useful = true;
@@ -663,15 +575,14 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     // Which kernel sees the batch first?  When the outcome table answered most of the latest batch, the text lookup (no hashing at
     // all; what it does not find goes through the full-width kernel, read by read); else the signature kernel as before.
     // (the share is only known exactly while the lookup runs: it is tried again after 8, 16, ... 256 batches)
-    static const double list_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
+    const double list_below = kSparseBelow;
     const bool list_mode = c->dfs_frac < list_below;       // few reads need the graph walk (the latest batch says so)
     const bool text_try = c->text_hit_frac >= 0.7 || ++c->batches_without_text >= c->text_retry_gap;
     s->text_used = !c->prm.keep_sketches && c->dix.text_tab && c->dix.out_tab && text_try && s->max_len >= c->dix.w && !c->tab_capture;
     if (s->text_used) c->batches_without_text = 0;
     if (c->lsh_list.p && !c->prm.keep_sketches) {
         a.lsh_list = c->lsh_list.p; a.lsh_count = c->lsh_count.p; a.lsh_sketch = c->lsh_sketch.p;
-        a.lsh_route = c->lsh_route; a.lsh_defer_rows = c->lsh_defer_rows; a.lsh_cap = c->lsh_cap;
-        if (c->lsh_route == 2) { a.heavy_list = c->heavy_list.p; a.heavy_count = c->lsh_count.p + 1; }
+        a.lsh_defer_rows = c->lsh_defer_rows; a.lsh_cap = c->lsh_cap;
         HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, 2 * sizeof(uint32_t), c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(c->vcount.p, 0, 2 * sizeof(uint32_t), c->stream));
@@ -687,11 +598,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
             a.dfs_list = c->perm.p; a.dfs_count = c->perm_count.p;
             HIP_TRY(c, hipMemsetAsync(c->perm_count.p, 0, sizeof(uint32_t), c->stream));
         }
-        switch (text_key_dwords((c->dix.w + 15) / 16)) {
-        case 7: hipLaunchKernelGGL((text_lookup_kernel<7>), grid, dim3(kBlock), lds, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((text_lookup_kernel<8>), grid, dim3(kBlock), lds, c->stream, a); break;
-        default: hipLaunchKernelGGL((text_lookup_kernel<14>), grid, dim3(kBlock), lds, c->stream, a); break;
-        }
+        launch_text_lookup(text_key_dwords((c->dix.w + 15) / 16), a, grid, lds, c->stream);
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
         launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
@@ -708,17 +615,8 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
     }
-    if (a.lsh_list && a.lsh_route != 1) {
-        // the reads of the LSH-Forest branch: a lane each; those with many candidate rows: a wavefront each
-        if (a.lsh_route == 2) {
-            if (c->l_max <= 8) hipLaunchKernelGGL((lsh_lane_kernel<8>), dim3(std::min<uint32_t>(grid.x, 4096u)), dim3(kBlock), 0, c->stream, a);
-            else hipLaunchKernelGGL((lsh_lane_kernel<16>), dim3(std::min<uint32_t>(grid.x, 4096u)), dim3(kBlock), 0, c->stream, a);
-        }
-        hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, 2048u)), dim3(kBlock), 0, c->stream, a);
-    } else if (a.lsh_list) {                // (experiments: every read of that branch, a wavefront per 64 of them)
-        const size_t lds = (size_t)(kBlock / 64) * lsh_wave_lds_dw(c->l_max) * sizeof(uint32_t);
-        hipLaunchKernelGGL(lsh_query_kernel, dim3(std::min<uint32_t>(grid.x, 1024u)), dim3(kBlock), lds, c->stream, a);
-    }
+    // the reads of the LSH-Forest branch with many candidate rows: a wavefront each
+    if (a.lsh_list) hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, 2048u)), dim3(kBlock), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (c->profiling && !s->text_used) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));   // (signature kernel + its list pass / the full-width kernel)
     // seed lists of more than four windows that are not ascending (LSH-Forest hits come in band order): sorted, a wavefront per read
@@ -800,25 +698,21 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
     // (few reads left for the walk -- the latest batch says so: half the persistent grid starts and drains 0.05 ms sooner and the
     // slowest read, not the number of wavefronts, sets the duration anyway)
-    static const double sparse_below = getenv("GROOT_LIST_BELOW") ? atof(getenv("GROOT_LIST_BELOW")) : 0.05;
-    if (c->dfs_frac < sparse_below && !getenv("GROOT_ALIGN_GRID_PER_CU")) blocks = std::max(1u, blocks / 2);
+    if (c->dfs_frac < kSparseBelow) blocks = std::max(1u, blocks / 2);
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB
     {
         // 8 zero bytes, then the read in whole 16-byte pieces up to 12 bytes past its end; odd dword stride = no bank conflicts
         const uint32_t stride = (2 + 4 * ((s->max_len + 27) / 16)) | 1u;
-        a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 && !getenv("GROOT_ALIGN_NO_LDS") ? stride : 0;
+        a.lds_stride_dw = (size_t)kBlock * stride * 4 <= 64 * 1024 ? stride : 0;
     }
     if (c->tab_capture) {
         a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p; a.incr_cap = c->incr_cap;
         HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
     }
-    if (const char *e = getenv("GROOT_ROUND_LANES")) a.round_lanes = (uint32_t)std::max(1, std::min(64, atoi(e)));   // experiments
     a.head_lanes = s->mixed_len ? 16u : 0u;              // (8: best at 2 M reads before the items of split reads took the head; 16: 2.9 / 5.2 ms at 2 M / 8 M reads, 8 gave 3.05 / 5.6)
-    if (const char *e = getenv("GROOT_HEAD_LANES")) a.head_lanes = (uint32_t)std::max(0, std::min(64, atoi(e)));   // experiments
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
-    if (const char *e = getenv("GROOT_REFILL")) a.refill = (uint32_t)std::max(1, std::min(64, atoi(e)));   // experiments
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
     launch_align(c->pw, a, dim3(blocks), c->stream);
@@ -842,10 +736,8 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
     hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, s->d_ctr.p);
     OrderTabArgs ot{};
     if (c->dix.out_tab) {
-        ot.seed_count = c->seed_count.p; ot.seed_win = c->seed_win.p; ot.seed_slots = c->seed_slots;
         ot.tab_idx = c->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
         ot.update_weights = update_weights ? 1 : 0;
-        if (const char *e = getenv("GROOT_EXP_ORDER")) ot.exp = (uint32_t)atoi(e);   // experiments
         ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
         ot.q_tab = c->dix.w - c->k + 1; ot.n_windows = c->n_windows;
     }
@@ -924,7 +816,7 @@ static int ensure_slot(groot_ctx *c, Slot *s, Slot::Input in, uint64_t n_exc)
         HIP_TRY(c, s->d_ctr.alloc(1));
         HIP_TRY(c, s->h_ctr.alloc(1));
         // (GROOT_TEST_SMALL_BUFFERS: start with buffers that every batch outgrows, so that the tests walk the grow-and-redo paths)
-        static const bool tiny = getenv("GROOT_TEST_SMALL_BUFFERS") != nullptr;
+        const bool tiny = c->kn.small_buffers;
         if (int rc = alloc_trav(c, s, tiny ? 64u : std::max<uint32_t>(1024, R + R / 4))) return rc;
     }
     if (in == Slot::IN_DEVICE) return GROOT_OK;
@@ -1169,9 +1061,6 @@ static int finish_counters(groot_ctx *c, Slot *s)
             s->status_msg = buf;
         }
     }
-    if (getenv("GROOT_SIG_STATS"))
-        fprintf(stderr, "[groot sig] %u of %u reads went through the full-width sketch kernel (%u windows without a text)\n", h.todo_reads, s->n_reads,
-                c->sig_disabled);
 #ifdef GROOT_WORK_COUNTERS
     for (int e = 0; e < 32; e++)
         if (h.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, h.dbg[e], h.dbg[32 + e]);
@@ -1448,7 +1337,7 @@ inline void pack_at(const std::vector<uint32_t> &packed, size_t i, uint32_t len,
 static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const std::vector<uint8_t> &text, const std::vector<uint32_t> &tlen,
                                std::vector<uint32_t> &info, uint32_t w, uint32_t vstride)
 {
-    const bool stats = getenv("GROOT_OPEN_STATS") != nullptr;
+    const bool stats = c->kn.open_stats;
     auto t_lap = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!stats) return;
@@ -1464,7 +1353,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     // ---- 1. the strings: every WindowSize-mer of every path, both strands, each once ----
     // (the text table serves reads of exactly WindowSize bases whose kmerCount puts Query on the every-slot-equal branch)
     const uint32_t q_w = w - c->k + 1;
-    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && !getenv("GROOT_NO_TEXT_TABLE");
+    const bool text_ok = w <= 224 && q_w < c->h_q_min_eq.size() && !c->kn.no_text_table;
     // strings with a few bytes other than ACGT (a path through an N): bases with code 0 at those positions, then the bytes and their
     // positions as the text table keeps them (device_types.hpp text_exc_dwords) -- only the text lookup can find these
     const uint32_t twk = text_key_dwords(tw);               // dwords of bases in a text-table entry (zero-padded)
@@ -1744,8 +1633,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
 static int build_signature_index(groot_ctx *c, const groot_index_view *v, const std::vector<uint32_t> &sketch_class)
 {
     const uint32_t n = v->n_windows, s = v->sketch_size, w = v->window_size, k = v->kmer_size;
-    if (getenv("GROOT_NO_SIG") || !sig_supported(s, v->max_k, k) || w > kTextMax || w < k || !n) return GROOT_OK;
-    const bool open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
+    if (c->kn.no_sig || !sig_supported(s, v->max_k, k) || w > kTextMax || w < k || !n) return GROOT_OK;
+    const bool open_stats = c->kn.open_stats;
     auto t_lap = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!open_stats) return;
@@ -1874,7 +1763,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));
     HIP_TRY(c, upload(c->sig_info, verdict.data(), verdict.size()));
     HIP_TRY(c, upload(c->win_nodes, nodes.data(), nodes.size(), 4));
-    c->dix.sig_info = getenv("GROOT_NO_SIG_VERDICTS") ? nullptr : c->sig_info.p;
+    c->dix.sig_info = c->sig_info.p;
     c->dix.sig_verdict_stride = vstride;
     c->dix.win_nodes = c->win_nodes.p;
     lap("tables + uploads");
@@ -1882,7 +1771,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     c->dix.sig_mask = cap - 1;
     c->dix.win_text = c->win_text.p;
     // 5. outcome table: the align stage itself, once, on every string that confirms reads
-    if (c->dix.sig_info && !getenv("GROOT_NO_OUTCOME_TABLE") && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
+    if (c->dix.sig_info && !c->kn.no_outcome_table && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
         const auto t0 = std::chrono::steady_clock::now();
         if (int rc = build_outcome_table(c, v, text, tlen, verdict, w, vstride)) return rc;
         c->out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1899,6 +1788,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     if (device_id < 0 || device_id >= ndev) return fail(c, GROOT_E_INVALID, "device %d out of range (%d devices)", device_id, ndev);
     if (!v) return fail(c, GROOT_E_INVALID, "null index view");
     c->device = device_id;
+    c->kn = Knobs::read();
     HIP_TRY(c, hipSetDevice(device_id));
     groot_params d;
     groot_params_default(&d);
@@ -1936,7 +1826,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         c->slots.push_back(std::move(s));
     }
 
-    const bool open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
+    const bool open_stats = c->kn.open_stats;
     auto t_open = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!open_stats) return;
@@ -1969,7 +1859,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         for (auto &x : th) x.join();
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
-    if (!getenv("GROOT_NO_NODE_PRE4")) {   // which 4-mers the level-2 start positions of every node can spell
+    {   // which 4-mers the level-2 start positions of every node can spell
         std::vector<uint32_t> pre((size_t)v->n_nodes * 8, 0);
         for (uint32_t nd = 0; nd < v->n_nodes; nd++) {
             const uint32_t s0 = v->node_seq_off[nd], nlen = v->node_seq_off[nd + 1] - s0;
@@ -2000,7 +1890,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->h_node_graph.resize(v->n_nodes);
     for (uint32_t g = 0; g < v->n_graphs; g++)
         for (uint32_t nd = v->graph_node_off[g]; nd < v->graph_node_off[g + 1]; nd++) c->h_node_graph[nd] = g;
-    c->packed_travs = !c->prm.results_on_device && c->prm.max_batch_reads <= (1u << 24) && !getenv("GROOT_WIDE_COPYOUT");
+    c->packed_travs = !c->prm.results_on_device && c->prm.max_batch_reads <= (1u << 24);
     {   // windows are numbered graph by graph (canonical seed order): the last window of every graph
         std::vector<uint32_t> end(v->n_graphs, 0);
         bool grouped = true;
@@ -2200,7 +2090,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
     if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
     // (+ vcap slots behind the reads: the items of split reads, AlignArgs::vitem)
-    c->vcap = getenv("GROOT_NO_SPLIT") ? 0u : std::max<uint32_t>(4096, R / 4);
+    c->vcap = c->kn.small_buffers ? 8u : std::max<uint32_t>(4096, R / 4);   // (small: most split reads find no room for their items and are handled whole)
     HIP_TRY(c, c->trav_first.alloc((size_t)R + c->vcap));
     HIP_TRY(c, c->mask_first.alloc(((size_t)R + c->vcap) * c->pw));
     HIP_TRY(c, c->trav_cnt.alloc((size_t)R + c->vcap));
@@ -2210,34 +2100,22 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, hipMemset(c->vcount.p, 0, 4 * sizeof(uint32_t)));
     HIP_TRY(c, c->trav_off.alloc(R));
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
-    if (int rc = alloc_ovf(c, getenv("GROOT_TEST_SMALL_BUFFERS") ? 2u : std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
+    if (int rc = alloc_ovf(c, c->kn.small_buffers ? 2u : std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    uint32_t per_cu = c->pw > 3 ? GROOT_ALIGN_WAVES_WIDE : GROOT_ALIGN_WAVES;
-    if (const char *e = getenv("GROOT_ALIGN_GRID_PER_CU")) per_cu = std::max(1, std::min(16, atoi(e)));   // experiments (tools/overlap_probe.py)
+    uint32_t per_cu = c->pw > 3 ? kAlignWavesWide : kAlignWaves;
     c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, (uint32_t)std::max(n_cu, 1) * per_cu * kBlock);
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
     HIP_TRY(c, c->stk_mask.alloc((size_t)c->stk_depth * c->align_threads * c->pw));
-    // lsh_query_kernel (the rows of a wavefront's reads dealt over its lanes) is parity-green and SLOWER than the per-lane walk on
-    // every workload measured (2.46 vs ~0.8 ms for 720 000 mixed-length reads at t = 0.95: the rows of a lane are consecutive 32-byte
-    // records, four to a cache line, which a lane walks at ~0.3 us per row; a dealt row costs a bisection, a cold line and LDS
-    // traffic, ~3 us per step of 64).  Opt-in for experiments: GROOT_LSH_KERNEL=1.
-    // Handing it only the reads with many candidate rows (GROOT_LSH_DEFER=rows: a lane walking a thousand rows while 63 wait) does
-    // not pay either: resfinder.90, 2 M reads of 75..150 bases, seed stage 2.2 ms without it, 4.3 / 6.4 / 2.2 ms at 64 / 256 / 1024 rows.
-    // Route 0 (default): the hashing kernels query in place and hand the reads with many rows to lsh_heavy_kernel.  Route 2
-    // (GROOT_LSH_ROUTE=2): the hashing kernels only sketch and every read of the branch is queried by lsh_lane_kernel, a launch of its
-    // own without the minima in registers and with rows fetched ahead -- measured slower too (mixed-length batch of 8 M reads, seed
-    // stage 8.1 vs 6.9 ms at t = 0.99, 14.0 vs 11.3 ms at t = 0.90: writing and re-reading the sketches costs more than the walk gains).
-    if (c->l_max <= kLshMaxBands && !getenv("GROOT_NO_LSH_KERNEL")) {
-        c->lsh_route = getenv("GROOT_LSH_KERNEL") ? 1u : 0u;
-        if (const char *e = getenv("GROOT_LSH_ROUTE")) c->lsh_route = (uint32_t)std::max(0, std::min(2, atoi(e)));
+    // LSH-Forest branch of Query: the hashing kernels query in place (a lane per read) and hand the reads with more than lsh_defer_rows
+    // candidate rows to lsh_heavy_kernel (a wavefront per read).  Two alternatives were built, measured slower on every workload
+    // and removed in round 4 ("Removed"): a kernel dealing the rows of 64 reads over a wavefront, and a query launch of its own.
+    if (c->l_max <= kLshMaxBands) {
         c->lsh_defer_rows = 64u;
-        if (const char *e = getenv("GROOT_LSH_DEFER")) c->lsh_defer_rows = (uint32_t)std::max(1, atoi(e));
-        c->lsh_cap = c->lsh_route ? R : std::max<uint32_t>(4096, R / 4);
+        c->lsh_cap = c->kn.small_buffers ? 4u : std::max<uint32_t>(4096, R / 4);   // (small: most heavy reads find the list full and walk their own rows)
         HIP_TRY(c, c->lsh_list.alloc(c->lsh_cap));
-        HIP_TRY(c, c->heavy_list.alloc(c->lsh_cap));
         HIP_TRY(c, c->lsh_count.alloc(4));
         HIP_TRY(c, c->lsh_sketch.alloc((size_t)c->lsh_cap * s));
     }
@@ -2842,7 +2720,7 @@ int groot_hip_attempts_allreduce(groot_ctx *const *ctxs, int n_ctx)
     }
     // GROOT_FORCE_RCCL=1: take the RCCL branch even when all ctxs share one device (a communicator over a single device is legal):
     // the one way to run dlopen, the symbol lookups, the enum values and the grouped in-place ncclAllReduce on a one-GPU box
-    const bool force_rccl = getenv("GROOT_FORCE_RCCL") != nullptr;
+    const bool force_rccl = c0->kn.force_rccl;
     if (n_ctx == 1 && !force_rccl) return drain(c0);
     // union row layout (ascending kmerCount) on every ctx
     std::vector<uint32_t> all;

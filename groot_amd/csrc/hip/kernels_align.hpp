@@ -1,0 +1,742 @@
+#pragma once
+
+#include "kernels_common.hpp"
+
+namespace groot {
+
+// ---------------------------------------------------------------------------------------------
+// K3
+// ---------------------------------------------------------------------------------------------
+
+// K3 as a per-lane state machine with wave-coherent phase scheduling.
+//   graphMinion loop (graphminion.go:46-102) -> AlignRead hierarchy (alignment.go:13-159)
+//   -> performAlignment / dfsRecursive / processTraversal (alignment.go:162-317)
+// Each lane is in one of three phases and advances by ONE step when its phase is executed:
+//   FETCH  take the next read (its record, in processing order; bases staged in the lane's LDS slice) / pick the
+//          read's next seed window, count IncrementSubPath, apply the seed stage's verdicts on hierarchy levels
+//   SCAN   test up to 16 candidate start offsets of one node against the read prefix (SWAR, 4-base
+//          filter then exact 8-base check of the lowest survivor); walks the hierarchy levels 1..4
+//   DFS    match up to 32 bases of one graph node, choose the next neighbour, emit / backtrack
+// Per iteration the wave executes only the phase holding the most lanes (ballot + popcount in SALU), so
+// lanes in different reads / levels / depths never serialise each other's loops and every executed
+// instruction runs at the best available lane fill.  A wavefront takes 64 consecutive reads of the processing order
+// at a time (they share a seed window, hence the graph nodes they walk) and asks for more when all lanes are done.
+enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
+constexpr uint32_t kWaveChunk = 128;   // consecutive slots a wave takes before asking for more (multiple of 64)
+
+// 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
+__device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
+{
+    return ~(nonzero_bytes(x ^ (kOnes * c)) & nonzero_bytes(x ^ (kOnes * 'N'))) & kHi1;
+}
+// 0x80 in the low n bytes (n may exceed 8 or be <= 0)
+__device__ __forceinline__ uint64_t low_bytes(int n) { return n <= 0 ? 0 : (n >= 8 ? kHi1 : (kHi1 >> (8 * (8 - n)))); }
+
+// a NodeRec held in registers as dwords (16-byte loads; every access below uses a constant index)
+template <int PW> struct RecRegs {
+    static constexpr int NQ = (int)(sizeof(NodeRec<PW>) / 16);
+    uint32_t d[NQ * 4];
+    __device__ __forceinline__ void load(const NodeRec<PW> *rp)
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(rp);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const uint4 v = q[i];
+            d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+        }
+        // The whole record is wanted NOW, in one round trip.  Left to itself the compiler sinks field loads into the
+        // branches that use them (seq_off after the length test, first8 folded into a pointer select with the bases
+        // load), which turns one DFS step into three dependent trips to L2.
+#pragma unroll
+        for (int i = 0; i < NQ * 4; i++) asm volatile("" : "+v"(d[i]));
+    }
+    __device__ __forceinline__ uint32_t seq_off() const { return d[0]; }
+    __device__ __forceinline__ uint32_t seq_len() const { return d[1]; }
+    __device__ __forceinline__ uint32_t deg() const { return d[2] & 0x7FFFFFFFu; }
+    __device__ __forceinline__ bool wild() const { return (d[2] >> 31) != 0; }     // the node holds an 'N'
+    __device__ __forceinline__ unsigned child_first(int e) const { return (d[3] >> (8 * e)) & 0xFFu; }
+    __device__ __forceinline__ uint64_t first8() const { return (uint64_t)d[4] | ((uint64_t)d[5] << 32); }
+    __device__ __forceinline__ uint32_t edge(int e) const { return d[6 + e]; }
+    __device__ __forceinline__ uint64_t mask(int i) const { return (uint64_t)d[10 + 2 * i] | ((uint64_t)d[11 + 2 * i] << 32); }
+};
+
+// LDSR: the oriented read of every lane is staged in LDS when its first DFS of that orientation starts
+// (lane-private slice of lds_stride_dw dwords, odd stride = conflict-free across lanes); DFS steps then read
+// their 8-base chunks with three ds_read_b32 + two alignbit instead of going back to the Infinity Cache /
+// HBM for the read's line and re-doing the reverse complement at every step.
+template <int PW, bool LDSR>
+__global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) void align_kernel(AlignArgs a)
+{
+    using Rec = NodeRec<PW>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_reads[];
+    __shared__ unsigned long long red[4];
+    uint32_t *my_lds = lds_reads + (size_t)threadIdx.x * a.lds_stride_dw;
+    const DeviceIndex &ix = a.ix;
+    const Rec *recs = reinterpret_cast<const Rec *>(a.node_rec);
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    // the seed stage ran out of per-read slots (or the call-count table out of rows): the host grows them and re-runs the whole batch
+    if (a.ctr->flags & (kFlagSeedOverflow | kFlagQOverflow)) return;
+    unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
+#ifdef GROOT_WORK_COUNTERS
+    uint32_t ev = 0;                                       // events of this lane in the current wave iteration
+    uint32_t wc_iter = 0, wc_round0 = 0;                   // wave iterations so far / at the last refill
+    unsigned long long wc_t[3] = {0, 0, 0};                // wall-clock ticks (100 MHz) per phase, wave-uniform
+    uint32_t wc_n[3] = {0, 0, 0};                          // steps per phase
+#define GROOT_EV(i) (ev |= 1u << (i))
+#else
+#define GROOT_EV(i) ((void)0)
+#endif
+
+    uint32_t phase = PH_WAIT;
+    // reads are handed out per wavefront: chunks of kWaveChunk consecutive (sorted) slots, round-robin over the
+    // waves of the grid, consecutive slots to the lanes that ask together
+    // (a wavefront that runs out takes the next chunk from a global cursor: no static shares, so no wave idles while
+    // another still holds several chunks)
+    // Rounds of 64 slots are handed out through two cursors.  The first eighth of the order holds the longest walks (one
+    // round of them can take a quarter of the launch): cursor 0 hands those out one round at a time; once it has run past
+    // them, cursor 1 hands out the rest kWaveChunk slots at a time.  (Only atomics touch the cursors: an atomic LOAD at
+    // agent scope in this loop halves the kernel's speed.)
+    // reads without seeds sort last and have nothing to do here (the seed stage zeroed their traversal counts)
+    // (items of split reads come first: slot j < nv is AlignArgs::vitem[j], slot nv + i is position i of the processing order)
+    const uint32_t nv = a.vitem ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)*a.vcount), a.vcap) : 0u;
+    const uint32_t n_todo = nv + (a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads)) : a.n_reads);   // (scalar: it bounds every refill)
+    // Lanes per round.  A round lasts as long as its slowest read, so when there are fewer reads than 64 per resident wavefront
+    // (most of the batch was answered from the outcome table: what is left are the hard reads) the rounds are made smaller
+    // and spread over all wavefronts: the launch then ends with the slowest read instead of the slowest sum of rounds.
+    uint32_t U = 64;
+    if (a.round_lanes) U = a.round_lanes;
+    else
+        while (U > 1u && n_todo < U * (gridDim.x * (uint32_t)(kBlock / 64))) U >>= 1;
+    const uint32_t n_rounds = (n_todo + U - 1u) / U;
+    // (odd on purpose: with an even count the two-round chunks behind the head start at multiples of 128 slots and the kernel is
+    // 6 % slower -- measured both ways, cause not established)
+    const uint32_t head_rounds = (n_rounds >> 3) | 1u;
+    // The head of the order holds the longest walks.  When the reads of a batch do not march in step (a.head_lanes != 0: mixed
+    // read lengths) a round of 64 of them lasts as long as their steps laid end to end -- one such round was a quarter of the
+    // launch --, so the head is handed out in rounds of a.head_lanes reads; the tail keeps full rounds.
+    const uint32_t Uh = a.head_lanes ? min(a.head_lanes, U) : U;
+    const uint32_t head_slots = min(head_rounds * U, n_todo);
+    const uint32_t head_small = (head_slots + Uh - 1u) / Uh;
+    uint32_t chunk_len = 0, chunk_base = 0;                // slots in the current chunk, its first slot (wave-uniform)
+    bool head_done = head_small == 0;                      // wave-uniform
+    auto take_chunk = [&]() {
+        uint32_t c = 0, tail = 0;
+        if ((threadIdx.x & 63) == 0) {
+            if (!head_done) c = atomicAdd(a.ovf_cnt + kOvfShards, 1u);
+            if (head_done || c >= head_small) {
+                tail = 1;
+                c = atomicAdd(a.ovf_cnt + kOvfShards + 1, kWaveChunk / 64u);
+            }
+        }
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail);
+        if (tail) {
+            head_done = true;
+            // (saturating: past the end the base only has to be >= n_todo)
+            const unsigned long long b = (unsigned long long)head_slots + (unsigned long long)c * U;
+            chunk_base = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
+            chunk_len = (kWaveChunk / 64u) * U;
+        } else {
+            chunk_base = c * Uh;
+            chunk_len = min(Uh, head_slots - chunk_base);
+        }
+    };
+    take_chunk();
+    uint32_t chunk_pos = 0;                                // slots of the chunk already handed out (wave-uniform)
+    uint32_t slot = 0, r = 0;
+    // ---- read ----
+    bool have_read = false;
+    const uint8_t *p = nullptr;
+    uint32_t len = 0, cnt = 0, qrow = 0, n_graphs = 0, ord = 0, read_id = 0;
+    uint32_t sd0 = kEmpty, sd1 = kEmpty, sd2 = kEmpty, sd3 = kEmpty;   // the read's first four seed windows
+    uint32_t high_byte = 0;                                // RevComplement would panic on this read
+    uint32_t cls = 0;                                      // kRec* verdicts of the read record >> 24; bit 6: they apply to w
+    long long last = -1;                                   // last seed window handled (ascending window id order)
+    uint32_t done_graph = kEmpty, cur_graph = kEmpty;
+    bool group_rc_called = false;
+    // ---- seed / hierarchy ----
+    uint32_t w = 0, g = 0, seed = 0, seed_s0 = 0, seed_len = 0, off0 = 0, l1_hi = 0, cn_cur = 0, cn_begin = 0, cn_end = 0;
+    uint32_t rc = 0, level = 1;
+    uint32_t sc_node = 0, sc_s0 = 0, sc_len = 0, sc_pos = 0, sc_end = 0;   // range being scanned
+    uint32_t clip_lo = 0, eff = 0, tflags = 0;
+    uint64_t pre8 = 0;
+    // ---- DFS ----
+    uint32_t node0 = 0, noff0 = 0, cur = 0, coff = 0, dist = 0, sp = 0, emitted = 0;
+    uint64_t cur8 = 0;                                     // oriented read bases [dist, dist+8)
+    uint64_t mask[PW];
+#pragma unroll
+    for (int i = 0; i < PW; i++) mask[i] = 0;
+
+    // oriented bases [d, d+8) of the current view during DFS
+    // LDSR: the lane's slice holds 8 zero bytes, then the read as it came (forward), staged when the read was fetched.
+    // Oriented bases [i, i+8) are slice bytes [8+i, 16+i) forward, or the reverse complement of slice bytes [len-i, len-i+8).
+    auto dfs_chunk = [&](uint32_t d) -> uint64_t {
+        if (!LDSR) return read_chunk(p, len, rc, clip_lo, d);
+        const uint32_t i = d + clip_lo;
+        const uint32_t o = rc ? len - i : 8u + i;
+        const uint32_t *wp = my_lds + (o >> 2);
+        const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2];
+        const uint32_t sh = (o & 3u) * 8u;
+        const uint64_t v = (uint64_t)__funnelshift_r(x0, x1, sh) | ((uint64_t)__funnelshift_r(x1, x2, sh) << 32);
+        return rc ? revcomp8(v) : v;
+    };
+    auto set_view = [&](uint32_t clip_lo_, uint32_t eff_, uint32_t clip_flag) {
+        clip_lo = clip_lo_; eff = eff_;
+        tflags = (rc ? GROOT_TRAV_RC : 0u) | clip_flag;
+        pre8 = dfs_chunk(0);
+    };
+    auto scan_range = [&](uint32_t node, uint32_t s0, uint32_t nlen, uint32_t from, uint32_t to) {
+        sc_node = node; sc_s0 = s0; sc_len = nlen; sc_pos = from; sc_end = to;
+    };
+    // verdict of the seed stage for the current orientation (f = kRecNo12F / kRecNo3F / kRecNo4F)
+    auto verdict = [&](uint32_t f) -> bool { return (cls & 0x40u) && ((cls >> (rc ? 3 : 0)) & (f >> 24)); };
+    // 1. seed offset shuffling (alignment.go:34-45).  Returns true when levels 1 and 2 cannot start anywhere for this
+    // orientation (prefix tables): the ranges are left empty and the caller moves on through the hierarchy.
+    auto start_orientation = [&](uint32_t t) -> bool {
+        rc = t; level = 1;
+        set_view(0, len, 0);
+        scan_range(seed, seed_s0, seed_len, off0, l1_hi);
+        phase = PH_SCAN;
+        bool no;
+        if (cls & 0x40u) no = verdict(kRecNo12F);
+        else no = prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff >= 12 ? dfs_chunk(8) : 0, eff);
+        if (no) { level = 2; cn_cur = cn_end; sc_pos = sc_end = 0; }
+        return no;
+    };
+    // the current scan range is used up: move through the hierarchy until a non-empty range or the end
+    auto next_range = [&]() {
+        for (;;) {
+            if (level == 1) { level = 2; cn_cur = cn_begin; }
+            else if (level == 2) cn_cur++;
+            else if (level == 3) {
+                level = 4;                                  // 4. hard clip the last base (:87-103)
+                if (verdict(kRecNo4F)) continue;            // its single start position fails the first comparison
+                set_view(0, len - 1, GROOT_TRAV_END_CLIP);
+                scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
+                return;
+            } else {
+                // AlignRead found nothing in this orientation: graphminion.go:94 RevComplement
+                if (!group_rc_called) {                     // first RevComplement of this minion's copy of the read
+                    group_rc_called = true;
+                    if (high_byte) panics++;                 // seqio.go:126 index out of range
+                }
+                if (rc == 0) {
+                    if (start_orientation(1)) continue;
+                } else phase = PH_FETCH;                     // both orientations failed: next mapping
+                return;
+            }
+            if (level == 2) {                               // 2. seed node shuffling (:47-70): offsets 0..10
+                // Contained nodes none of whose offsets 0..10 can spell the first four read bases would each cost a SCAN step
+                // that finds nothing (its 4-base filter is the same test): DeviceIndex::node_pre4 says so per node, four nodes
+                // per pair of trips.  A read that fails everywhere walks every contained node of every seed window in both
+                // orientations -- it is the slowest read of its batch, and the launch lasts as long as it does.
+                if (ix.node_pre4 && eff >= 4u && cn_cur < cn_end) {
+                    const int c4 = kmer4_code(pre8);
+                    if (c4 >= 0) {
+                        const uint32_t wi = (uint32_t)c4 >> 5, bi = (uint32_t)c4 & 31u;
+                        while (cn_cur < cn_end) {
+                            const uint32_t left = cn_end - cn_cur;
+                            const uint32_t n0 = ix.cn_node[cn_cur], n1 = left > 1 ? ix.cn_node[cn_cur + 1] : n0, n2 = left > 2 ? ix.cn_node[cn_cur + 2] : n0,
+                                           n3 = left > 3 ? ix.cn_node[cn_cur + 3] : n0;
+                            const uint32_t w0 = ix.node_pre4[(size_t)n0 * 8 + wi], w1 = ix.node_pre4[(size_t)n1 * 8 + wi], w2 = ix.node_pre4[(size_t)n2 * 8 + wi],
+                                           w3 = ix.node_pre4[(size_t)n3 * 8 + wi];
+                            uint32_t hit = 4;
+                            if (left > 3 && ((w3 >> bi) & 1u)) hit = 3;
+                            if (left > 2 && ((w2 >> bi) & 1u)) hit = 2;
+                            if (left > 1 && ((w1 >> bi) & 1u)) hit = 1;
+                            if ((w0 >> bi) & 1u) hit = 0;
+                            cn_cur += min(hit, left);
+                            if (hit < 4) break;
+                        }
+                    }
+                }
+                if (cn_cur < cn_end) {
+                    const uint32_t node = ix.cn_node[cn_cur];
+                    const uint32_t nlen = recs[node].seq_len;
+                    scan_range(node, recs[node].seq_off, nlen, 0, min(nlen, 11u));
+                    return;
+                }
+                level = 3;                                  // 3. hard clip the first base (:72-85)
+                if (off0 >= seed_len) { level = 4; continue; }   // :199-201 holds for levels 3 and 4 alike
+                if (verdict(kRecNo3F)) continue;
+                set_view(1, len - 1, GROOT_TRAV_START_CLIP);
+                scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
+                return;
+            }
+        }
+    };
+
+    for (;;) {
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2     // (2 = phase timing only: the tally itself costs time)
+        for (int e = 0; e < 32; e++) {                         // convergent point: tally the previous iteration
+            const unsigned long long b = __ballot((ev >> e) & 1u);
+            if (b && (threadIdx.x & 63) == 0) {
+                atomicAdd(&a.ctr->dbg[e], 1ull);
+                atomicAdd(&a.ctr->dbg[32 + e], (unsigned long long)__popcll(b));
+            }
+        }
+        ev = 0;
+#endif
+#ifdef GROOT_WORK_COUNTERS
+        wc_iter++;
+#endif
+        // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
+        const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
+        {
+            // Lanes that finished their read wait until kRefill of them have gathered (or nothing else is left to
+            // run), then take the next consecutive slots together.  Reads are sorted by (first seed window,
+            // orientation class), so lanes that start together do near-identical work and share phases.
+            const unsigned long long bw = __ballot(phase == PH_WAIT);
+            const int cw = __popcll(bw);
+            const uint32_t Uc = max(1u, min(chunk_len, min(U, 64u)));   // lanes a round of the current chunk fills
+            if (cw >= (int)((64u - Uc) + max(1u, a.refill * Uc / 64u)) || (cw && !(bf | bs | bd))) {
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
+                if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
+                if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
+                wc_round0 = wc_iter;
+#elif defined(GROOT_WORK_COUNTERS)
+                wc_round0 = wc_iter;
+#endif
+                const uint64_t base = chunk_base;
+                if (base >= n_todo) {                          // this wave's share is used up
+                    if (phase == PH_WAIT) phase = PH_DONE;
+                } else {
+                    const uint32_t room = chunk_len - chunk_pos;
+                    if (phase == PH_WAIT) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
+                        const uint64_t sl = base + chunk_pos + rank;
+                        if (rank < room) {
+                            if (sl < n_todo) { slot = (uint32_t)sl; phase = PH_FETCH; GROOT_EV(20); }
+                            else phase = PH_DONE;
+                        }
+                    }
+                    chunk_pos += min((uint32_t)cw, room);
+                    if (chunk_pos >= chunk_len) { chunk_pos = 0; take_chunk(); }
+                }
+                continue;
+            }
+            if (!(bf | bs | bd)) break;                         // no lane has work and none waits
+        }
+        const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
+        const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
+        if (phase != run) continue;
+        GROOT_EV(run);                                          // events 0,1,2: a step of FETCH / SCAN / DFS
+#ifdef GROOT_WORK_COUNTERS
+        const unsigned long long wc_t0 = wall_clock64();
+        const uint32_t wc_steps0 = wc_iter;
+#endif
+        bool advance = false;                                   // leave the current scan range (one call site: the code is large)
+
+        if (run == PH_FETCH) {
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
+#define GROOT_SUBT(i) do { const unsigned long long t__ = wall_clock64(); if ((threadIdx.x & 63) == (__ffsll((unsigned long long)__ballot(1)) - 1)) atomicAdd(&a.ctr->dbg[40 + (i)], t__ - wc_sub); wc_sub = t__; } while (0)
+            unsigned long long wc_sub = wall_clock64();
+#else
+#define GROOT_SUBT(i) ((void)0)
+#endif
+            if (!have_read) {
+                GROOT_EV(3);
+                const bool virt = slot < nv;                   // an item of a split read: seed positions [vlo, vhi) of its ascending list
+                uint32_t vlo = 0, vhi = 0;
+                if (virt) {
+                    const uint4 vi = a.vitem[slot];
+                    r = vi.x; vlo = vi.y; vhi = vi.z;
+                    if (r == kEmpty) { phase = PH_WAIT; continue; }   // (found no room: its read is handled whole)
+                } else {
+                    const uint32_t so = slot - nv;
+                    r = a.perm ? a.perm[so] : so;              // reads in (first seed window, orientation) order
+                }
+                uint4 ra, rb;                                     // one 32-byte record per read
+                load32(a.read_rec + r, ra, rb);                  // (gathering the records into processing order first costs more than this dependent trip)
+                const uint32_t sc = ra.w;
+                cnt = min(sc & (kRecSplit - 1u), a.seed_slots);   // overflow already flagged; batch is re-run
+                cls = a.perm ? (sc >> 24) & 0x3Fu : 0x80u;     // bit 7: no verdicts without the seed stage's sort keys
+                if (sc & kRecAscending) cls |= 0x100u;         // bit 8: the read's seed list is in ascending window order
+                // bit 9: the windows come from the list, not from the read record; bit 10: an item (mapped / multimapped are counted
+                // with the read's first item); bit 11: a split read (multimapped was counted when it was split)
+                if (sc & kRecSplit) cls |= 0xA00u;
+                if (virt) { cnt = min(vhi, a.seed_slots); cls = 0x80u | 0x100u | 0x200u | 0x400u; }
+                if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
+                high_byte = sc >> 31;
+                len = ra.z;
+                p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
+                sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
+                if (cls & 0x200u) sd0 = vlo;                   // (ascending list: sd0 is the position in it; else sd0 / sd1 = smallest / largest window)
+                else if (cnt > 4 && (cls & 0x100u)) sd0 = 0;
+                GROOT_SUBT(0);
+                if (LDSR && 2 + 4 * ((len + 27) >> 4) > a.lds_stride_dw) {   // longer than the max_len the batch was submitted with
+                    atomicOr(&a.ctr->flags, kFlagLongRead);
+                    a.trav_cnt[(cls & 0x400u) ? a.n_reads + slot : r] = 0;
+                    phase = PH_WAIT;
+                    continue;
+                }
+                qrow = ix.q_row[len - ix.k + 1];              // graphminion.go:60 kmerCount -> its row of the call-count table
+                read_id = a.first_read_id + ((cls & 0x400u) ? a.n_reads + slot : r);   // (an item labels its records with its own slot: order_ovf_kernel)
+                n_graphs = 0; ord = 0; last = -1;
+                done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
+                have_read = true;
+                if (LDSR) {                                   // stage the read: 64 bytes per pass, the four loads in flight together
+                    my_lds[0] = 0; my_lds[1] = 0;
+                    for (uint32_t b = 0; b < len; b += 64) {       // reads at most 15 bytes past the read's end
+                        const uint4 *src = reinterpret_cast<const uint4 *>(p + b);   // unaligned 16-byte global loads
+                        const bool h1 = b + 16 < len, h2 = b + 32 < len, h3 = b + 48 < len;
+                        uint4 v0, v1 = {}, v2 = {}, v3 = {};
+                        __builtin_memcpy(&v0, src, 16);
+                        if (h1) __builtin_memcpy(&v1, src + 1, 16);
+                        if (h2) __builtin_memcpy(&v2, src + 2, 16);
+                        if (h3) __builtin_memcpy(&v3, src + 3, 16);
+                        uint32_t *d = my_lds + 2 + (b >> 2);
+                        d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w;
+                        if (h1) { d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w; }
+                        if (h2) { d[8] = v2.x; d[9] = v2.y; d[10] = v2.z; d[11] = v2.w; }
+                        if (h3) { d[12] = v3.x; d[13] = v3.y; d[14] = v3.z; d[15] = v3.w; }
+                    }
+                }
+            }
+            GROOT_SUBT(1);
+            // seeds in canonical order = ascending window id (graph, Node, OffSet, list position)
+            uint32_t nw = kEmpty;
+            if (cnt <= 4 && !(cls & 0x200u)) {                // the seeds travel in the read record
+                if ((long long)sd0 > last && sd0 < nw) nw = sd0;
+                if (cnt > 1 && (long long)sd1 > last && sd1 < nw) nw = sd1;
+                if (cnt > 2 && (long long)sd2 > last && sd2 < nw) nw = sd2;
+                if (cnt > 3 && (long long)sd3 > last && sd3 < nw) nw = sd3;
+            } else if (cls & 0x100u) {
+                // An ascending list is walked, not searched (a read of a sequence that many graphs share brings a hundred seed
+                // windows: looking through all of them for every one of them made it the slowest read of its batch by far).
+                // sd0 = first position not handled yet; after a graph is done `last` has jumped past its windows: bisect.
+                uint32_t lo = sd0;
+                uint32_t cand = lo < cnt ? a.seed_win[(size_t)lo * a.n_reads + r] : kEmpty;
+                if (lo < cnt && (long long)cand <= last) {
+                    uint32_t hi = cnt;
+                    lo++;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((long long)a.seed_win[(size_t)mid * a.n_reads + r] > last) hi = mid; else lo = mid + 1;
+                    }
+                    cand = lo < cnt ? a.seed_win[(size_t)lo * a.n_reads + r] : kEmpty;
+                }
+                if (lo < cnt) nw = cand;
+                sd0 = lo + 1;
+            } else if (last < 0) nw = sd0;                    // the smallest window, from the read record
+            else if ((long long)sd1 > last)                   // (else nothing is left: no look at the list)
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
+                    if ((long long)cand > last && cand < nw) nw = cand;
+                }
+            if (nw == kEmpty) {                               // every seed of the read handled
+                GROOT_EV(4);
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
+                atomicAdd(&a.ctr->dbg[64 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // when in its round the lane finished
+#endif
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
+                if (wc_iter - wc_round0 >= 100) {              // slow reads, by name (meaningful with GROOT_ROUND_LANES=1)
+                    const unsigned long long sl = atomicAdd(&a.ctr->dbg[128], 1ull);
+                    if (sl < 60) a.ctr->dbg[129 + sl] = (unsigned long long)r | ((unsigned long long)(wc_iter - wc_round0) << 32);
+                }
+#endif
+                a.trav_cnt[(cls & 0x400u) ? a.n_reads + slot : r] = ord;
+                if (!(cls & 0x400u)) mapped++;                // boss.go:195-200
+                if (!(cls & 0xC00u) && n_graphs > 1) multimapped++;
+                if (a.incr_cnt && n_graphs > 1) a.incr_cnt[r] |= 0x80000000u;   // (capture pass of groot_hip_open; the lane owns the read)
+                have_read = false;
+                phase = PH_WAIT;
+                continue;
+            }
+            cls = (cls & ~0x40u) | ((last < 0 && !(cls & 0x80u)) ? 0x40u : 0u);   // bit 6: w is the read's first seed window
+            w = nw; last = nw;
+            uint4 wa, wb;                                     // the whole lshe.Key in one 32-byte load
+            load32(ix.win_rec + w, wa, wb);
+            g = wa.x;
+            GROOT_SUBT(2);
+            if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
+            if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
+            if (a.update_weights) {                            // :67 IncrementSubPath
+                // neighbouring lanes mostly hold reads of the same window (processing order): one atomic per distinct cell
+                // among the lanes that are here together instead of one per lane (0.44 of 3.15 ms per 10 M reads)
+                const uint64_t cell = (uint64_t)qrow * ix.n_windows + w;
+                for (bool pending = true; pending;) {
+                    const uint64_t first = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cell) |
+                                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cell >> 32)) << 32);
+                    const unsigned long long same = __ballot(cell == first);
+                    if (cell == first) {
+                        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u)) == 0)
+                            atomicAdd(&a.attempts[first], (uint32_t)__popcll(same));
+                        pending = false;
+                    }
+                }
+            }
+            GROOT_SUBT(3);
+            if (a.incr_cnt) {              // capture pass: which windows had IncrementSubPath called, in call order
+                const uint32_t n = a.incr_cnt[r];
+                a.incr_cnt[r] = n + 1;
+                if (n < a.incr_cap) a.incr_win[(size_t)r * a.incr_cap + n] = w;
+            }
+            if (a.no_align) continue;                         // :70-72
+            seed = wa.y; off0 = wa.z;
+            l1_hi = wa.w;                                     // alignment.go:36 and :199-201, folded at open
+            cn_begin = wb.x; cn_end = wb.y;
+            seed_s0 = wb.z; seed_len = wb.w;
+            GROOT_EV(5);
+            advance = start_orientation(0);
+            GROOT_SUBT(4);
+        } else if (run == PH_SCAN) {
+            if (sc_pos >= sc_end) { GROOT_EV(6); advance = true; }   // only after a DFS that used the range's last offset
+            else {
+            // up to 16 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
+            const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
+            const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
+            const uint32_t npos = min(16u, sc_end - sc_pos);
+            const int room = (int)(sc_len - sc_pos);          // bases from sc_pos to the node end
+            uint64_t c_lo = low_bytes((int)npos), c_hi = low_bytes((int)npos - 8);
+            const uint32_t kf = min(4u, eff);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((uint32_t)b >= kf) break;
+                const unsigned rb = (unsigned)(pre8 >> (8 * b)) & 0xFF;
+                // positions whose base b lies inside the node must match it; past the node end the DFS decides
+                const uint64_t need_lo = low_bytes(room - b), need_hi = low_bytes(room - b - 8);
+                c_lo &= match_or_n(window8(w0, w1, b), rb) | ~need_lo;
+                c_hi &= match_or_n(window8(w1, w2, b), rb) | ~need_hi;
+            }
+            uint32_t j = 16;
+            if (c_lo) j = (uint32_t)__builtin_ctzll(c_lo) >> 3;
+            else if (c_hi) j = 8 + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
+            if (j >= npos) {
+                GROOT_EV(7);
+                sc_pos += npos;
+                advance = sc_pos >= sc_end;                   // set up the next range in this step: no empty one
+            } else {
+                // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
+                const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
+                const uint32_t off = sc_pos + j;
+                sc_pos = off + 1;
+                if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
+                    GROOT_EV(8);
+                    advance = sc_pos >= sc_end;
+                } else {
+                    node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
+                    cur8 = pre8;
+#pragma unroll
+                    for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
+                    phase = PH_DFS;
+                    GROOT_EV(10);
+                }
+            }
+            }
+        } else {
+            // ---- DFS: match up to 32 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
+            // The lanes stay in here for as long as the scheduling rule above would pick the phase again (lanes only leave
+            // it for FETCH or SCAN, both counted below), which saves the ballots and the refill logic per step.
+            int nd, nf, ns;
+            do {
+            if (phase == PH_DFS) {
+            RecRegs<PW> rec;
+            rec.load(recs + cur);
+            // The common step, on its own: a whole short node (<= 8 bases, from its first base, no 'N') matches, the read goes on,
+            // some path is left and exactly one neighbour can take the next base.  Everything is in the record: no graph bases, no
+            // stack, nothing to report.  Whatever does not fit falls through to the general step below, state untouched; a
+            // wavefront whose lanes all fit skips that code altogether (it is most of this kernel's instructions).
+            // (Letting the lanes that fit run ahead, step after step, while the others wait is slower: 3.08 vs 2.53 ms -- a step
+            // is a trip to L2 whatever it computes, and the general step hides some of it.)
+            bool fast_done = false;
+            {
+                const uint32_t take = min(rec.seq_len(), eff - dist);
+                const uint32_t rdeg = rec.deg();
+                if (coff == 0 && take >= 1 && take <= 8 && take == rec.seq_len() && dist + take < eff && !rec.wild() && rdeg >= 1 && rdeg <= 4 &&
+                    prefix_eq(rec.first8(), cur8, take)) {
+                    uint64_t nm[PW];
+                    bool any = false;
+#pragma unroll
+                    for (int i = 0; i < PW; i++) { nm[i] = mask[i] & rec.mask(i); any |= nm[i] != 0; }
+                    const uint64_t c8 = dfs_chunk(dist + take);
+                    const unsigned nextb = (unsigned)c8 & 0xFF;
+                    uint32_t hits = 0, pick = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned cf1 = rec.child_first(e);
+                        const bool m = (uint32_t)e < rdeg && (cf1 == 'N' || cf1 == nextb);
+                        hits += m;
+                        if (m) pick = rec.edge(e);
+                    }
+                    if (any && hits == 1) {
+#pragma unroll
+                        for (int i = 0; i < PW; i++) mask[i] = nm[i];
+                        dist += take; cur8 = c8; cur = pick; coff = 0;
+                        fast_done = true;
+                    }
+                }
+            }
+            if (!fast_done) {
+            if (coff != 0 && !(cur == node0 && coff == noff0 && dist == 0)) GROOT_EV(18);
+            const uint32_t take = min(rec.seq_len() - coff, eff - dist);
+            const uint32_t nb = min(take, 32u);
+            bool ok = true;
+            if (nb) {
+                const uint8_t *gb = ix.bases + rec.seq_off() + coff;
+                const uint64_t ga = coff == 0 ? rec.first8() : ld8(gb);
+                ok = prefix_ok(ga, cur8, min(nb, 8u));
+                for (uint32_t i = 8; ok && i < nb; i += 8)
+                    ok = prefix_ok(ld8(gb + i), dfs_chunk(dist + i), nb - i);
+            }
+            bool backtrack = !ok;
+            if (!ok) GROOT_EV(12);
+            if (take > 8) GROOT_EV(11);
+            if (take > 32) GROOT_EV(21);
+            if (ok) {
+                dist += nb; coff += nb;
+                cur8 = dfs_chunk(dist);
+                if (nb == take) {                              // node consumed (or read finished)
+                    GROOT_EV(13);
+                    bool any = false;
+#pragma unroll
+                    for (int i = 0; i < PW; i++) { mask[i] &= rec.mask(i); any |= mask[i] != 0; }
+                    const uint32_t rdeg = rec.deg();
+                    if (dist == eff || rdeg == 0) {             // :229-236 report the traversal
+                        if (any) {
+                            GROOT_EV(14);
+                            if (ord) GROOT_EV(19);
+                            groot_trav t;
+                            t.read_id = read_id; t.graph_id = g; t.node = node0; t.offset = noff0;
+                            t.ord = (uint16_t)ord;
+                            t.flags = (uint8_t)(tflags | (emitted == 0 ? GROOT_TRAV_FIRST : 0));
+                            t.reserved = 0;
+                            if (ord == 0) {                    // the common case: no allocation at all
+                                const uint32_t os = (cls & 0x400u) ? a.n_reads + slot : r;
+                                a.trav_first[os] = t;
+#pragma unroll
+                                for (int i = 0; i < PW; i++) a.mask_first[(size_t)os * PW + i] = mask[i];
+                            } else {
+                                const uint32_t shard = blockIdx.x & (kOvfShards - 1);
+                                const uint32_t slot = atomicAdd(&a.ovf_cnt[shard], 1u);
+                                if (slot < a.ovf_cap) {
+                                    const size_t o = (size_t)shard * a.ovf_cap + slot;
+                                    a.ovf_trav[o] = t;
+#pragma unroll
+                                    for (int i = 0; i < PW; i++) a.ovf_mask[o * PW + i] = mask[i];
+                                } else atomicOr(&a.ctr->flags, kFlagOvfOverflow);
+                            }
+                            if (ord >= 0xFFFFu) atomicOr(&a.ctr->flags, kFlagOrdOverflow);
+                            ord++;
+#pragma unroll
+                            for (int i = 0; i < PW; i++) alns += __popcll(mask[i]);
+                            emitted++;
+                        }
+                        backtrack = true;
+                    } else if (!any) backtrack = true;         // no path left: descendants cannot yield ids
+                    else {
+                        // :242-252 neighbours in OutEdges order; a neighbour whose first base cannot match the
+                        // next read base dies in its first comparison, so it is skipped without being visited
+                        const unsigned nextb = (unsigned)cur8 & 0xFF;
+                        uint32_t first = kEmpty, more = kEmpty;
+                        if (rdeg <= 4) {
+#pragma unroll
+                            for (int e = 3; e >= 0; e--) {
+                                const unsigned cf1 = rec.child_first(e);
+                                if ((uint32_t)e < rdeg && (cf1 == 'N' || cf1 == nextb)) { more = first; first = e; }
+                            }
+                        } else { first = 0; more = 1; }
+                        if (first == kEmpty) backtrack = true;
+                        else {
+                            if (more != kEmpty) {              // further candidates stay pending
+                                GROOT_EV(15);
+                                const size_t si = (size_t)sp * a.n_threads + gtid;
+                                a.stk_hdr[si] = (uint64_t)cur | ((uint64_t)more << 32) | ((uint64_t)dist << 48);
+#pragma unroll
+                                for (int i = 0; i < PW; i++) a.stk_mask[si * PW + i] = mask[i];
+                                sp++;
+                            }
+                            if (rdeg <= 4) {                   // select, not index: keeps the record in registers
+                                cur = rec.edge(0);
+                                if (first == 1) cur = rec.edge(1);
+                                if (first == 2) cur = rec.edge(2);
+                                if (first == 3) cur = rec.edge(3);
+                            } else cur = ix.edges[rec.edge(0) + first];
+                            coff = 0;
+                        }
+                    }
+                }
+            }
+            if (backtrack) {
+                GROOT_EV(16);
+                if (sp == 0) {                                 // performAlignment is over
+                    if (emitted) {                             // alignment found for (read, graph)
+                        done_graph = g; phase = PH_FETCH;
+                        // graphminion.go:96-98 passes over the graph's other seeds: they are the windows up to the graph's last one
+                        // (a read below the window size can bring a hundred of them: one FETCH step instead of one each)
+                        if (ix.graph_win_end) last = (long long)ix.graph_win_end[g] - 1;
+                    }
+                    else phase = PH_SCAN;
+                } else {                                       // resume at the newest pending neighbour
+                    GROOT_EV(17);
+                    const size_t si = (size_t)(sp - 1) * a.n_threads + gtid;
+                    const uint64_t hdr = a.stk_hdr[si];
+                    const uint32_t pn = (uint32_t)hdr, e = (uint32_t)(hdr >> 32) & 0xFFFFu;
+                    dist = (uint32_t)(hdr >> 48);
+#pragma unroll
+                    for (int i = 0; i < PW; i++) mask[i] = a.stk_mask[si * PW + i];
+                    cur8 = dfs_chunk(dist);
+                    RecRegs<PW> pr;
+                    pr.load(recs + pn);
+                    const uint32_t deg = pr.deg();
+                    uint32_t more = kEmpty;
+                    if (deg <= 4) {
+                        const unsigned nextb = (unsigned)cur8 & 0xFF;
+#pragma unroll
+                        for (int e2 = 3; e2 >= 1; e2--) {
+                            const unsigned cf1 = pr.child_first(e2);
+                            if ((uint32_t)e2 > e && (uint32_t)e2 < deg && (cf1 == 'N' || cf1 == nextb)) more = e2;
+                        }
+                        cur = pr.edge(0);
+                        if (e == 1) cur = pr.edge(1);
+                        if (e == 2) cur = pr.edge(2);
+                        if (e == 3) cur = pr.edge(3);
+                    } else {
+                        if (e + 1 < deg) more = e + 1;
+                        cur = ix.edges[pr.edge(0) + e];
+                    }
+                    coff = 0;
+                    if (more == kEmpty) sp--;
+                    else a.stk_hdr[si] = (uint64_t)pn | ((uint64_t)more << 32) | ((uint64_t)dist << 48);
+                }
+            }
+            }   // general step
+            }
+#ifdef GROOT_WORK_COUNTERS
+            wc_iter++;                                         // (events of the steps inside this loop are merged)
+#endif
+            nd = __popcll(__ballot(phase == PH_DFS));
+            nf = cf + __popcll(__ballot(phase == PH_FETCH));
+            ns = cs + __popcll(__ballot(phase == PH_SCAN));
+            } while (nd > 0 && nd >= ns && nd >= nf);
+        }
+        if (advance) next_range();
+#ifdef GROOT_WORK_COUNTERS
+        {   // wall-clock ticks (100 MHz) and steps of this phase execution (wave-uniform values)
+            const unsigned long long dt = wall_clock64() - wc_t0;
+            const uint32_t st = run == PH_DFS ? wc_iter - wc_steps0 : 1u;
+            if (run == PH_FETCH) { wc_t[0] += dt; wc_n[0] += st; } else if (run == PH_SCAN) { wc_t[1] += dt; wc_n[1] += st; } else { wc_t[2] += dt; wc_n[2] += st; }
+        }
+#endif
+    }
+
+#ifdef GROOT_WORK_COUNTERS
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 3; i++) { atomicAdd(&a.ctr->dbg[24 + i], wc_t[i]); atomicAdd(&a.ctr->dbg[27 + i], (unsigned long long)wc_n[i]); }
+#endif
+    alns = block_sum(alns, red);
+    mapped = block_sum(mapped, red);
+    multimapped = block_sum(multimapped, red);
+    panics = block_sum(panics, red);
+    if (threadIdx.x == 0) {
+        if (alns) atomicAdd(&a.ctr->alignments, alns);
+        if (a.update_weights) {
+            if (mapped) atomicAdd(&a.ctr->mapped, mapped);
+            if (multimapped) atomicAdd(&a.ctr->multimapped, multimapped);
+            if (panics) atomicAdd(&a.ctr->revcomp_panics, panics);
+        }
+    }
+}
+
+
+} // namespace groot

@@ -585,36 +585,17 @@ def test_configs4_at_single_gpu_scale(resfinder_index, threshold):
     al.close()
 
 
-@pytest.mark.parametrize("threshold", [0.97, 0.90])
-def test_wave_cooperative_lsh_query_kernel(resfinder_index, threshold, monkeypatch):
-    """lsh_query_kernel (opt-in, GROOT_LSH_KERNEL=1: the hashing kernels hand the sketches of reads on the LSH-Forest branch to a kernel
-    that deals the rows of equal band prefix of 64 reads over the lanes of a wavefront -- ballot + popcount on the signature filter,
-    owners verify their survivors) returns what the per-lane walk returns and what the oracle returns (lshe.go:153-175)"""
-    global KEEP_SKETCHES
-    KEEP_SKETCHES = False                                  # (with sketches kept the full-width kernel answers alone)
-    monkeypatch.setenv("GROOT_LSH_KERNEL", "1")
-    index = resfinder_index
-    cat, o, lens = synth.reference_sequences(index)
-    seq, off, _ = synth.reads_np(cat, o, lens, 12000, 150, first=777, min_len=60)
-    al, counts, run = run_both(index, seq, off, threshold=threshold)
-    assert_same(al, counts, run, index)
-    assert counts["seeds"] > counts["mapped"] > 1000
-    al.close()
-
-
-@pytest.mark.parametrize("variant", ["default", "no_split", "no_heavy_kernel"])
+@pytest.mark.parametrize("variant", ["default", "small_buffers"])
 def test_reads_with_many_seed_windows(argannot_index, monkeypatch, variant):
     """reads shorter than the windows at a low threshold bring dozens of seed windows, of several graphs: their lists are sorted and
     cut at graph boundaries into items that different lanes of the align stage take (device_types.hpp kSplitMin; records and
     counters put right by split_fix / order_split / order_ovf), and reads with many candidate rows on the LSH-Forest branch get a
     wavefront each (lsh_heavy_kernel).  Seeds, records in (read, ord) order, counters and call counts equal the oracle's
-    (lshe.go:153-175, graphminion.go:46-102) -- and equal what the ctx produces with either mechanism switched off"""
-    for v in ("GROOT_NO_SPLIT", "GROOT_NO_LSH_KERNEL", "GROOT_LSH_KERNEL", "GROOT_LSH_DEFER"):
-        monkeypatch.delenv(v, raising=False)
-    if variant == "no_split":
-        monkeypatch.setenv("GROOT_NO_SPLIT", "1")
-    if variant == "no_heavy_kernel":
-        monkeypatch.setenv("GROOT_NO_LSH_KERNEL", "1")
+    (lshe.go:153-175, graphminion.go:46-102) -- and equal what the ctx produces when the item list holds 8 items and the heavy list 4
+    reads (GROOT_TEST_SMALL_BUFFERS): most such reads then find no room and are handled whole / walk their own rows"""
+    monkeypatch.delenv("GROOT_TEST_SMALL_BUFFERS", raising=False)
+    if variant == "small_buffers":
+        monkeypatch.setenv("GROOT_TEST_SMALL_BUFFERS", "1")
     index = argannot_index
     cat, o, lens = synth.reference_sequences(index)
     seq, off, _ = synth.reads_np(cat, o, lens, 12000, 99, min_len=70)
