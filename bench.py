@@ -38,7 +38,7 @@ sys.path.insert(0, REPO)
 
 READ_LEN = 100
 HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
-PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc.json")   # {workload: {kernel: per-launch counters}}, tools/profile_r04.sh
 
 
 def usable_cpus():
@@ -124,6 +124,107 @@ def cpu_baseline(index_path, seconds):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def pmc_of(workload, kernel):
+    """per-launch PMC figures of `kernel` on `workload` from the committed profile (separate rocprofv3 --pmc passes of tools/kernel_path_probe.py:
+    they cannot run inside this process); {} when absent"""
+    try:
+        return json.load(open(PMC_FILE)).get(workload, {}).get(kernel, {})
+    except Exception:
+        return {}
+
+
+def kernel_blocks(workload, ms, counts, R, mean_len, pw):
+    """per-kernel roofline of the hashing / graph-walk path for one workload: live HIP-event time of the kernel (groot_stage_ms), the
+    algorithmic bytes of SURVEY 8d for the reads that kernel handles, and -- from the committed PMC passes -- HBM traffic and VALU issue"""
+    todo, walked, travs = counts["full_sketch_reads"], counts["walked_reads"], counts["travs"]
+    spec = {
+        # every read: bases + u64 offset in; seed count, scheduling key, 32-byte read record out
+        "sketch_sig_kernel": (ms["first_seed_kernel"], R, R * (mean_len + 8) + R * (4 + 4 + 32)),
+        # the reads the first kernel could not decide: bases + offset in, seeds + key + record out
+        "sketch_seed_kernel<LIST>": (ms["list_pass"], todo, todo * (mean_len + 8) + todo * (4 + 4 + 32) + 4 * counts["seeds"]),
+        # the reads that need the graph walk: record + bases + seeds in; traversal record + path set + count out
+        "align_kernel": (ms["align"], walked, walked * (32 + mean_len + 4) + (20 + 8 * pw) * travs + 4 * R),
+    }
+    out = {}
+    for k, (t_ms, n, b) in spec.items():
+        e = {"kernel_ms": t_ms, "reads": n, "bytes_per_launch": b}
+        if t_ms > 0:
+            e["achieved"] = b / (t_ms * 1e-3) / 1e9
+            e["frac"] = e["achieved"] / HBM_PEAK_GBS
+        p = pmc_of(workload, k.split("<")[0])
+        if p:
+            e["traffic"] = p.get("hbm_bytes_per_launch")
+            pl = p.get("per_launch", {})
+            if pl.get("SQ_WAVE_CYCLES"):
+                # share of the resident waves' cycles in which a VALU instruction issued (4 cycles each)
+                e["valu_issue"] = 4.0 * pl.get("SQ_INSTS_VALU", 0.0) / pl["SQ_WAVE_CYCLES"] if pl.get("SQ_INSTS_VALU") else None
+                e["wait_frac"] = pl.get("SQ_WAIT_ANY", 0.0) / pl["SQ_WAVE_CYCLES"]
+            e["pmc_kernel_ms"] = p.get("avg_ms")
+            e["traffic_source"] = "profiles/r04_pmc.json[%s]" % workload
+        out[k] = e
+    return out
+
+
+def substituted(d_seq, R, p, gen):
+    """a copy of the batch with every base replaced by another one with probability p"""
+    import torch
+
+    dev = d_seq.device
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    err = d_seq.clone()
+    rows = err[: R * READ_LEN].view(R, READ_LEN)
+    CH = 1_000_000
+    for c0 in range(0, R, CH):
+        n = min(CH, R - c0)
+        hit = torch.rand(n, READ_LEN, generator=gen, device=dev) < p
+        cur = torch.searchsorted(acgt, rows[c0:c0 + n].contiguous())          # A C G T -> 0..3
+        other = acgt[(cur + 1 + torch.randint(0, 3, (n, READ_LEN), generator=gen, device=dev)) % 4]
+        rows[c0:c0 + n] = torch.where(hit, other, rows[c0:c0 + n])
+    return err
+
+
+def kernel_path(index, d_seq, d_off, R, steps, local_rank, pw):
+    """BASELINE configs[2] through the north_star kernels themselves: a ctx WITHOUT the memo of groot_hip_open (no outcome table, no
+    text table), so every read is hashed (sketch_sig_kernel; what it cannot decide: sketch_seed_kernel<LIST>), looked up and walked
+    through its graph (align_kernel) -- khf.go:35-55, lshe.go:153-175, alignment.go:13-254.  Then the same ctx on reads with 1 %
+    substitutions."""
+    import torch
+
+    from groot_amd import device
+
+    env = {"GROOT_NO_OUTCOME_TABLE": "1", "GROOT_NO_TEXT_TABLE": "1"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        al = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64, results_on_device=True, pipeline_depth=2)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    al.set_profiling(True)
+    out = {"what": "configs[2] with the memo off (GROOT_NO_OUTCOME_TABLE, GROOT_NO_TEXT_TABLE): every read goes through hashing, containment lookup and the graph walk",
+           "open_ms": al.open_stats()["open_ms"]}
+    v, ms, c = resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
+    out["error_free"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "full_sketch_reads": c["full_sketch_reads"], "walked_reads": c["walked_reads"], "mapped": c["mapped"],
+                         "alignments": c["alignments"], "kernels": kernel_blocks("c2_nomemo", ms, c, R, READ_LEN, pw),
+                         "whole_step": {"bytes": R * (READ_LEN + 4) + 4 * R + 8 * c["seeds"] + (20 + 8 * pw) * c["travs"]}}
+    ws = out["error_free"]["whole_step"]
+    ws["ms"] = R / v / 1e3
+    ws["achieved"] = ws["bytes"] / (ws["ms"] * 1e-3) / 1e9
+    ws["frac"] = ws["achieved"] / HBM_PEAK_GBS
+    g = torch.Generator(device=d_seq.device)
+    g.manual_seed(0x67726F6F74)
+    err = substituted(d_seq, R, 0.01, g)
+    v, ms, c = resident_rate(al, err.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
+    out["substitutions_1pct"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "full_sketch_reads": c["full_sketch_reads"], "walked_reads": c["walked_reads"],
+                                 "mapped": c["mapped"], "kernels": kernel_blocks("sub1_nomemo", ms, c, R, READ_LEN, pw)}
+    del err
+    al.close()
+    return out
+
+
 def resident_rate(al, d_seq_ptr, d_off_ptr, R, max_len, steps, warmup, mixed=False):
     """`steps` batches of R reads that sit in HBM through ctx `al`, two in flight (the ctx is a pipeline: the next batch is
     enqueued while the GPU works on this one); returns (Mreads/s, mean stage ms, counts of the last batch)"""
@@ -160,17 +261,11 @@ def robustness(al, index, d_seq, d_off, R, steps):
     CH = 1_000_000
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     # (a) substitution errors: every base is replaced by another one with probability 0.01 (63 % of the reads hold at least one)
-    err = d_seq.clone()
-    rows = err[: R * READ_LEN].view(R, READ_LEN)
-    for c0 in range(0, R, CH):
-        n = min(CH, R - c0)
-        hit = torch.rand(n, READ_LEN, generator=g, device=dev) < 0.01
-        cur = torch.searchsorted(acgt, rows[c0:c0 + n].contiguous())          # A C G T -> 0..3
-        other = acgt[(cur + 1 + torch.randint(0, 3, (n, READ_LEN), generator=g, device=dev)) % 4]
-        rows[c0:c0 + n] = torch.where(hit, other, rows[c0:c0 + n])
+    err = substituted(d_seq, R, 0.01, g)
     v, ms, c = resident_rate(al, err.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
     out["substitutions_1pct"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "mapped": c["mapped"], "full_sketch_reads": c["full_sketch_reads"],
-                                 "walked_reads": c["walked_reads"], "what": "each base replaced with probability 0.01: reads with an error take the hashing kernels"}
+                                 "walked_reads": c["walked_reads"], "what": "each base replaced with probability 0.01: reads with an error take the hashing kernels",
+                                 "kernels": kernel_blocks("sub1", ms, c, R, READ_LEN, index.view.path_words)}
     # (b) metagenome-like: 99 % of the reads are uniform random ACGT
     rows = err[: R * READ_LEN].view(R, READ_LEN)
     rows[:] = d_seq[: R * READ_LEN].view(R, READ_LEN)
@@ -226,7 +321,9 @@ def mixed_leg(local_rank, n_reads, steps, cli_reads, bam_level):
         al.set_profiling(True)
         v, ms, c = resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), n_reads, 150, steps, 2, mixed=True)
         out["kernels"]["t=%.2f" % t] = {"value": v, "unit": "Mreads/s", "mapped": c["mapped"], "seeds_per_read": c["seeds"] / n_reads,
-                                         "alignments": c["alignments"], "walked_reads": c["walked_reads"], "stage_ms": ms}
+                                         "alignments": c["alignments"], "walked_reads": c["walked_reads"], "full_sketch_reads": c["full_sketch_reads"], "stage_ms": ms}
+        if t in (0.99, 0.90):
+            out["kernels"]["t=%.2f" % t]["kernels"] = kernel_blocks("mixed%d" % round(t * 100), ms, c, n_reads, total / n_reads, index.view.path_words)
         if t == 0.99 and n_reads > 2_000_000:
             # the align stage of such a batch lasts at least as long as its slowest read (~2 ms: 150 dependent steps): smaller batches
             # of the same stream pay that floor for fewer reads
@@ -585,7 +682,7 @@ def main():
         pmc_key = dom.split(" ")[0]
         if os.path.exists(PMC_FILE):
             try:
-                rec = json.load(open(PMC_FILE)).get(pmc_key, {})
+                rec = json.load(open(PMC_FILE)).get("headline", {}).get(pmc_key, {})
                 traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -604,7 +701,7 @@ def main():
                                     "pipeline on every such string (DESIGN.md); robustness.* below is the same ctx on reads the memo cannot answer"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r03_pmc.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "traffic_source": "profiles/r04_pmc.json[headline] (separate rocprofv3 --pmc passes of this command)" if traffic else None,
                          "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
                          "note": "table lookups and scattered record writes: bound by random 64-byte HBM accesses and call-count atomics, not by streaming bandwidth (DESIGN.md)",
                          "whole_step": {"bytes": step_bytes, "ms": step_ms, "achieved": step_bytes / (step_ms * 1e-3) / 1e9,
@@ -621,6 +718,10 @@ def main():
             al.close()
             al = None
             if not args.no_legs:
+                try:
+                    line["kernel_path"] = kernel_path(index, d_seq, d_off, R, args.leg_steps, local_rank, pw)
+                except Exception as e:
+                    line["kernel_path"] = {"error": repr(e)}
                 try:
                     line["thresholds"] = threshold_sweep(index, d_seq, d_off, R, args.leg_steps, local_rank)
                 except Exception as e:

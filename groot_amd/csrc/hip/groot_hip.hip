@@ -71,7 +71,7 @@ template <class T> struct PinBuf {
 
 // The environment switches of the shipped library, read when a ctx is opened (everything else that used to be tunable from the
 // environment was an experiment and went in round 4: DESIGN.md "Removed").  The three NO_* switch a tier of the seed stage off (tests
-// compare the tiers with each other and with the oracle); TEST_SMALL_BUFFERS starts every growable buffer and list too small, so that
+// compare the tiers with each other and with the CPU checker); TEST_SMALL_BUFFERS starts every growable buffer and list too small, so that
 // a test batch walks the grow-and-redo and the fall-back paths; OPEN_STATS prints where groot_hip_open spent its time.
 struct Knobs {
     bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false;
@@ -92,6 +92,7 @@ struct Slot {
     State state = FREE;
     uint64_t ticket = 0;
     uint32_t n_reads = 0, first_read_id = 0, max_len = 0;
+    uint32_t set = 0;                      // groot_ctx::ws the batch runs through
     uint32_t uniform_len = 0;              // IN_PACKED16: every read has this length (0 = lengths differ): no length array on the wire
     bool mixed_len = false;                // the reads are known to differ in length (the align stage then refills its wavefronts earlier)
     bool text_used = false;                // text_lookup_kernel ran first (the list behind it goes through the full-width kernel)
@@ -127,8 +128,9 @@ struct Slot {
     uint32_t n_trav = 0, copied = 0;               // records of the batch / records the copy-out enqueued at submit covers
     uint64_t n_mask_words = 0, copied_words = 0;
     bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
+    hipEvent_t ev_seed = nullptr;          // behind the batch's seed stage on the compute stream: its align stage waits for it
     hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
-    hipEvent_t ev[11]{};                   // [7..8] around the first seed kernel, [9..10] around order_first_kernel
+    hipEvent_t ev[13]{};                   // [7..8] around the first seed kernel, [9..10] around order_first_kernel, [11] start of the align stage (align stream), [12] behind the list pass
                                            // [0..6] stage boundaries on the compute stream (profiling)
     groot_counts counts{};
     int status = GROOT_OK;
@@ -138,13 +140,27 @@ struct Slot {
     const uint64_t *off() const { return input == IN_DEVICE ? ext_off : d_off.p; }
 };
 
+// One of the two sets of buffers a batch's seed stage fills for its align and order stages (groot_ctx::ws)
+struct WorkSet {
+    DevBuf<uint32_t> seed_count, seed_win, perm, perm_count, trav_cnt, tab_idx;
+    DevBuf<ReadRec> read_rec;
+    DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
+    DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
+    DevBuf<groot_trav> trav_first;
+    DevBuf<uint64_t> mask_first, sketches;
+    hipEvent_t ev_free = nullptr;          // on the align stream behind the order stage of the batch that used the set last
+    bool used = false;
+    Slot *owner = nullptr;                 // whose seeds / sketches the set holds
+    uint64_t ticket = 0;
+};
+
 struct groot_ctx {
     int device = 0;
     std::string err;
     groot_params prm{};
     Knobs kn;
     uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, astream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;   // stream: seed stage (the caller's, if given); astream: align + order stage
     bool profiling = false;
 
     // index in HBM
@@ -191,28 +207,28 @@ struct groot_ctx {
     std::vector<uint32_t> h_node_graph;    // graph of every node (the expansion)
     DevBuf<uint8_t> graph_words;           // ceil(paths / 64) per graph
     std::vector<uint8_t> h_graph_words;
-    Slot *work_owner = nullptr;            // whose seeds / sketches the shared work buffers hold
-    uint64_t work_ticket = 0;
+    // What the seed stage of a batch leaves for its align and order stages lives in one of TWO work sets, taken in turn: the seed
+    // stage of batch b+1 (compute stream) runs beside the align + order stages of batch b (align stream) -- the reference's sketching
+    // minions and graph minions run side by side too (boss.go:134-203, graphminion.go:46-102).  Hashing is VALU-issue bound, the
+    // graph walk waits on dependent loads: they want different resources.
+    WorkSet ws[2];
+    uint32_t next_set = 0;
 
-    // shared work buffers (compute stream only)
+    // shared work buffers: used on ONE of the two streams only, inside one stage
     uint32_t seed_slots = 0;
-    DevBuf<uint32_t> seed_count, seed_win, sort_key, sort_key_out, perm_in, perm, perm_count, todo_list, todo_count;
-    DevBuf<uint32_t> long_list, long_count;              // SeedArgs::long_list
-    DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
-    DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
+    DevBuf<uint32_t> sort_key, sort_key_out, perm_in, todo_list, todo_count;   // seed stage
+    DevBuf<uint32_t> long_list, long_count;              // SeedArgs::long_list (seed stage)
     uint32_t vcap = 0;
     uint32_t lsh_defer_rows = 0, lsh_cap = 0;   // SeedArgs::lsh_defer_rows
     DevBuf<unsigned long long> seed_shards;
-    DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch + their sketches, for lsh_query_kernel (absent: per-lane row walks)
+    DevBuf<uint32_t> lsh_list, lsh_count;  // reads on the LSH-Forest branch with many candidate rows + their sketches, for lsh_heavy_kernel (seed stage)
     DevBuf<uint64_t> lsh_sketch;
-    DevBuf<char> sort_tmp;
-    DevBuf<ReadRec> read_rec;
-    DevBuf<uint64_t> sketches;
+    DevBuf<char> sort_tmp, in_tmp;         // rocprim scratch of the seed stage / of the input decoding (compute stream)
     uint32_t ovf_cap = 0;
-    DevBuf<groot_trav> trav_first, ovf_trav;
-    DevBuf<uint64_t> mask_first, ovf_mask;
-    DevBuf<uint32_t> trav_cnt, trav_off, ovf_cnt;
-    DevBuf<char> scan_tmp;
+    DevBuf<groot_trav> ovf_trav;           // align + order stage
+    DevBuf<uint64_t> ovf_mask;
+    DevBuf<uint32_t> trav_off, ovf_cnt;
+    DevBuf<char> scan_tmp;                 // rocprim scratch of the order stage (align stream)
     // DFS stacks
     uint32_t align_threads = 0, stk_depth = 0;
     DevBuf<uint64_t> stk_hdr, stk_mask;
@@ -466,7 +482,7 @@ static constexpr uint32_t kMaxLdsReadBytes = 64 * 1024;
 static int alloc_seed_slots(groot_ctx *c, uint32_t slots)
 {
     c->seed_slots = slots;
-    HIP_TRY(c, c->seed_win.alloc((size_t)slots * c->prm.max_batch_reads));
+    for (WorkSet &w : c->ws) HIP_TRY(c, w.seed_win.alloc((size_t)slots * c->prm.max_batch_reads));
     return GROOT_OK;
 }
 
@@ -532,6 +548,7 @@ static uint32_t list_lds_stride(uint32_t stride_dw)
 }
 static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
+    WorkSet *w = &c->ws[s->set];
     SeedArgs a{};
     a.ix = c->dix;
     a.seq = s->seq();
@@ -541,18 +558,18 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     const uint64_t want = (uint64_t)kBlock * s->max_len + 32;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>(want, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots;
-    a.seed_count = c->seed_count.p;
-    a.seed_win = c->seed_win.p;
-    a.sketch_out = c->prm.keep_sketches ? c->sketches.p : nullptr;
+    a.seed_count = w->seed_count.p;
+    a.seed_win = w->seed_win.p;
+    a.sketch_out = c->prm.keep_sketches ? w->sketches.p : nullptr;
     a.sort_key = c->sort_key.p;
-    a.read_rec = c->read_rec.p;
+    a.read_rec = w->read_rec.p;
     a.q_seen = c->q_seen.p;
-    a.trav_cnt = c->trav_cnt.p;
+    a.trav_cnt = w->trav_cnt.p;
     a.shards = c->seed_shards.p;
     a.ctr = s->d_ctr.p;
     a.long_list = c->long_list.p; a.long_count = c->long_count.p;
     if (c->dix.out_tab) {                                   // reads the signature kernel finds in the outcome table say so here
-        a.tab_idx = c->tab_idx.p;
+        a.tab_idx = w->tab_idx.p;
         a.tab_hist = c->tab_hist.p;
     }
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
@@ -585,7 +602,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.lsh_defer_rows = c->lsh_defer_rows; a.lsh_cap = c->lsh_cap;
         HIP_TRY(c, hipMemsetAsync(c->lsh_count.p, 0, 2 * sizeof(uint32_t), c->stream));
     }
-    HIP_TRY(c, hipMemsetAsync(c->vcount.p, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(w->vcount.p, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[7], c->stream));
     if (s->text_used) {
         a.todo_list = c->todo_list.p;
@@ -595,8 +612,8 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const size_t lds = kTextBad + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
         if (list_mode) {       // the reads left for the graph walk are a subset of the lookup's misses: the list pass appends them itself
-            a.dfs_list = c->perm.p; a.dfs_count = c->perm_count.p;
-            HIP_TRY(c, hipMemsetAsync(c->perm_count.p, 0, sizeof(uint32_t), c->stream));
+            a.dfs_list = w->perm.p; a.dfs_count = w->perm_count.p;
+            HIP_TRY(c, hipMemsetAsync(w->perm_count.p, 0, sizeof(uint32_t), c->stream));
         }
         launch_text_lookup(text_key_dwords((c->dix.w + 15) / 16), a, grid, lds, c->stream);
         HIP_TRY(c, hipGetLastError());
@@ -610,23 +627,28 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         a.list_stride_dw = list_lds_stride(stride_dw);
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
         const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;   // (+: the kernel reads whole register rows past a read)
-        launch_sig(c->s, a, s->max_len, grid, lds, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
+        launch_sig(c->s, a, s->max_len, grid, lds, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
+        launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
     } else {
         const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
         launch_seed(c->s, c->max_k, a, c->prm.keep_sketches != 0, grid, lds, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
     }
     // the reads of the LSH-Forest branch with many candidate rows: a wavefront each
     if (a.lsh_list) hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, 2048u)), dim3(kBlock), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
-    if (c->profiling && !s->text_used) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));   // (signature kernel + its list pass / the full-width kernel)
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[12], c->stream));   // (the list pass behind the first kernel + the heavy LSH-Forest reads)
     // seed lists of more than four windows that are not ascending (LSH-Forest hits come in band order): sorted, a wavefront per read
     // ... and the longest ones cut into items that different lanes of the align stage take
     {
         SplitArgs sa{};
-        sa.list = c->long_list.p; sa.count = c->long_count.p; sa.seed_count = c->seed_count.p; sa.seed_win = c->seed_win.p;
-        sa.n_reads = s->n_reads; sa.seed_slots = c->seed_slots; sa.read_rec = c->read_rec.p; sa.win_rec = c->dix.win_rec;
+        sa.list = c->long_list.p; sa.count = c->long_count.p; sa.seed_count = w->seed_count.p; sa.seed_win = w->seed_win.p;
+        sa.n_reads = s->n_reads; sa.seed_slots = c->seed_slots; sa.read_rec = w->read_rec.p; sa.win_rec = c->dix.win_rec;
         sa.split = c->vcap && !c->tab_capture && !c->prm.no_exact_align;
-        sa.vitem = c->vitem.p; sa.vcount = c->vcount.p; sa.vcap = c->vcap; sa.split_list = c->split_list.p;
+        sa.vitem = w->vitem.p; sa.vcount = w->vcount.p; sa.vcap = c->vcap; sa.split_list = w->split_list.p;
         sa.ctr = s->d_ctr.p; sa.update_weights = update_weights ? 1 : 0;
         hipLaunchKernelGGL(sort_seed_lists_kernel, dim3(2048), dim3(kBlock), 0, c->stream, sa);
     }
@@ -646,30 +668,31 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         size_t tb = 0;
         HasKey pred{c->sort_key.p};
         rocprim::counting_iterator<uint32_t> ids(0u);
-        HIP_TRY(c, rocprim::select(nullptr, tb, ids, c->perm.p, c->perm_count.p, (size_t)s->n_reads, pred, c->stream));
+        HIP_TRY(c, rocprim::select(nullptr, tb, ids, w->perm.p, w->perm_count.p, (size_t)s->n_reads, pred, c->stream));
         if (tb > c->sort_tmp.n) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, c->sort_tmp.alloc(tb + tb / 4));
         }
-        HIP_TRY(c, rocprim::select(c->sort_tmp.p, tb, ids, c->perm.p, c->perm_count.p, (size_t)s->n_reads, pred, c->stream));
+        HIP_TRY(c, rocprim::select(c->sort_tmp.p, tb, ids, w->perm.p, w->perm_count.p, (size_t)s->n_reads, pred, c->stream));
         return GROOT_OK;
     }
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p, s->n_reads, 0,
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, w->perm.p, s->n_reads, 0,
                                          end_bit, c->stream));
     if (tmp_bytes > c->sort_tmp.n) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes + tmp_bytes / 4));
     }
-    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, c->perm.p,
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, w->perm.p,
                                          s->n_reads, 0, end_bit, c->stream));
     return GROOT_OK;
 }
 
 static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
+    WorkSet *w = &c->ws[s->set];
     AlignArgs a{};
     a.ix = c->dix;
     a.seq = s->seq();
@@ -677,28 +700,29 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     a.n_reads = s->n_reads;
     a.first_read_id = s->first_read_id;
     a.seed_slots = c->seed_slots;
-    a.seed_count = c->seed_count.p;
-    a.seed_win = c->seed_win.p;
-    a.perm = c->perm.p;
-    a.read_rec = c->read_rec.p;
+    a.seed_count = w->seed_count.p;
+    a.seed_win = w->seed_win.p;
+    a.perm = w->perm.p;
+    a.read_rec = w->read_rec.p;
     a.no_align = c->prm.no_exact_align;
     a.update_weights = update_weights ? 1 : 0;
     a.attempts = c->attempts_ptr;
     a.node_rec = c->node_rec.p;
-    a.trav_first = c->trav_first.p;
-    a.mask_first = c->mask_first.p;
-    a.trav_cnt = c->trav_cnt.p;
+    a.trav_first = w->trav_first.p;
+    a.mask_first = w->mask_first.p;
+    a.trav_cnt = w->trav_cnt.p;
     a.ovf_trav = c->ovf_trav.p;
     a.ovf_mask = c->ovf_mask.p;
     a.ovf_cnt = c->ovf_cnt.p;
     a.ovf_cap = c->ovf_cap;
-    if (c->vcap) { a.vitem = c->vitem.p; a.vcount = c->vcount.p; a.vcap = c->vcap; }
+    if (c->vcap) { a.vitem = w->vitem.p; a.vcount = w->vcount.p; a.vcap = c->vcap; }
     a.stk_hdr = c->stk_hdr.p;
     a.stk_mask = c->stk_mask.p;
     uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
     // (few reads left for the walk -- the latest batch says so: half the persistent grid starts and drains 0.05 ms sooner and the
     // slowest read, not the number of wavefronts, sets the duration anyway)
     if (c->dfs_frac < kSparseBelow) blocks = std::max(1u, blocks / 2);
+    if (const char *e = getenv("GROOT_DEV_ALIGN_PER_CU")) blocks = std::min<uint32_t>(blocks, 256u * (uint32_t)std::max(1, atoi(e)));   // DEV-ONLY (round 4 measurement), to be removed
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB
@@ -709,13 +733,13 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     }
     if (c->tab_capture) {
         a.incr_cnt = c->incr_cnt.p; a.incr_win = c->incr_win.p; a.incr_cap = c->incr_cap;
-        HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->astream));
     }
     a.head_lanes = s->mixed_len ? 16u : 0u;              // (8: best at 2 M reads before the items of split reads took the head; 16: 2.9 / 5.2 ms at 2 M / 8 M reads, 8 gave 3.05 / 5.6)
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
     a.ctr = s->d_ctr.p;
-    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->stream));   // + the two chunk cursors
-    launch_align(c->pw, a, dim3(blocks), c->stream);
+    HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->astream));   // + the two chunk cursors
+    launch_align(c->pw, a, dim3(blocks), c->astream);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
 }
@@ -723,68 +747,78 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
 // traversal records -> (read, ord) order: exclusive scan of the per-read counts, then two scatters into the slot's output
 static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
+    WorkSet *w = &c->ws[s->set];
     const uint32_t n = s->n_reads;
     size_t tmp_bytes = 0;
     // split reads: their items' counts become the read's count, every item learns where its records go in the read's run
-    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(256), dim3(kBlock), 0, c->stream, c->split_list.p, c->vcount.p, c->vitem.p, c->trav_cnt.p, n, s->d_ctr.p);
-    HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
+    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(256), dim3(kBlock), 0, c->astream, w->split_list.p, w->vcount.p, w->vitem.p, w->trav_cnt.p, n, s->d_ctr.p);
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, w->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->astream));
     if (tmp_bytes > c->scan_tmp.n) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->astream));
         HIP_TRY(c, c->scan_tmp.alloc(tmp_bytes + tmp_bytes / 4));
     }
-    HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->stream, c->trav_off.p, c->trav_cnt.p, n, s->d_ctr.p);
+    HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, w->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->astream));
+    hipLaunchKernelGGL(order_total_kernel, dim3(1), dim3(1), 0, c->astream, c->trav_off.p, w->trav_cnt.p, n, s->d_ctr.p);
     OrderTabArgs ot{};
     if (c->dix.out_tab) {
-        ot.tab_idx = c->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
+        ot.tab_idx = w->tab_idx.p; ot.out_tab = c->dix.out_tab; ot.stride_q = c->dix.out_stride_q; ot.first_read_id = s->first_read_id;
         ot.update_weights = update_weights ? 1 : 0;
         ot.attempts = c->attempts_ptr; ot.q_row = c->q_row.p;
         ot.q_tab = c->dix.w - c->k + 1; ot.n_windows = c->n_windows;
     }
-    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[9], c->stream));
-    hipLaunchKernelGGL(order_first_kernel, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, 2048u)), dim3(kBlock), 0, c->stream, c->trav_first.p,
-                       c->mask_first.p, c->trav_off.p, c->trav_cnt.p, n, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw,
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[9], c->astream));
+    hipLaunchKernelGGL(order_first_kernel, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, 2048u)), dim3(kBlock), 0, c->astream, w->trav_first.p,
+                       w->mask_first.p, c->trav_off.p, w->trav_cnt.p, n, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw,
                        c->pw_view, s->d_ctr.p, ot);
-    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[10], c->stream));
-    if (c->vcap) hipLaunchKernelGGL(order_split_kernel, dim3(std::min<uint32_t>((c->vcap + kBlock - 1) / kBlock, 256u)), dim3(kBlock), 0, c->stream, c->vitem.p, c->vcount.p, c->vcap, c->trav_cnt.p,
-                                    c->trav_off.p, c->trav_first.p, c->mask_first.p, n, s->first_read_id, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
-    hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->stream,
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[10], c->astream));
+    if (c->vcap) hipLaunchKernelGGL(order_split_kernel, dim3(std::min<uint32_t>((c->vcap + kBlock - 1) / kBlock, 256u)), dim3(kBlock), 0, c->astream, w->vitem.p, w->vcount.p, c->vcap, w->trav_cnt.p,
+                                    c->trav_off.p, w->trav_first.p, w->mask_first.p, n, s->first_read_id, s->d_trav.p, s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p);
+    hipLaunchKernelGGL(order_ovf_kernel, dim3((c->ovf_cap + kBlock - 1) / kBlock, kOvfShards), dim3(kBlock), 0, c->astream,
                        c->ovf_trav.p, c->ovf_mask.p, c->ovf_cnt.p, c->ovf_cap, c->trav_off.p, s->first_read_id, s->d_trav.p,
-                       s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p, c->vitem.p, n);
+                       s->d_mask.p, s->trav_cap, c->pw, c->pw_view, s->d_ctr.p, w->vitem.p, n);
     HIP_TRY(c, hipGetLastError());
     if (!c->prm.results_on_device) {
         // compact path sets for the copy-out (kernels.hpp): words per traversal, their exclusive scan, the copy
         const dim3 g((s->trav_cap + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(mask_words_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_ctr.p, s->trav_cap, c->graph_words.p, (uint32_t)c->h_graph_words.size(),
+        hipLaunchKernelGGL(mask_words_kernel, g, dim3(kBlock), 0, c->astream, s->d_trav.p, s->d_ctr.p, s->trav_cap, c->graph_words.p, (uint32_t)c->h_graph_words.size(),
                            s->d_mwords.p);
         size_t tb = 0;
-        HIP_TRY(c, rocprim::exclusive_scan(nullptr, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
+        HIP_TRY(c, rocprim::exclusive_scan(nullptr, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->astream));
         if (tb > c->scan_tmp.n) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->astream));
             HIP_TRY(c, c->scan_tmp.alloc(tb + tb / 4));
         }
-        HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->stream));
-        hipLaunchKernelGGL(mask_compact_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_mask.p, c->pw_view, s->d_ctr.p, s->trav_cap,
+        HIP_TRY(c, rocprim::exclusive_scan(c->scan_tmp.p, tb, s->d_mwords.p, s->d_moff.p, 0u, s->trav_cap, rocprim::plus<uint32_t>(), c->astream));
+        hipLaunchKernelGGL(mask_compact_kernel, g, dim3(kBlock), 0, c->astream, s->d_trav.p, s->d_mask.p, c->pw_view, s->d_ctr.p, s->trav_cap,
                            c->graph_words.p, (uint32_t)c->h_graph_words.size(), s->d_moff.p, s->d_cmask.p, s->d_ckpt.p);
-        if (c->packed_travs) hipLaunchKernelGGL(trav_pack_kernel, g, dim3(kBlock), 0, c->stream, s->d_trav.p, s->d_ctr.p, s->trav_cap, s->first_read_id, s->d_ctrav.p);
+        if (c->packed_travs) hipLaunchKernelGGL(trav_pack_kernel, g, dim3(kBlock), 0, c->astream, s->d_trav.p, s->d_ctr.p, s->trav_cap, s->first_read_id, s->d_ctrav.p);
         HIP_TRY(c, hipGetLastError());
     }
     return GROOT_OK;
 }
 
-// sketch+seed -> schedule -> align -> order for the batch of slot s, on the compute stream
+// sketch+seed -> schedule (compute stream) | align -> order (align stream) for the batch of slot s
 static int run_batch_async(groot_ctx *c, Slot *s, bool update_weights)
 {
+    WorkSet *w = &c->ws[s->set];
+    // compute stream: the seed stage, once the batch that used this work set last is through its order stage
+    if (w->used) HIP_TRY(c, hipStreamWaitEvent(c->stream, w->ev_free, 0));
     HIP_TRY(c, hipMemsetAsync(s->d_ctr.p, 0, sizeof(DeviceCounters), c->stream));
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[1], c->stream));
     if (int rc = launch_seed_stage(c, s, update_weights)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[3], c->stream));
+    HIP_TRY(c, hipEventRecord(s->ev_seed, c->stream));
+    // align stream: graph walk and ordering, beside the seed stage of the next batch
+    HIP_TRY(c, hipStreamWaitEvent(c->astream, s->ev_seed, 0));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[11], c->astream));
     if (int rc = launch_align_stage(c, s, update_weights)) return rc;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[4], c->stream));
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[4], c->astream));
     if (int rc = launch_order_stage(c, s, update_weights)) return rc;
-    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[5], c->stream));
-    c->work_owner = s;
-    c->work_ticket = s->ticket;
+    if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[5], c->astream));
+    HIP_TRY(c, hipEventRecord(w->ev_free, c->astream));
+    w->used = true;
+    w->owner = s;
+    w->ticket = s->ticket;
     return GROOT_OK;
 }
 
@@ -912,15 +946,17 @@ static int enqueue(groot_ctx *c, Slot *s)
             auto in = rocprim::make_transform_iterator(s->d_len.p, LenToU64());
             size_t tmp_bytes = 0;
             HIP_TRY(c, rocprim::inclusive_scan(nullptr, tmp_bytes, in, s->d_off.p + 1, s->n_reads, rocprim::plus<uint64_t>(), c->stream));
-            if (tmp_bytes > c->scan_tmp.n) {
+            if (tmp_bytes > c->in_tmp.n) {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
-                HIP_TRY(c, c->scan_tmp.alloc(tmp_bytes + tmp_bytes / 4));
+                HIP_TRY(c, c->in_tmp.alloc(tmp_bytes + tmp_bytes / 4));
             }
-            HIP_TRY(c, rocprim::inclusive_scan(c->scan_tmp.p, tmp_bytes, in, s->d_off.p + 1, s->n_reads, rocprim::plus<uint64_t>(), c->stream));
+            HIP_TRY(c, rocprim::inclusive_scan(c->in_tmp.p, tmp_bytes, in, s->d_off.p + 1, s->n_reads, rocprim::plus<uint64_t>(), c->stream));
         }
     }
+    s->set = c->next_set;
+    c->next_set ^= 1u;
     if (int rc = run_batch_async(c, s, true)) return rc;
-    HIP_TRY(c, hipEventRecord(s->ev_compute, c->stream));
+    HIP_TRY(c, hipEventRecord(s->ev_compute, c->astream));
     // Copy-out on its own stream with no host in between.  The record count is only known on the device, and asking for it
     // would put a host round trip between the last kernel and the copy; so the copy engine is given a PREDICTED count now
     // -- records per read of the latest finished batch, plus a margin -- and collect fetches the rest in the rare batch
@@ -991,8 +1027,8 @@ static int finish_counters(groot_ctx *c, Slot *s)
 {
     DeviceCounters &h = *s->h_ctr.p;
     auto refetch = [&](DeviceCounters &dst) -> int {
-        HIP_TRY(c, hipMemcpyAsync(s->h_ctr.p, s->d_ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_ctr.p, s->d_ctr.p, sizeof(DeviceCounters), hipMemcpyDeviceToHost, c->astream));
+        HIP_TRY(c, hipStreamSynchronize(c->astream));
         dst = *s->h_ctr.p;
         return GROOT_OK;
     };
@@ -1007,6 +1043,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
         // batch as a whole.  A pass whose align stage did nothing (seed slots / table rows ran out) is simply repeated;
         // after any other overflow the weights and read counters of the first pass stand and only records are re-made.
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->astream));
         bool redo_weights = !have_first;
         if (fl & (kFlagSeedOverflow | kFlagQOverflow)) {
             if (fl & kFlagSeedOverflow) { if (int rc = alloc_seed_slots(c, h.max_seeds + 4)) return rc; }
@@ -1141,11 +1178,13 @@ static int collect_impl(groot_ctx *c, Slot **out)
         (void)hipEventElapsedTime(&s->ms.unpack, s->ev[0], s->ev[1]);
         (void)hipEventElapsedTime(&s->ms.sketch_seed, s->ev[1], s->ev[2]);
         (void)hipEventElapsedTime(&s->ms.schedule, s->ev[2], s->ev[3]);
-        (void)hipEventElapsedTime(&s->ms.align, s->ev[3], s->ev[4]);
+        (void)hipEventElapsedTime(&s->ms.align, s->ev[11], s->ev[4]);
         (void)hipEventElapsedTime(&s->ms.sort, s->ev[4], s->ev[5]);
         (void)hipEventElapsedTime(&s->ms.total, s->ev[0], s->ev[5]);
         (void)hipEventElapsedTime(&s->ms.first_seed_kernel, s->ev[7], s->ev[8]);
         (void)hipEventElapsedTime(&s->ms.order_kernel, s->ev[9], s->ev[10]);
+        (void)hipEventElapsedTime(&s->ms.list_pass, s->ev[8], s->ev[12]);
+        (void)hipEventElapsedTime(&s->ms.wall, s->ev[1], s->ev[5]);
         if (!c->prm.results_on_device) (void)hipEventElapsedTime(&s->ms.d2h, s->ev_d2h0, s->ev_d2h);
     }
     c->inflight.pop_front();
@@ -1160,6 +1199,7 @@ static int drain(groot_ctx *c)     // everything submitted has finished on the d
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->inflight.empty()) { if (int rc = progress(c, c->inflight.back())) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->astream));
     HIP_TRY(c, hipStreamSynchronize(c->d2h_stream));
     return GROOT_OK;
 }
@@ -1200,16 +1240,20 @@ void groot_hip_close(groot_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->astream) (void)hipStreamSynchronize(ctx->astream);
     if (ctx->h2d_stream) (void)hipStreamSynchronize(ctx->h2d_stream);
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (auto &s : ctx->slots) {
-        for (hipEvent_t e : {s->ev_h2d0, s->ev_h2d, s->ev_compute, s->ev_ctr, s->ev_d2h0, s->ev_d2h})
+        for (hipEvent_t e : {s->ev_seed, s->ev_h2d0, s->ev_h2d, s->ev_compute, s->ev_ctr, s->ev_d2h0, s->ev_d2h})
             if (e) (void)hipEventDestroy(e);
         for (auto &e : s->ev)
             if (e) (void)hipEventDestroy(e);
     }
     ctx->slots.clear();
+    for (WorkSet &w : ctx->ws)
+        if (w.ev_free) (void)hipEventDestroy(w.ev_free);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->astream) (void)hipStreamDestroy(ctx->astream);
     if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     delete ctx;
@@ -1470,8 +1514,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                 HIP_TRY(c, hipMemcpy(travs.data(), done->d_trav.p, (size_t)nt * sizeof(groot_trav), hipMemcpyDeviceToHost));
                 HIP_TRY(c, hipMemcpy(masks.data(), done->d_mask.p, (size_t)nt * pw * sizeof(uint64_t), hipMemcpyDeviceToHost));
             }
-            HIP_TRY(c, hipMemcpy(nseeds.data(), c->seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(nseeds.data(), c->ws[done->set].seed_count.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy2D(seedw.data(), (size_t)m * 4, c->ws[done->set].seed_win.p, (size_t)m * 4, (size_t)m * 4, seed_rows, hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(icnt.data(), c->incr_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(iwin.data(), c->incr_win.p, (size_t)m * incr_cap * 4, hipMemcpyDeviceToHost));
         }
@@ -1554,7 +1598,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
         HIP_TRY(c, hipMemset(c->q_seen.p, 0, (size_t)(c->max_q + 2) * 4));
         HIP_TRY(c, hipMemset(c->q_nrows.p, 0, 4));
         if (c->att_cap) HIP_TRY(c, hipMemset(c->attempts_ptr, 0, (size_t)c->att_cap * c->n_windows * sizeof(uint32_t)));
-        c->work_owner = nullptr;
+        for (WorkSet &w : c->ws) w.owner = nullptr;
         c->trav_per_read = 1.25; c->words_per_trav = 0; c->dfs_frac = 1.0;
     }
     if (rc_all) return rc_all;
@@ -1590,7 +1634,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     HIP_TRY(c, hipMemcpy(c->out_tab.p, tab.data(), (c->out_entries * sq + 4) * sizeof(uint4), hipMemcpyHostToDevice));
     c->h_out_tab = std::move(tab);
     HIP_TRY(c, hipMemcpy(c->sig_info.p, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(c, c->tab_idx.alloc(c->prm.max_batch_reads));
+    for (WorkSet &w : c->ws) HIP_TRY(c, w.tab_idx.alloc(c->prm.max_batch_reads));
     HIP_TRY(c, c->tab_hist.alloc(c->n_windows));
     HIP_TRY(c, hipMemset(c->tab_hist.p, 0, (size_t)c->n_windows * sizeof(uint32_t)));
     c->dix.out_tab = c->out_tab.p;
@@ -1816,12 +1860,14 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->max_q = c->prm.max_read_len - c->k + 1;
 
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->astream, hipStreamNonBlocking));
+    for (WorkSet &w : c->ws) HIP_TRY(c, hipEventCreateWithFlags(&w.ev_free, hipEventDisableTiming));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (uint32_t i = 0; i < c->prm.pipeline_depth; i++) {
         std::unique_ptr<Slot> s(new Slot());
-        for (hipEvent_t *e : {&s->ev_h2d0, &s->ev_h2d, &s->ev_compute, &s->ev_ctr, &s->ev_d2h0, &s->ev_d2h}) HIP_TRY(c, hipEventCreate(e));
+        for (hipEvent_t *e : {&s->ev_seed, &s->ev_h2d0, &s->ev_h2d, &s->ev_compute, &s->ev_ctr, &s->ev_d2h0, &s->ev_d2h}) HIP_TRY(c, hipEventCreate(e));
         for (auto &e : s->ev) HIP_TRY(c, hipEventCreate(&e));
         c->slots.push_back(std::move(s));
     }
@@ -2073,12 +2119,8 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     lap("per-kmerCount tables");
     // ---- shared work buffers (inputs / outputs are per pipeline slot, allocated at their first use) ----
     const uint32_t R = c->prm.max_batch_reads;
-    HIP_TRY(c, c->seed_count.alloc(R));
     HIP_TRY(c, c->sort_key.alloc(R));
-    HIP_TRY(c, c->read_rec.alloc(R));
     HIP_TRY(c, c->sort_key_out.alloc(R));
-    HIP_TRY(c, c->perm.alloc(R));
-    HIP_TRY(c, c->perm_count.alloc(4));
     HIP_TRY(c, c->long_list.alloc(kLongListCap));
     HIP_TRY(c, c->long_count.alloc(4));
     HIP_TRY(c, hipMemset(c->long_count.p, 0, 4 * sizeof(uint32_t)));
@@ -2088,16 +2130,22 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->perm_in, iota.data(), iota.size()));
     }
     if (int rc = alloc_seed_slots(c, c->prm.max_seeds_per_read)) return rc;
-    if (c->prm.keep_sketches) HIP_TRY(c, c->sketches.alloc((size_t)R * s));
     // (+ vcap slots behind the reads: the items of split reads, AlignArgs::vitem)
     c->vcap = c->kn.small_buffers ? 8u : std::max<uint32_t>(4096, R / 4);   // (small: most split reads find no room for their items and are handled whole)
-    HIP_TRY(c, c->trav_first.alloc((size_t)R + c->vcap));
-    HIP_TRY(c, c->mask_first.alloc(((size_t)R + c->vcap) * c->pw));
-    HIP_TRY(c, c->trav_cnt.alloc((size_t)R + c->vcap));
-    HIP_TRY(c, c->vitem.alloc(std::max<uint32_t>(c->vcap, 1)));
-    HIP_TRY(c, c->split_list.alloc(kLongListCap));
-    HIP_TRY(c, c->vcount.alloc(4));
-    HIP_TRY(c, hipMemset(c->vcount.p, 0, 4 * sizeof(uint32_t)));
+    for (WorkSet &w : c->ws) {     // what a batch's seed stage hands to its align and order stages: two sets, taken in turn
+        HIP_TRY(c, w.seed_count.alloc(R));
+        HIP_TRY(c, w.read_rec.alloc(R));
+        HIP_TRY(c, w.perm.alloc(R));
+        HIP_TRY(c, w.perm_count.alloc(4));
+        if (c->prm.keep_sketches) HIP_TRY(c, w.sketches.alloc((size_t)R * s));
+        HIP_TRY(c, w.trav_first.alloc((size_t)R + c->vcap));
+        HIP_TRY(c, w.mask_first.alloc(((size_t)R + c->vcap) * c->pw));
+        HIP_TRY(c, w.trav_cnt.alloc((size_t)R + c->vcap));
+        HIP_TRY(c, w.vitem.alloc(std::max<uint32_t>(c->vcap, 1)));
+        HIP_TRY(c, w.split_list.alloc(kLongListCap));
+        HIP_TRY(c, w.vcount.alloc(4));
+        HIP_TRY(c, hipMemset(w.vcount.p, 0, 4 * sizeof(uint32_t)));
+    }
     HIP_TRY(c, c->trav_off.alloc(R));
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
     if (int rc = alloc_ovf(c, c->kn.small_buffers ? 2u : std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
@@ -2460,12 +2508,12 @@ int groot_hip_read_travs(groot_ctx *c, groot_trav *out, uint64_t *masks, uint64_
     return GROOT_OK;
 }
 
-// seeds and sketches stay in the shared work buffers: they are the waited batch's only while no newer batch has run
+// seeds and sketches stay in the batch's work set: they are the waited batch's only until a newer batch runs through that set
 static int work_buffers_of_waited(groot_ctx *c)
 {
     Slot *s = c->waited;
     if (!s) return fail(c, GROOT_E_STATE, "no finished batch");
-    if (s->n_reads && (c->work_owner != s || c->work_ticket != s->ticket))
+    if (s->n_reads && (c->ws[s->set].owner != s || c->ws[s->set].ticket != s->ticket))
         return fail(c, GROOT_E_STATE, "a newer batch has been submitted: the seeds / sketches of the waited batch are gone");
     return GROOT_OK;
 }
@@ -2479,14 +2527,14 @@ int groot_hip_read_seeds(groot_ctx *c, groot_seed *out, uint64_t cap, uint64_t *
     const uint32_t R = s->n_reads;
     std::vector<uint32_t> cnt(R), win((size_t)c->seed_slots * R);
     if (R) {
-        HIP_TRY(c, hipMemcpy(cnt.data(), c->seed_count.p, (size_t)R * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(win.data(), c->seed_win.p, (size_t)c->seed_slots * R * 4, hipMemcpyDeviceToHost));   // [slot][R], R = this batch
+        HIP_TRY(c, hipMemcpy(cnt.data(), c->ws[s->set].seed_count.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(win.data(), c->ws[s->set].seed_win.p, (size_t)c->seed_slots * R * 4, hipMemcpyDeviceToHost));   // [slot][R], R = this batch
     }
     // reads the text lookup answered have their seed windows in the outcome table, not in the seed slots
     std::vector<uint32_t> tidx;
     if (R && c->dix.out_tab && !c->h_out_tab.empty()) {
         tidx.resize(R);
-        HIP_TRY(c, hipMemcpy(tidx.data(), c->tab_idx.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(tidx.data(), c->ws[s->set].tab_idx.p, (size_t)R * 4, hipMemcpyDeviceToHost));
     }
     const size_t ed = (size_t)c->dix.out_stride_q * 4;       // dwords per entry
     uint64_t total = 0;
@@ -2521,7 +2569,7 @@ int groot_hip_read_sketches(groot_ctx *c, uint64_t *out, uint64_t cap_reads, uin
     HIP_TRY(c, hipSetDevice(c->device));
     *n_reads = c->waited->n_reads;
     const uint64_t m = std::min<uint64_t>(cap_reads, c->waited->n_reads);
-    if (m && out) HIP_TRY(c, hipMemcpy(out, c->sketches.p, m * c->s * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (m && out) HIP_TRY(c, hipMemcpy(out, c->ws[c->waited->set].sketches.p, m * c->s * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return GROOT_OK;
 }
 
@@ -2808,7 +2856,7 @@ int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     a.ix.max_q = 0;   // no lookup: every read gets min_eq = S+1
     a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = c->prm.max_read_len;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * std::min(max_len, c->prm.max_read_len) + 32, kMaxLdsReadBytes);
-    a.seed_slots = c->seed_slots; a.seed_count = c->seed_count.p; a.seed_win = c->seed_win.p;
+    a.seed_slots = c->seed_slots; a.seed_count = c->ws[0].seed_count.p; a.seed_win = c->ws[0].seed_win.p;
     a.sketch_out = sk.p; a.sort_key = nullptr; a.read_rec = nullptr; a.q_seen = nullptr; a.ctr = ctr.p; a.shards = c->seed_shards.p;
     launch_seed(c->s, c->max_k, a, true, dim3((n + kBlock - 1) / kBlock), kLdsReads + ((a.lds_read_bytes + 15) & ~15u), c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -2816,7 +2864,7 @@ int groot_hip_sketch(groot_ctx *c, const uint8_t *seq_concat, const uint64_t *se
     HIP_TRY(c, hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, sk.p, (size_t)n * c->s * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->work_owner = nullptr;       // the seed slots were used as scratch
+    c->ws[0].owner = nullptr;      // its seed slots were used as scratch
     if (h.flags & kFlagShortRead) return fail(c, GROOT_E_SHORT_READ, "k size is greater than sequence length");
     if (h.flags & kFlagLongRead) return fail(c, GROOT_E_NOSPACE, "a sequence is longer than max_read_len=%u", c->prm.max_read_len);
     return GROOT_OK;

@@ -8,18 +8,17 @@
 
 namespace groot {
 
-// sketch_sig_kernel + the list pass of sketch_seed_kernel behind it: instances for the (sketch size, k) pairs that have a
+// sketch_sig_kernel and the list pass of sketch_seed_kernel that follows it (or the text lookup): instances for the (sketch size, k) pairs that have a
 // strength-reduced sketch_seed_kernel
 template <int S, int M5> static void launch_list_sm(const SeedArgs &a, dim3 list_grid, hipStream_t st)
 {
     hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
 }
-template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
+template <int S, int M5> static void launch_sig_sm(const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, hipStream_t st)
 {
     // (reads of up to 128 bases: half the registers and instructions in the text comparison)
     if (max_len <= 128) hipLaunchKernelGGL((sketch_sig_kernel<S, M5, 8>), grid, dim3(kBlock), lds, st, a);
     else hipLaunchKernelGGL((sketch_sig_kernel<S, M5, (int)kTextMax / 16>), grid, dim3(kBlock), lds, st, a);
-    launch_list_sm<S, M5>(a, list_grid, st);
 }
 void launch_list(uint32_t s, const SeedArgs &a, dim3 list_grid, hipStream_t st)
 {
@@ -37,15 +36,15 @@ bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
     if (max_k != 4) return false;
     return (s == 21 && (m5 == 6 || m5 == 10 || m5 == 14 || m5 == 2)) || (s == 20 && m5 == 6) || (s == 30 && m5 == 14);
 }
-void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, dim3 list_grid, hipStream_t st)
+void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, dim3 grid, size_t lds, hipStream_t st)
 {
     const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, max_len, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, max_len, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, max_len, grid, lds, list_grid, st);
-    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, max_len, grid, lds, list_grid, st);
-    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, max_len, grid, lds, list_grid, st);
-    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, max_len, grid, lds, list_grid, st);
+    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, max_len, grid, lds, st);
+    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, max_len, grid, lds, st);
+    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, max_len, grid, lds, st);
+    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, max_len, grid, lds, st);
+    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, max_len, grid, lds, st);
+    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, max_len, grid, lds, st);
 }
 
 void launch_text_lookup(uint32_t key_dwords, const SeedArgs &a, dim3 grid, size_t lds, hipStream_t st)

@@ -39,7 +39,7 @@ class OpenStats(C.Structure):
 
 
 class StageMs(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack", "first_seed_kernel", "order_kernel")]
+    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack", "first_seed_kernel", "order_kernel", "list_pass", "wall")]
 
 
 class BatchBuffers(C.Structure):

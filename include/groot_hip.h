@@ -87,6 +87,11 @@ typedef struct groot_stage_ms {
      * batch first (text lookup / signature kernel / full-width kernel), inside sketch_seed; order_kernel = order_first_kernel,
      * inside sort */
     float first_seed_kernel, order_kernel;
+    /* list_pass = what runs behind the first seed kernel inside sketch_seed: the full-width hashing kernel on the reads the first
+     * kernel could not decide (LIST instance) + the wavefront-per-read LSH-Forest walk; 0 when the full-width kernel ran alone.
+     * wall = first kernel of the batch .. last kernel of the batch on the wall clock of the device: the seed stage of the next
+     * batch runs beside this batch's align stage, so wall < sketch_seed + schedule + align + sort of two neighbouring batches */
+    float list_pass, wall;
 } groot_stage_ms;
 
 int groot_hip_device_count(int *n);
@@ -192,8 +197,8 @@ int groot_hip_in_flight(groot_ctx *ctx, uint32_t *submitted_not_collected, uint3
 int groot_hip_wait(groot_ctx *ctx, groot_counts *counts);
 int groot_hip_read_travs(groot_ctx *ctx, groot_trav *out, uint64_t *masks /* [cap*path_words] */, uint64_t cap,
                          uint64_t *n);
-/* seeds / sketches live in the ctx's shared work buffers: readable only while the waited batch is the newest one
- * submitted (GROOT_E_STATE otherwise) */
+/* seeds / sketches live in one of the ctx's two work sets (batches take them in turn): readable until the second batch
+ * submitted after the waited one has started, i.e. always for the newest batch and the one before it (GROOT_E_STATE otherwise) */
 int groot_hip_read_seeds(groot_ctx *ctx, groot_seed *out, uint64_t cap, uint64_t *n);
 int groot_hip_read_sketches(groot_ctx *ctx, uint64_t *out /* [cap_reads*sketch_size] */, uint64_t cap_reads,
                             uint64_t *n_reads);

@@ -201,14 +201,16 @@ def test_results_on_device_and_legacy_reads(small_index):
     assert len(recs) == len(per[0]) and all(np.array_equal(recs[f], per[0][f]) for f in per[0].dtype.names)
     seeds0 = al.seeds()
     assert len(seeds0)
-    # seeds / sketches live in the shared work buffers: gone once a newer batch has been submitted
-    al.submit(*batches[0]); al.submit(*batches[1])
+    # seeds / sketches live in one of the two work sets, which batches take in turn: gone once the second newer batch has been submitted
+    al.submit(*batches[0]); al.submit(*batches[1]); al.submit(*batches[0])
     al.wait()
     with pytest.raises(host.GrootError) as e:
         al.seeds()
     assert e.value.code == -9
     al.wait()
     assert len(al.seeds())
+    al.wait()
+    assert np.array_equal(al.seeds(), seeds0)
     al.close()
 
 
