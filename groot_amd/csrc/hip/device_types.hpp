@@ -162,9 +162,10 @@ struct DeviceIndex {
     // per window: which read prefixes (6-mer codes of oriented bases [0,6) and [6,12), 2 bits per base A=0 C=1 T=2 G=3)
     // can be spelled from any level-1 / level-2 start position of AlignRead (alignment.go:34-70): 2 x 4096 bits
     const uint32_t *win_prefix;
-    // per node: which 4-mers (2 bits per base) can be spelled from its offsets 0..10 (level 2 of AlignRead, alignment.go:47-70), the
-    // graph's 'N' and the bases past the node's end counting as wildcards: 256 bits; null = none
-    const uint32_t *node_pre4;
+    // per ContainedNodes entry (cn_node order: windows one after the other, ascending SegmentID within a window) a 32-byte prefix
+    // record = two uint4: bytes 0..23 the node's first 24 bases (0 past its end), dword 6 the global node index, dword 7 its length --
+    // level 2 of AlignRead (alignment.go:47-70: offsets 0..10 of every contained node) reads nothing else until a start position matches
+    const uint4 *cn_pre;
     // lookup structures
     const ExactEntry *exact;        // open addressing, exact_mask+1 slots
     uint32_t exact_mask;

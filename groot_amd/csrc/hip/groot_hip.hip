@@ -165,7 +165,7 @@ struct groot_ctx {
 
     // index in HBM
     DevBuf<uint32_t> graph_win_end;
-    DevBuf<uint32_t> node_pre4;
+    DevBuf<uint4> cn_pre;                  // DeviceIndex::cn_pre
     DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
         band_keys, band_ids;
     DevBuf<ExactEntry> band_hash;
@@ -722,7 +722,6 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     // (few reads left for the walk -- the latest batch says so: half the persistent grid starts and drains 0.05 ms sooner and the
     // slowest read, not the number of wavefronts, sets the duration anyway)
     if (c->dfs_frac < kSparseBelow) blocks = std::max(1u, blocks / 2);
-    if (const char *e = getenv("GROOT_DEV_ALIGN_PER_CU")) blocks = std::min<uint32_t>(blocks, 256u * (uint32_t)std::max(1, atoi(e)));   // DEV-ONLY (round 4 measurement), to be removed
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB
@@ -737,6 +736,9 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     }
     a.head_lanes = s->mixed_len ? 16u : 0u;              // (8: best at 2 M reads before the items of split reads took the head; 16: 2.9 / 5.2 ms at 2 M / 8 M reads, 8 gave 3.05 / 5.6)
     a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
+#ifdef GROOT_WORK_COUNTERS
+    if (const char *e = getenv("GROOT_DEV_ROUND")) a.round_lanes = (uint32_t)atoi(e);   // instrumented builds only (tools/slow_reads_probe.py: one read per round)
+#endif
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->astream));   // + the two chunk cursors
     launch_align(c->pw, a, dim3(blocks), c->astream);
@@ -1905,31 +1907,17 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         for (auto &x : th) x.join();
         HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
-    {   // which 4-mers the level-2 start positions of every node can spell
-        std::vector<uint32_t> pre((size_t)v->n_nodes * 8, 0);
-        for (uint32_t nd = 0; nd < v->n_nodes; nd++) {
+    {   // level 2 of AlignRead: the first 24 bases, index and length of every ContainedNodes entry, in list order (DeviceIndex::cn_pre)
+        std::vector<uint32_t> pre((size_t)v->n_cn * 8 + 8, 0);
+        for (uint64_t i = 0; i < v->n_cn; i++) {
+            const uint32_t nd = v->cn_node[i];
             const uint32_t s0 = v->node_seq_off[nd], nlen = v->node_seq_off[nd + 1] - s0;
-            uint32_t *bits = &pre[(size_t)nd * 8];
-            for (uint32_t o = 0; o < std::min(nlen, 11u); o++) {
-                // every code compatible with the four positions (a wildcard position takes all four bases)
-                uint32_t codes[256], nc = 1;
-                codes[0] = 0;
-                for (uint32_t b = 0; b < 4; b++) {
-                    const uint8_t ch = o + b < nlen ? v->bases[s0 + o + b] : (uint8_t)'N';
-                    const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-                    if (acgt) {
-                        for (uint32_t i = 0; i < nc; i++) codes[i] |= (uint32_t)((ch >> 1) & 3u) << (2 * b);
-                    } else {
-                        for (uint32_t i = 0; i < nc; i++)
-                            for (uint32_t x = 1; x < 4; x++) codes[nc * x + i] = codes[i] | (x << (2 * b));
-                        nc *= 4;
-                    }
-                }
-                for (uint32_t i = 0; i < nc; i++) bits[codes[i] >> 5] |= 1u << (codes[i] & 31);
-            }
+            uint32_t *e = &pre[(size_t)i * 8];
+            memcpy(e, v->bases + s0, std::min(nlen, 24u));
+            e[6] = nd; e[7] = nlen;
         }
-        HIP_TRY(c, upload(c->node_pre4, pre.data(), pre.size()));
-        c->dix.node_pre4 = c->node_pre4.p;
+        HIP_TRY(c, upload(c->cn_pre, reinterpret_cast<const uint4 *>(pre.data()), pre.size() / 4));
+        c->dix.cn_pre = c->cn_pre.p;
     }
     lap("node records + prefix tables");
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));

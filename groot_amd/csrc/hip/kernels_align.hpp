@@ -204,12 +204,22 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         return no;
     };
     // the current scan range is used up: move through the hierarchy until a non-empty range or the end
+    // (no loads in here: level 2 reads DeviceIndex::cn_pre, whose next entry is the next address)
     auto next_range = [&]() {
         for (;;) {
-            if (level == 1) { level = 2; cn_cur = cn_begin; }
-            else if (level == 2) cn_cur++;
-            else if (level == 3) {
+            if (level == 1) {                               // 2. seed node shuffling (:47-70): offsets 0..10 of every contained node
+                level = 2; cn_cur = cn_begin; sc_pos = 0; sc_end = 11;
+                if (cn_cur < cn_end) return;
+            } else if (level == 2) {
+                level = 3;                                  // 3. hard clip the first base (:72-85)
+                if (off0 >= seed_len) { level = 4; continue; }   // :199-201 holds for levels 3 and 4 alike
+                if (verdict(kRecNo3F)) continue;
+                set_view(1, len - 1, GROOT_TRAV_START_CLIP);
+                scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
+                return;
+            } else if (level == 3) {
                 level = 4;                                  // 4. hard clip the last base (:87-103)
+                if (off0 >= seed_len) continue;
                 if (verdict(kRecNo4F)) continue;            // its single start position fails the first comparison
                 set_view(0, len - 1, GROOT_TRAV_END_CLIP);
                 scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
@@ -225,45 +235,34 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 } else phase = PH_FETCH;                     // both orientations failed: next mapping
                 return;
             }
-            if (level == 2) {                               // 2. seed node shuffling (:47-70): offsets 0..10
-                // Contained nodes none of whose offsets 0..10 can spell the first four read bases would each cost a SCAN step
-                // that finds nothing (its 4-base filter is the same test): DeviceIndex::node_pre4 says so per node, four nodes
-                // per pair of trips.  A read that fails everywhere walks every contained node of every seed window in both
-                // orientations -- it is the slowest read of its batch, and the launch lasts as long as it does.
-                if (ix.node_pre4 && eff >= 4u && cn_cur < cn_end) {
-                    const int c4 = kmer4_code(pre8);
-                    if (c4 >= 0) {
-                        const uint32_t wi = (uint32_t)c4 >> 5, bi = (uint32_t)c4 & 31u;
-                        while (cn_cur < cn_end) {
-                            const uint32_t left = cn_end - cn_cur;
-                            const uint32_t n0 = ix.cn_node[cn_cur], n1 = left > 1 ? ix.cn_node[cn_cur + 1] : n0, n2 = left > 2 ? ix.cn_node[cn_cur + 2] : n0,
-                                           n3 = left > 3 ? ix.cn_node[cn_cur + 3] : n0;
-                            const uint32_t w0 = ix.node_pre4[(size_t)n0 * 8 + wi], w1 = ix.node_pre4[(size_t)n1 * 8 + wi], w2 = ix.node_pre4[(size_t)n2 * 8 + wi],
-                                           w3 = ix.node_pre4[(size_t)n3 * 8 + wi];
-                            uint32_t hit = 4;
-                            if (left > 3 && ((w3 >> bi) & 1u)) hit = 3;
-                            if (left > 2 && ((w2 >> bi) & 1u)) hit = 2;
-                            if (left > 1 && ((w1 >> bi) & 1u)) hit = 1;
-                            if ((w0 >> bi) & 1u) hit = 0;
-                            cn_cur += min(hit, left);
-                            if (hit < 4) break;
-                        }
-                    }
-                }
-                if (cn_cur < cn_end) {
-                    const uint32_t node = ix.cn_node[cn_cur];
-                    const uint32_t nlen = recs[node].seq_len;
-                    scan_range(node, recs[node].seq_off, nlen, 0, min(nlen, 11u));
-                    return;
-                }
-                level = 3;                                  // 3. hard clip the first base (:72-85)
-                if (off0 >= seed_len) { level = 4; continue; }   // :199-201 holds for levels 3 and 4 alike
-                if (verdict(kRecNo3F)) continue;
-                set_view(1, len - 1, GROOT_TRAV_START_CLIP);
-                scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
-                return;
-            }
         }
+    };
+    // which of the start offsets [0, npos) of a base string (w0, w1, w2 = its first 24 bytes; `room` of them lie inside the node) can
+    // spell the first min(4, eff) read bases?  0x80 per surviving offset: offsets 0..7 in lo, 8..15 in hi
+    auto filter16 = [&](const uint64_t w0, const uint64_t w1, const uint64_t w2, const int npos, const int room, uint64_t &c_lo, uint64_t &c_hi) {
+        c_lo = low_bytes(npos); c_hi = low_bytes(npos - 8);
+        const uint32_t kf = min(4u, eff);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if ((uint32_t)b >= kf) break;
+            const unsigned rb = (unsigned)(pre8 >> (8 * b)) & 0xFF;
+            // positions whose base b lies inside the node must match it; past the node end the DFS decides
+            const uint64_t need_lo = low_bytes(room - b), need_hi = low_bytes(room - b - 8);
+            c_lo &= match_or_n(window8(w0, w1, b), rb) | ~need_lo;
+            c_hi &= match_or_n(window8(w1, w2, b), rb) | ~need_hi;
+        }
+    };
+    auto first16 = [](const uint64_t c_lo, const uint64_t c_hi) -> uint32_t {
+        if (c_lo) return (uint32_t)__builtin_ctzll(c_lo) >> 3;
+        if (c_hi) return 8u + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
+        return 16u;
+    };
+    auto begin_dfs = [&](uint32_t node, uint32_t off) {
+        node0 = node; noff0 = off; cur = node; coff = off; dist = 0; sp = 0; emitted = 0;
+        cur8 = pre8;
+#pragma unroll
+        for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
+        phase = PH_DFS;
     };
 
     for (;;) {
@@ -318,6 +317,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             if (!(bf | bs | bd)) break;                         // no lane has work and none waits
         }
         const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
+        // (running the smaller phases in the same iteration as well -- every lane a step per iteration -- was measured in round 4: the
+        // phases' trips to memory then follow each other inside the iteration and nothing is gained: 3.1 -> 3.5 ms on reads with errors)
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
         if (phase != run) continue;
         GROOT_EV(run);                                          // events 0,1,2: a step of FETCH / SCAN / DFS
@@ -481,48 +482,71 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             advance = start_orientation(0);
             GROOT_SUBT(4);
         } else if (run == PH_SCAN) {
-            if (sc_pos >= sc_end) { GROOT_EV(6); advance = true; }   // only after a DFS that used the range's last offset
-            else {
-            // up to 16 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
-            const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
-            const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
-            const uint32_t npos = min(16u, sc_end - sc_pos);
-            const int room = (int)(sc_len - sc_pos);          // bases from sc_pos to the node end
-            uint64_t c_lo = low_bytes((int)npos), c_hi = low_bytes((int)npos - 8);
-            const uint32_t kf = min(4u, eff);
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if ((uint32_t)b >= kf) break;
-                const unsigned rb = (unsigned)(pre8 >> (8 * b)) & 0xFF;
-                // positions whose base b lies inside the node must match it; past the node end the DFS decides
-                const uint64_t need_lo = low_bytes(room - b), need_hi = low_bytes(room - b - 8);
-                c_lo &= match_or_n(window8(w0, w1, b), rb) | ~need_lo;
-                c_hi &= match_or_n(window8(w1, w2, b), rb) | ~need_hi;
-            }
-            uint32_t j = 16;
-            if (c_lo) j = (uint32_t)__builtin_ctzll(c_lo) >> 3;
-            else if (c_hi) j = 8 + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
-            if (j >= npos) {
-                GROOT_EV(7);
-                sc_pos += npos;
-                advance = sc_pos >= sc_end;                   // set up the next range in this step: no empty one
-            } else {
-                // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
-                const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
-                const uint32_t off = sc_pos + j;
-                sc_pos = off + 1;
-                if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
-                    GROOT_EV(8);
-                    advance = sc_pos >= sc_end;
-                } else {
-                    node0 = sc_node; noff0 = off; cur = sc_node; coff = off; dist = 0; sp = 0; emitted = 0;
-                    cur8 = pre8;
-#pragma unroll
-                    for (int i = 0; i < PW; i++) mask[i] = ~0ULL;
-                    phase = PH_DFS;
-                    GROOT_EV(10);
+            if (level == 2) {
+                // 2. seed node shuffling: offsets sc_pos..10 of ContainedNodes entry cn_cur and 0..10 of the next one, from their
+                // 32-byte prefix records (24 bases, node, length) -- no trip to the node list, the node records or the graph bases
+                if (cn_cur >= cn_end) { GROOT_EV(6); advance = true; }
+                else {
+                    const uint4 *e = ix.cn_pre + 2 * (size_t)cn_cur;
+                    const bool two = cn_cur + 1 < cn_end;
+                    uint4 a0 = e[0], a1 = e[1], b0 = make_uint4(0, 0, 0, 0), b1 = make_uint4(0, 0, 0, 0);
+                    if (two) { b0 = e[2]; b1 = e[3]; }
+                    uint64_t c_lo, c_hi;
+                    uint64_t w0 = (uint64_t)a0.x | ((uint64_t)a0.y << 32), w1 = (uint64_t)a0.z | ((uint64_t)a0.w << 32), w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
+                    uint32_t node = a1.z, nlen = a1.w;
+                    filter16(w0, w1, w2, (int)min(nlen, 11u), (int)nlen, c_lo, c_hi);
+                    c_lo &= ~low_bytes((int)sc_pos); c_hi &= ~low_bytes((int)sc_pos - 8);
+                    uint32_t j = first16(c_lo, c_hi);
+                    if (j >= 16u && two) {                     // nothing (left) in this node: the next one
+                        cn_cur++; sc_pos = 0;
+                        w0 = (uint64_t)b0.x | ((uint64_t)b0.y << 32); w1 = (uint64_t)b0.z | ((uint64_t)b0.w << 32); w2 = (uint64_t)b1.x | ((uint64_t)b1.y << 32);
+                        node = b1.z; nlen = b1.w;
+                        filter16(w0, w1, w2, (int)min(nlen, 11u), (int)nlen, c_lo, c_hi);
+                        j = first16(c_lo, c_hi);
+                    }
+                    if (j >= 16u) {
+                        GROOT_EV(7);
+                        cn_cur++; sc_pos = 0;
+                        advance = cn_cur >= cn_end;
+                    } else {
+                        // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
+                        const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
+                        sc_pos = j + 1; sc_end = min(nlen, 11u);
+                        if (!prefix_ok(g8, pre8, min(min(nlen - j, eff), 8u))) {
+                            GROOT_EV(8);
+                            if (sc_pos >= sc_end) { cn_cur++; sc_pos = 0; advance = cn_cur >= cn_end; }
+                        } else {
+                            begin_dfs(node, j);
+                            GROOT_EV(10);
+                        }
+                    }
                 }
-            }
+            } else if (sc_pos >= sc_end) { GROOT_EV(6); advance = true; }
+            else {
+                // levels 1, 3, 4: up to 16 start offsets sc_pos.. of node sc_node: which can spell the first bases of the read?
+                const uint8_t *gb = ix.bases + sc_s0 + sc_pos;
+                const uint32_t npos = min(16u, sc_end - sc_pos);
+                const uint64_t w0 = ld8(gb), w1 = ld8(gb + 8), w2 = ld8(gb + 16);
+                uint64_t c_lo, c_hi;
+                filter16(w0, w1, w2, (int)npos, (int)(sc_len - sc_pos), c_lo, c_hi);   // (room = bases from sc_pos to the node end)
+                const uint32_t j = first16(c_lo, c_hi);
+                const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
+                if (j >= npos) {
+                    GROOT_EV(7);
+                    sc_pos += npos;
+                    advance = sc_pos >= sc_end;                   // set up the next range in this step: no empty one
+                } else {
+                    // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
+                    const uint32_t off = sc_pos + j;
+                    sc_pos = off + 1;
+                    if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
+                        GROOT_EV(8);
+                        advance = sc_pos >= sc_end;
+                    } else {
+                        begin_dfs(sc_node, off);
+                        GROOT_EV(10);
+                    }
+                }
             }
         } else {
             // ---- DFS: match up to 32 bases of node `cur` from offset coff (dfsRecursive, alignment.go:203-223) ----
@@ -666,7 +690,15 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                         // (a read below the window size can bring a hundred of them: one FETCH step instead of one each)
                         if (ix.graph_win_end) last = (long long)ix.graph_win_end[g] - 1;
                     }
-                    else phase = PH_SCAN;
+                    else {
+                        phase = PH_SCAN;
+                        // (the start position just tried was the range's last one: the next range is set up right away instead of by a SCAN
+                        // step of its own -- 30 % of the SCAN lane-steps of a batch of reads with errors were such empty ones)
+                        if (sc_pos >= sc_end) {
+                            if (level == 2) { cn_cur++; sc_pos = 0; advance = cn_cur >= cn_end; }
+                            else advance = true;
+                        }
+                    }
                 } else {                                       // resume at the newest pending neighbour
                     GROOT_EV(17);
                     const size_t si = (size_t)(sp - 1) * a.n_threads + gtid;

@@ -377,7 +377,7 @@ constexpr int kGenericMaxS = 256;      // largest sketch the run-time-sized inst
 constexpr int kGenericMaxBands = kGenericMaxS;   // ... and the most bands (sketch size / maxK >= 1)
 // align_kernel is persistent: workgroups per CU (= waves per SIMD) it is compiled and launched for
 constexpr int kAlignWaves = 4;         // 4 waves/SIMD = at most 128 VGPRs (5 or 6 spill and are slower; 3 hide too little latency)
-constexpr int kAlignWavesWide = 3;     // 704-bit path sets: at 4 waves (128 VGPRs) the kernel spills 260 bytes per lane and is 40 % slower
+constexpr int kAlignWavesWide = 2;     // 704-bit path sets (eleven words in registers + as many per node record): 2 waves = 256 VGPRs, no spills (3 waves: 78 spilled VGPRs for 5 % more speed on graphs of more than 192 paths; 4 waves: 260 bytes of scratch per lane, 40 % slower)
 constexpr uint32_t kLshMaxBands = 16;          // bands per read lsh_heavy_kernel handles (sketch size / maxK; `groot index` default: 5)
 
 // seqio.go:17-23 complementBases: anything but ACGTN becomes 0 (never equals a graph base)
