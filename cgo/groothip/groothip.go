@@ -110,7 +110,13 @@ type Params struct {
 	MaxReadLen           uint32
 	MaxBatchReads        uint32
 	PipelineDepth        uint32
+	// MemoBudgetMB: 0 = the library's default budget for the memo of groot_hip_open, MemoOff = no memo (a run over a few
+	// million reads: the memo costs more at open than it saves), else MiB
+	MemoBudgetMB uint32
 }
+
+// MemoOff is GROOT_MEMO_OFF
+const MemoOff = uint32(C.GROOT_MEMO_OFF)
 
 // DeviceCount returns the number of visible GPUs
 func DeviceCount() int {
@@ -138,6 +144,7 @@ func Open(device int, idx *Index, p Params) (*Ctx, error) {
 	if p.PipelineDepth != 0 {
 		prm.pipeline_depth = C.uint32_t(p.PipelineDepth)
 	}
+	prm.memo_budget_mb = C.uint32_t(p.MemoBudgetMB)
 	c := &Ctx{idx: idx, device: device, params: p}
 	if c.params.MaxReadLen == 0 {
 		c.params.MaxReadLen = uint32(prm.max_read_len)
@@ -152,7 +159,7 @@ func Open(device int, idx *Index, p Params) (*Ctx, error) {
 func (c *Ctx) MaxReadLen() int { return int(c.params.MaxReadLen) }
 
 // Reopen replaces the ctx by one that accepts reads of up to maxReadLen bases and carries the IncrementSubPath call counts
-// over (groot_hip_attempts_export -> close -> open -> groot_hip_attempts_import): the reference has no read length limit
+// over (groot_hip_attempts_export -> close -> open -> groot_hip_attempts_import, in that order): the reference has no read length limit
 // (boss.go:145-203), the device sizes its LDS staging and DFS stacks for one.  Nothing may be in flight.
 func (c *Ctx) Reopen(maxReadLen int) error {
 	var nRows, nWin C.uint32_t
@@ -164,8 +171,11 @@ func (c *Ctx) Reopen(maxReadLen int) error {
 	if rc := C.groot_hip_attempts_export(c.h, (*C.uint32_t)(unsafe.Pointer(&q[0])), (*C.uint32_t)(unsafe.Pointer(&counts[0])), nRows, &nRows, &nWin); rc != 0 {
 		return c.err("groot_hip_attempts_export")
 	}
+	// close first, then open: the index and the tables of groot_hip_open would otherwise sit in HBM twice
 	p := c.params
 	p.MaxReadLen = uint32(maxReadLen)
+	C.groot_hip_close(c.h)
+	c.h = nil
 	bigger, err := Open(c.device, c.idx, p)
 	if err != nil {
 		return err
@@ -175,7 +185,6 @@ func (c *Ctx) Reopen(maxReadLen int) error {
 		bigger.Close()
 		return err
 	}
-	C.groot_hip_close(c.h)
 	c.h, c.params = bigger.h, bigger.params
 	return nil
 }

@@ -73,6 +73,7 @@ struct Args {
     std::string stats_file;
     double threshold = 0.99, min_kmer_cov = 1.0;
     bool no_align = false, fasta = false;
+    std::string memo = "auto";             // auto | on | off | <MiB>
 };
 
 std::vector<std::string> split(const std::string &s, char d)
@@ -97,6 +98,7 @@ void usage()
             "                  [--writeGob]   (also write the reference's groot.gg + groot.lshe: experimental, unpinned against a Go-written file)\n"
             "  groot-hip align -i <indexDir> -f <fastq>[,<fastq>...] [-t 0.99] [-c 1.0] [-g <graphDir>] [--noAlign] [-p N] [--log F]\n"
             "                  [--gpu 0 | --gpus N] [--batch 1048576] [--maxReadLen 512] [--bam out.bam] [--bamLevel -2..9] [--stats f.json]\n"
+            "                  [--memo auto|on|off|<MiB>]   (the device's memo of indexed strings; auto: on for inputs of 20 GB and more)\n"
             "                  (BAM goes to stdout unless --bam; --gpus N shards the reads over N GPUs, index replicated)\n"
             "  groot-hip report [--bamFile x.bam] [-c 0.97] [--lowCov] [--log F]      (BAM from stdin unless --bamFile)\n",
             groot_host_version());
@@ -149,6 +151,7 @@ Args parse(int argc, char **argv)
         else if (f == "--stats") a.stats_file = v();
         else if (f == "--writeGob") a.write_gob = true;
         else if (f == "--bam") a.bam_out = v();
+        else if (f == "--memo") a.memo = v();
         else if (f == "-h" || f == "--help") { usage(); exit(0); }
         else { fprintf(stderr, "unknown flag: %s\n", f.c_str()); usage(); exit(1); }
     }
@@ -383,6 +386,20 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     for (int extra = 1; extra < a.ctx_per_gpu; extra++)          // test hook: several ctxs on one device (exercises the N>1 path on a one-GPU box)
         for (size_t i = 0, n = devices.size() / (size_t)extra; i < n; i++) devices.push_back(devices[i]);
     const uint32_t depth = std::max(2u, a.depth);
+    // The memo of groot_hip_open answers reads that equal an indexed string without hashing or graph walk: it costs a third
+    // of a second per GB of path bases at open and saves ~0.4 ms of GPU time per million such reads -- in this process the GPU waits for
+    // the FASTQ parser and the BAM writer, so it only pays on inputs that keep it busy for minutes.  auto: on from 20 GB of
+    // input (gzip counted four-fold; stdin: off).
+    uint32_t memo_budget = GROOT_MEMO_OFF;
+    if (a.memo == "on") memo_budget = 0;
+    else if (a.memo == "auto") {
+        uint64_t bytes = 0;
+        for (auto &f : a.fastq) {
+            struct stat st;
+            if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0 ? 4 : 1);
+        }
+        if (bytes >= (20ull << 30)) memo_budget = 0;
+    } else if (a.memo != "off") memo_budget = (uint32_t)std::max(1L, atol(a.memo.c_str()));
     auto params_for = [&](uint32_t max_read_len) {
         groot_params prm;
         groot_params_default(&prm);
@@ -392,6 +409,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         prm.max_read_len = max_read_len;
         prm.max_batch_bases = (uint64_t)a.batch * std::min<uint32_t>(max_read_len, 512);
         prm.pipeline_depth = depth;
+        prm.memo_budget_mb = memo_budget;
         return prm;
     };
     std::vector<std::unique_ptr<Gpu>> gpus;

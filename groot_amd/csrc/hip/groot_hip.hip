@@ -1408,11 +1408,23 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     {
         uint64_t expect = 0;
         for (uint32_t p = 0; p < v->n_paths; p++) expect += v->path_len[p] >= w ? 2 * (uint64_t)(v->path_len[p] - w + 1) : 0;
-        set.init(tw, (size_t)std::min<uint64_t>(expect, 1ull << 30));
+        // The memo's budget (groot_params.memo_budget_mb): per string at most one outcome entry (16 * stride bytes; strings with
+        // several traversals are few), one text-table entry at load factor 1/2 (128 bytes), and -- while it is built -- the string
+        // set on the host (4 tw + 8 bytes).  An index whose path strings need more is opened without the memo.
+        const uint64_t budget = (uint64_t)(c->prm.memo_budget_mb ? c->prm.memo_budget_mb : GROOT_MEMO_DEFAULT_MB) << 20;
+        const uint64_t need = expect * ((uint64_t)sq * 16 + 128 + 4 * tw + 8);
+        if (need > budget || expect >= (1ull << 30)) {
+            if (stats) fprintf(stderr, "[groot open]     memo: skipped, %llu path strings need about %llu MiB (budget %llu MiB)\n", (unsigned long long)expect,
+                               (unsigned long long)(need >> 20), (unsigned long long)(budget >> 20));
+            return GROOT_OK;
+        }
+        set.init(tw, (size_t)expect);
         xset.init(twk + xw, 4096);
         std::vector<uint8_t> seq, strand[2];
         std::vector<uint32_t> pk[2];
         std::vector<uint32_t> bad_before[2];                // number of bytes other than ACGT before position i
+        std::vector<uint32_t> high_before[2];               // ... of bytes above 'T': RevComplement panics on such a read (seqio.go:126) -- a string holding
+                                                            // one stays out of the memo (its batch status would drop the whole capture chunk with it)
         uint32_t buf[16 + 4];
         for (uint32_t g = 0; g < v->n_graphs; g++)
             for (uint32_t lp = 0; lp < v->graph_path_off[g + 1] - v->graph_path_off[g]; lp++) {
@@ -1426,6 +1438,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                 for (int st = 0; st < 2; st++) {
                     pk[st].assign(L / 16 + tw + 3, 0);
                     bad_before[st].assign(L + 1, 0);
+                    high_before[st].assign(L + 1, 0);
                     strand[st].resize(L);
                     for (size_t i = 0; i < L; i++) {
                         uint8_t b = st ? seq[L - 1 - i] : seq[i];       // (reverse strand: ACGT complemented, any other byte as it is)
@@ -1433,11 +1446,12 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
                         if (st && acgt) b = b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A';
                         strand[st][i] = b;
                         bad_before[st][i + 1] = bad_before[st][i] + (acgt ? 0 : 1);
+                        high_before[st][i + 1] = high_before[st][i] + (b > 'T' ? 1 : 0);
                         if (acgt) pk[st][i >> 4] |= (uint32_t)((b >> 1) & 3u) << (2 * (i & 15));
                     }
                     for (size_t i = 0; i + w <= L; i++) {
                         const uint32_t nb = bad_before[st][i + w] - bad_before[st][i];
-                        if (nb > 2 * xw) continue;
+                        if (nb > 2 * xw || high_before[st][i + w] != high_before[st][i]) continue;
                         pack_at(pk[st], i, w, tw, buf);
                         if (!nb) { (void)set.find(buf, true); continue; }
                         for (uint32_t x = tw; x < twk + xw; x++) buf[x] = 0;
@@ -1817,7 +1831,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     c->dix.sig_mask = cap - 1;
     c->dix.win_text = c->win_text.p;
     // 5. outcome table: the align stage itself, once, on every string that confirms reads
-    if (c->dix.sig_info && !c->kn.no_outcome_table && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
+    if (c->dix.sig_info && !c->kn.no_outcome_table && c->prm.memo_budget_mb != GROOT_MEMO_OFF && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
         const auto t0 = std::chrono::steady_clock::now();
         if (int rc = build_outcome_table(c, v, text, tlen, verdict, w, vstride)) return rc;
         c->out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2188,7 +2202,14 @@ int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, 
     *out = nullptr;
     groot_ctx *c = new groot_ctx();
     const auto t_open0 = std::chrono::steady_clock::now();
-    int rc = open_impl(c, device_id, idx, p);
+    int rc;
+    try {
+        rc = open_impl(c, device_id, idx, p);
+    } catch (const std::bad_alloc &) {      // (host tables of the index / the memo: nothing may unwind through the C boundary)
+        rc = fail(c, GROOT_E_NOSPACE, "out of host memory while building the device tables");
+    } catch (const std::exception &e) {
+        rc = fail(c, GROOT_E_INVALID, "groot_hip_open: %s", e.what());
+    }
     c->open_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_open0).count();
     if (rc) {
         g_open_err = c->err;

@@ -24,9 +24,15 @@ namespace groot {
 #endif
 // (the S running minima are 2 S registers: at GROOT_SEED_WAVES waves per SIMD (~100 VGPRs) sketch sizes above 30 spilled them --
 // 20 ms per 2 M reads at S = 64.  Larger sketches get fewer, larger waves: 3 per SIMD up to S = 48, 2 beyond)
-constexpr int seed_waves(int S) { return S == 0 ? 1 : (S <= 30 ? GROOT_SEED_WAVES : (S <= 48 ? 3 : 2)); }
+#ifndef GROOT_LIST_WAVES
+#define GROOT_LIST_WAVES 3      // the list instance: 3 waves = up to 168 VGPRs -- no spills (5 waves spilled 25 VGPRs) and room to fetch four rows of the LSH-Forest walk ahead (list pass of a mixed-length batch 4.0 -> 3.6 ms)
+#endif
+#ifndef GROOT_LIST_ROWS_AHEAD
+#define GROOT_LIST_ROWS_AHEAD 4
+#endif
+constexpr int seed_waves(int S, bool list = false) { return S == 0 ? 1 : (S <= 30 ? (list ? GROOT_LIST_WAVES : GROOT_SEED_WAVES) : (S <= 48 ? 3 : 2)); }
 template <int S, int MAXK, bool DUMP, int M5, bool LIST = false>
-__global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(SeedArgs a)
+__global__ __launch_bounds__(kBlock, seed_waves(S, LIST)) void sketch_seed_kernel(SeedArgs a)
 {
     constexpr int SM = S ? S : kGenericMaxS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(kBlock, seed_waves(S)) void sketch_seed_kernel(Seed
             const uint32_t lo = b_lo[b], e_end = b_end[b];
             // (rows are 32 consecutive bytes each: kRowsAhead of them are fetched together -- the walk is a chain of round trips, 790
             // load instructions per wavefront and read on mixed-length batches, two thirds of the kernel's time spent waiting)
-            constexpr uint32_t kRowsAhead = GROOT_LSH_ROWS_AHEAD;
+            constexpr uint32_t kRowsAhead = LIST ? GROOT_LIST_ROWS_AHEAD : GROOT_LSH_ROWS_AHEAD;
             for (uint32_t e4 = lo; e4 < e_end; e4 += kRowsAhead) {
             uint4 rowa[kRowsAhead], rowb[kRowsAhead];
 #pragma unroll

@@ -22,7 +22,10 @@ class Params(C.Structure):
     _fields_ = [("containment_threshold", C.c_double), ("no_exact_align", C.c_uint32), ("max_read_len", C.c_uint32),
                 ("max_batch_reads", C.c_uint32), ("max_seeds_per_read", C.c_uint32), ("max_batch_bases", C.c_uint64),
                 ("keep_sketches", C.c_uint32), ("pipeline_depth", C.c_uint32), ("results_on_device", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("memo_budget_mb", C.c_uint32)]
+
+
+MEMO_OFF = 0xFFFFFFFF
 
 
 class Counts(C.Structure):
@@ -111,10 +114,10 @@ class Aligner:
     """One groot_ctx: the replacement for theBoss.mapReads (src/pipeline/boss.go:108-242) on one GPU."""
 
     def __init__(self, index, device=0, threshold=0.99, no_align=False, max_read_len=256, max_batch_reads=1 << 20,
-                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0, pipeline_depth=0, results_on_device=False):
+                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0, pipeline_depth=0, results_on_device=False, memo_budget_mb=0):
         self.index = index
         self.params = Params(threshold, 1 if no_align else 0, max_read_len, max_batch_reads, max_seeds_per_read,
-                             max_batch_bases, 1 if keep_sketches else 0, pipeline_depth, 1 if results_on_device else 0, 0)
+                             max_batch_bases, 1 if keep_sketches else 0, pipeline_depth, 1 if results_on_device else 0, memo_budget_mb)
         self._h = C.c_void_p()
         rc = lib().groot_hip_open(C.byref(self._h), C.c_int(device), C.byref(index.view), C.byref(self.params))
         if rc:

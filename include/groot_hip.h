@@ -49,8 +49,16 @@ typedef struct groot_params {
     uint32_t results_on_device;     /* 1: traversal records stay in HBM (groot_batch_result.d_*), no D2H unless
                                        groot_hip_read_travs asks; 0 (default): D2H into pinned host memory, overlapped
                                        with the next batch's kernels                                 */
-    uint32_t reserved;
+    uint32_t memo_budget_mb;        /* the memo of groot_hip_open (every WindowSize-mer of every indexed path run through the ctx's
+                                       own pipeline once; reads that equal one are answered from it): 0 = default budget
+                                       (GROOT_MEMO_DEFAULT_MB of HBM, and about as much host memory while it is built),
+                                       GROOT_MEMO_OFF = no memo, else the budget in MiB.  An index whose strings need more than
+                                       the budget is opened without the memo (groot_open_stats.memo_strings == 0); a caller
+                                       with little input should switch it off: it costs ~0.3 s per GB of path bases at open
+                                       and pays for itself only after some hundred million reads       */
 } groot_params;
+#define GROOT_MEMO_OFF 0xFFFFFFFFu
+#define GROOT_MEMO_DEFAULT_MB 8192u
 
 void groot_params_default(groot_params *p);
 

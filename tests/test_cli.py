@@ -55,14 +55,16 @@ def test_index_subcommand_and_align_without_gpu(cli, msa_dir, tmp_path):
 
 
 @pytest.mark.gpu
-def test_align_subcommand_against_oracle(cli, argannot_index, perfect_reads, tmp_path):
+@pytest.mark.parametrize("memo", ["auto", "on"])
+def test_align_subcommand_against_oracle(cli, argannot_index, perfect_reads, tmp_path, memo):
+    """(--memo on: the reads are answered from the memo of groot_hip_open; auto leaves it off for an input this small)"""
     idx_dir = tmp_path / "idx"
     idx_dir.mkdir()
     argannot_index.save(str(idx_dir / "groot.gidx"))
     fq = os.path.join(DATA, "full-argannot-perfect-reads-small.fq.gz")
     log, graphs, bam = str(tmp_path / "align.log"), str(tmp_path / "graphs"), str(tmp_path / "out.bam")
     with open(bam, "wb") as out:
-        r = subprocess.run([cli, "align", "-i", str(idx_dir), "-f", fq, "--log", log, "-g", graphs, "--batch", "300"],
+        r = subprocess.run([cli, "align", "-i", str(idx_dir), "-f", fq, "--log", log, "-g", graphs, "--batch", "300", "--memo", memo],
                            cwd=REPO, stdout=out, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr
     # oracle

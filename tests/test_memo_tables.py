@@ -133,3 +133,22 @@ def test_reads_through_an_N_of_an_indexed_sequence(argannot_index, monkeypatch):
     counts, att = check_batch(al, index, batch2.reshape(-1).copy(), off2, att)
     assert counts["full_sketch_reads"] >= len(other)
     al.close()
+
+
+@pytest.mark.parametrize("budget", ["off", "too_small"])
+def test_memo_switched_off_by_the_caller_or_by_its_budget(argannot_index, monkeypatch, budget):
+    """groot_params.memo_budget_mb: GROOT_MEMO_OFF, or a budget the index's path strings do not fit (1 MiB) -- the ctx opens without
+    the memo (groot_open_stats says so), every read goes through the hashing and graph-walk kernels, results equal the oracle's"""
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+        monkeypatch.delenv(v, raising=False)
+    al = device.Aligner(argannot_index, max_batch_reads=8192, max_read_len=128, memo_budget_mb=device.MEMO_OFF if budget == "off" else 1)
+    st = al.open_stats()
+    assert st["memo_strings"] == 0 and st["memo_entries"] == 0 and st["text_entries"] == 0
+    seq, off = perfect_batch(argannot_index, 6000, 4242)
+    counts, _ = check_batch(al, argannot_index, seq, off, np.zeros((0, argannot_index.view.n_windows), dtype=np.uint32))
+    assert counts["walked_reads"] > 5000          # nothing was answered from a table
+    al.close()
+    # the default budget holds this index's memo
+    al = device.Aligner(argannot_index, max_batch_reads=8192, max_read_len=128)
+    assert al.open_stats()["memo_strings"] > 1_000_000
+    al.close()
