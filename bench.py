@@ -33,6 +33,9 @@ import time
 
 import numpy as np
 
+# (before torch initialises the HIP runtime: a ctx runs four streams beside torch's -- groot_hip.hip groot_hw_queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
@@ -412,14 +415,14 @@ def host_fed(index, d_seq, R, steps, depth=4):
         al.submit_acquired(b["ticket"], R, len(exc_pos))
         if al.in_flight()[0] == depth:
             r = al.collect(copy=False)
-            trav_bytes += r["n_travs"] * 12 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
+            trav_bytes += r["n_travs"] * 12 + r["n_mask_bytes"] + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
             for k, v in r["ms"].items():
                 stage[k] = stage.get(k, 0.0) + v
             al.release(r["ticket"])
             done += 1
     while done < steps:
         r = al.collect(copy=False)
-        trav_bytes += r["n_travs"] * 12 + r["n_mask_words"] * 8 + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
+        trav_bytes += r["n_travs"] * 12 + r["n_mask_bytes"] + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
         for k, v in r["ms"].items():
             stage[k] = stage.get(k, 0.0) + v
         al.release(r["ticket"])

@@ -307,7 +307,7 @@ func (c *Ctx) Collect() (*Result, error) {
 		uint64(r.counts.seeds), uint64(r.counts.travs), uint64(r.counts.revcomp_panics), uint64(r.counts.short_reads), uint64(r.counts.full_sketch_reads), uint64(r.counts.walked_reads)}
 	if n > 0 {
 		res.Travs = (*[1 << 28]Trav)(unsafe.Pointer(r.travs))[:n:n]
-		// the path sets travel compact (as many words as the traversal's graph has paths / 64); widen them once per batch
+		// the path sets travel compact (as many bytes as the traversal's graph has paths / 8); widen them once per batch
 		res.Masks = make([]uint64, n*res.PathWords)
 		if rc := C.groot_host_unpack_masks(&c.idx.view, r.travs, C.uint64_t(n), r.masks, (*C.uint64_t)(unsafe.Pointer(&res.Masks[0]))); rc != 0 {
 			return nil, fmt.Errorf("groot_host_unpack_masks: %s", C.GoString(C.groot_host_last_error()))

@@ -121,12 +121,12 @@ struct Slot {
     PinBuf<groot_trav> h_trav;                     // what collect hands out (expanded on the host from h_ctrav when the records travel packed)
     DevBuf<groot_ctrav> d_ctrav;                   // 12-byte records for the copy-out
     PinBuf<groot_ctrav> h_ctrav;
-    PinBuf<uint64_t> h_mask;                       // COMPACT path sets: ceil(paths(graph) / 64) words per traversal
+    PinBuf<uint8_t> h_mask;                        // COMPACT path sets: ceil(paths(graph) / 8) bytes per traversal
     PinBuf<uint32_t> h_ckpt;                       // offset into h_mask of every 256th traversal
-    DevBuf<uint64_t> d_cmask;                      // the compact copy the copy-out takes (host-result mode)
+    DevBuf<uint8_t> d_cmask;                       // the compact copy the copy-out takes (host-result mode)
     DevBuf<uint32_t> d_mwords, d_moff, d_ckpt;
     uint32_t n_trav = 0, copied = 0;               // records of the batch / records the copy-out enqueued at submit covers
-    uint64_t n_mask_words = 0, copied_words = 0;
+    uint64_t n_mask_bytes = 0, copied_bytes = 0;
     bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
     hipEvent_t ev_seed = nullptr;          // behind the batch's seed stage on the compute stream: its align stage waits for it
     hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
@@ -202,10 +202,10 @@ struct groot_ctx {
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
     double dfs_frac = 1.0;                 // share of the latest finished batch's reads that needed the align stage's graph walk (the rest: no seeds / tabulated outcomes)
     double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
-    double words_per_trav = 0;             // compact path-set words per traversal, likewise (0 = not seen yet: path_words)
+    double bytes_per_trav = 0;             // compact path-set bytes per traversal, likewise (0 = not seen yet: 8 * path_words)
     bool packed_travs = false;             // the copy-out sends 12-byte records (batches of at most 2^24 reads), collect expands them
     std::vector<uint32_t> h_node_graph;    // graph of every node (the expansion)
-    DevBuf<uint8_t> graph_words;           // ceil(paths / 64) per graph
+    DevBuf<uint8_t> graph_words;           // ceil(paths / 8) per graph: BYTES of a traversal's compact path set
     std::vector<uint8_t> h_graph_words;
     // What the seed stage of a batch leaves for its align and order stages lives in one of TWO work sets, taken in turn: the seed
     // stage of batch b+1 (compute stream) runs beside the align + order stages of batch b (align stream) -- the reference's sketching
@@ -238,6 +238,13 @@ struct groot_ctx {
     uint32_t att_cap = 0;                  // rows the table can hold
     bool att_external = false;
 };
+
+// A ctx drives four HIP streams at once -- seed stage, align + order stage, copy-in, copy-out -- beside whatever the host process
+// uses itself.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
+// run one after the other: with a fifth stream in the process the copy-in and the copy-out of neighbouring batches took turns
+// (host-fed rate 1 355 -> 717 Mreads/s).  Ask for eight before the runtime reads the setting (first HIP call of the process); a
+// value the user has set stands.
+__attribute__((constructor)) static void groot_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 static thread_local std::string g_open_err;
 
@@ -493,9 +500,9 @@ static int alloc_trav(groot_ctx *c, Slot *s, uint32_t cap)
     HIP_TRY(c, s->d_mask.alloc((size_t)cap * c->pw_view + 2));
     if (!c->prm.results_on_device) {
         HIP_TRY(c, s->h_trav.alloc((size_t)cap + 2));
-        HIP_TRY(c, s->h_mask.alloc((size_t)cap * c->pw_view + 2));
+        HIP_TRY(c, s->h_mask.alloc((size_t)cap * c->pw_view * 8 + 16));
         HIP_TRY(c, s->h_ckpt.alloc((size_t)cap / 256 + 2));
-        HIP_TRY(c, s->d_cmask.alloc((size_t)cap * c->pw_view + 2));
+        HIP_TRY(c, s->d_cmask.alloc((size_t)cap * c->pw_view * 8 + 16));
         HIP_TRY(c, s->d_mwords.alloc(cap));
         HIP_TRY(c, s->d_moff.alloc(cap));
         HIP_TRY(c, s->d_ckpt.alloc((size_t)cap / 256 + 2));
@@ -972,11 +979,11 @@ static int enqueue(groot_ctx *c, Slot *s)
         const double margin = 1.0 + std::max(0.01, 4.0 / std::sqrt((double)s->n_reads + 1.0));
         const uint64_t predicted = (uint64_t)((double)s->n_reads * c->trav_per_read * margin) + 1024;
         s->copied = (uint32_t)std::min<uint64_t>(predicted, s->trav_cap);
-        const double wpt = c->words_per_trav > 0 ? c->words_per_trav : (double)c->pw_view;
-        s->copied_words = std::min<uint64_t>((uint64_t)((double)s->copied * wpt * margin) + 1024, (uint64_t)s->trav_cap * c->pw_view);
+        const double bpt = c->bytes_per_trav > 0 ? c->bytes_per_trav : 8.0 * (double)c->pw_view;
+        s->copied_bytes = std::min<uint64_t>((uint64_t)((double)s->copied * bpt * margin) + 4096, (uint64_t)s->trav_cap * c->pw_view * 8);
         if (c->packed_travs) HIP_TRY(c, hipMemcpyAsync(s->h_ctrav.p, s->d_ctrav.p, (size_t)s->copied * sizeof(groot_ctrav), hipMemcpyDeviceToHost, c->d2h_stream));
         else HIP_TRY(c, hipMemcpyAsync(s->h_trav.p, s->d_trav.p, (size_t)s->copied * sizeof(groot_trav), hipMemcpyDeviceToHost, c->d2h_stream));
-        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_cmask.p, (size_t)s->copied_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(c, hipMemcpyAsync(s->h_mask.p, s->d_cmask.p, (size_t)s->copied_bytes, hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(c, hipMemcpyAsync(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->copied / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h_stream));
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_d2h, c->d2h_stream));
     }
@@ -1128,18 +1135,18 @@ static int finish_counters(groot_ctx *c, Slot *s)
         // mixed read lengths, another organism -- the next try comes later and later)
         if (s->text_used) c->text_retry_gap = c->text_hit_frac >= 0.7 ? 8u : std::min(256u, c->text_retry_gap * 2u);
     }
-    s->n_mask_words = s->n_trav ? h.mask_words : 0;
+    s->n_mask_bytes = s->n_trav ? h.mask_words : 0;
     if (!c->prm.results_on_device && s->n_trav) {
-        c->words_per_trav = (double)s->n_mask_words / (double)s->n_trav;
+        c->bytes_per_trav = (double)s->n_mask_bytes / (double)s->n_trav;
         const uint32_t have = redone ? 0 : std::min(s->copied, s->n_trav);      // a redo re-made the records: fetch them all
         if (have < s->n_trav) {
             if (c->packed_travs) HIP_TRY(c, hipMemcpy(s->h_ctrav.p + have, s->d_ctrav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_ctrav), hipMemcpyDeviceToHost));
             else HIP_TRY(c, hipMemcpy(s->h_trav.p + have, s->d_trav.p + have, (size_t)(s->n_trav - have) * sizeof(groot_trav), hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(s->h_ckpt.p, s->d_ckpt.p, ((size_t)s->n_trav / 256 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
         }
-        const uint64_t have_w = redone ? 0 : std::min<uint64_t>(s->copied_words, s->n_mask_words);
-        if (have_w < s->n_mask_words)
-            HIP_TRY(c, hipMemcpy(s->h_mask.p + have_w, s->d_cmask.p + have_w, (size_t)(s->n_mask_words - have_w) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        const uint64_t have_w = redone ? 0 : std::min<uint64_t>(s->copied_bytes, s->n_mask_bytes);
+        if (have_w < s->n_mask_bytes)
+            HIP_TRY(c, hipMemcpy(s->h_mask.p + have_w, s->d_cmask.p + have_w, (size_t)(s->n_mask_bytes - have_w), hipMemcpyDeviceToHost));
         if (c->packed_travs) expand_travs(c, s);
         s->host_results = true;
     }
@@ -1615,7 +1622,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
         HIP_TRY(c, hipMemset(c->q_nrows.p, 0, 4));
         if (c->att_cap) HIP_TRY(c, hipMemset(c->attempts_ptr, 0, (size_t)c->att_cap * c->n_windows * sizeof(uint32_t)));
         for (WorkSet &w : c->ws) w.owner = nullptr;
-        c->trav_per_read = 1.25; c->words_per_trav = 0; c->dfs_frac = 1.0;
+        c->trav_per_read = 1.25; c->bytes_per_trav = 0; c->dfs_frac = 1.0;
     }
     if (rc_all) return rc_all;
     lap("pipeline on the strings");
@@ -1953,7 +1960,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     }
     {
         std::vector<uint8_t> gw(v->n_graphs, 1);
-        for (uint32_t g = 0; g < v->n_graphs; g++) gw[g] = (uint8_t)std::max<uint32_t>(1, (v->graph_path_off[g + 1] - v->graph_path_off[g] + 63) / 64);
+        for (uint32_t g = 0; g < v->n_graphs; g++) gw[g] = (uint8_t)std::max<uint32_t>(1, (v->graph_path_off[g + 1] - v->graph_path_off[g] + 7) / 8);   // (<= 88: path sets of up to 704 bits)
         HIP_TRY(c, upload(c->graph_words, gw.data(), gw.size()));
         c->h_graph_words = gw;
     }
@@ -2444,7 +2451,7 @@ int groot_hip_collect(groot_ctx *c, groot_batch_result *out)
     out->travs = s->host_results ? s->h_trav.p : nullptr;
     out->masks = s->host_results ? s->h_mask.p : nullptr;
     out->mask_ckpt = s->host_results ? s->h_ckpt.p : nullptr;
-    out->n_mask_words = s->host_results ? s->n_mask_words : 0;
+    out->n_mask_bytes = s->host_results ? s->n_mask_bytes : 0;
     out->d_travs = s->d_trav.p; out->d_masks = s->d_mask.p;
     out->path_words = c->pw_view;
     out->status = s->status;
@@ -2506,7 +2513,7 @@ int groot_hip_read_travs(groot_ctx *c, groot_trav *out, uint64_t *masks, uint64_
             uint64_t o = 0;
             for (uint64_t i = 0; i < m; i++) {
                 const uint32_t w = c->h_graph_words[s->h_trav.p[i].graph_id];
-                memcpy(masks + i * c->pw_view, s->h_mask.p + o, (size_t)w * sizeof(uint64_t));
+                memcpy(masks + i * c->pw_view, s->h_mask.p + o, (size_t)w);     // (w bytes)
                 o += w;
             }
         }

@@ -550,9 +550,9 @@ __global__ __launch_bounds__(kBlock) void order_ovf_kernel(const groot_trav *ovf
 }
 
 // ---- compact path sets for the copy-out --------------------------------------------------------------------
-// A traversal's path set needs only as many 64-bit words as its graph has paths (one word for 579 of the 583 arg-annot.90
-// graphs, three for the widest): the copy-out carries ceil(paths(graph) / 64) words per traversal instead of path_words,
-// 33 instead of 46 bytes per read over PCIe.  words[i] for traversal i (0 beyond the batch's count), an exclusive scan of
+// A traversal's path set needs only as many bits as its graph has paths (three per graph on average on arg-annot.90, 704 for the
+// widest graph supported): the copy-out carries ceil(paths(graph) / 8) BYTES per traversal instead of path_words 64-bit words --
+// 13.6 instead of 24.5 (round 3: whole words) or 46 bytes per read over PCIe.  words[i] for traversal i (0 beyond the batch's count), an exclusive scan of
 // them (rocprim), then the copy; every 256th offset is kept as a checkpoint for the host.
 // (a record slot may hold anything when an overflow list filled up -- the batch is redone then -- hence the range checks)
 __global__ __launch_bounds__(kBlock) void mask_words_kernel(const groot_trav *__restrict__ trav, const DeviceCounters *ctr, uint32_t cap,
@@ -569,14 +569,14 @@ __global__ __launch_bounds__(kBlock) void mask_words_kernel(const groot_trav *__
 }
 __global__ __launch_bounds__(kBlock) void mask_compact_kernel(const groot_trav *__restrict__ trav, const uint64_t *__restrict__ mask, uint32_t pw_in,
                                                             DeviceCounters *ctr, uint32_t cap, const uint8_t *__restrict__ graph_words, uint32_t n_graphs,
-                                                            const uint32_t *__restrict__ off, uint64_t *__restrict__ out, uint32_t *__restrict__ ckpt)
+                                                            const uint32_t *__restrict__ off, uint8_t *__restrict__ out, uint32_t *__restrict__ ckpt)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n = min(ctr->n_trav, cap);
     if (i >= n) return;
     const uint32_t g = trav[i].graph_id;
     const uint32_t o = off[i], w = g < n_graphs ? graph_words[g] : 0u;
-    for (uint32_t x = 0; x < w; x++) out[(size_t)o + x] = mask[(size_t)i * pw_in + x];
+    for (uint32_t x = 0; x < w; x++) out[(size_t)o + x] = (uint8_t)(mask[(size_t)i * pw_in + (x >> 3)] >> (8 * (x & 7u)));   // (w bytes)
     if ((i & 255u) == 0) ckpt[i >> 8] = o;
     if (i == n - 1) ctr->mask_words = o + w;
 }

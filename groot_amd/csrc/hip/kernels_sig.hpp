@@ -56,7 +56,10 @@ __device__ __forceinline__ void todo_push(const SeedArgs &a, uint32_t r)
 
 // TW: dwords of a packed read the text comparison handles (reads of up to 16 * TW bases; longer ones take the full-width kernel)
 template <int S, int M5, int TW>
-__global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(SeedArgs a)
+#ifndef GROOT_SIG_WAVES_LONG
+#define GROOT_SIG_WAVES_LONG 5    // the instance for reads of up to 256 bases compares 16 dwords of text per orientation: at 6 waves (80 VGPRs) it spilled 34-60 of them
+#endif
+__global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVES) void sketch_sig_kernel(SeedArgs a)
 {
     static_assert(S >= 1 && S <= 32 && M5 >= 0 && M5 < 32, "slots i < 32 with a compile-time (k * multiSeed) & 31 only");
     static_assert(TW >= 1 && 16 * TW <= (int)kTextMax, "a read cannot be longer than a window text");
@@ -105,18 +108,21 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
     }
     __syncthreads();
     const uint32_t r = r0 + tid;
-    if (r >= a.n_reads) return;
-    const uint64_t o0 = a.seq_off[r];
-    const uint32_t len = (uint32_t)(a.seq_off[r + 1] - o0);
+    // (no thread leaves before the two barriers of the list bookkeeping below: threads without a read, or with one that is answered
+    // at once, are predicated off instead)
+    const bool valid = r < a.n_reads;
+    const uint64_t o0 = valid ? a.seq_off[r] : 0;
+    const uint32_t len = valid ? (uint32_t)(a.seq_off[r + 1] - o0) : 0;
     const uint32_t q = len - k + 1;                        // kmerCount, boss.go:169
-    if (len >= k && len <= a.max_read_len && (q > ix.max_q || ix.q_min_eq[q] > (uint32_t)S)) {
+    bool answered = !valid;
+    if (valid && len >= k && len <= a.max_read_len && (q > ix.max_q || ix.q_min_eq[q] > (uint32_t)S)) {
         // Containment > t is out of reach for this many k-mers: no seed, and nothing to hash
         seed_epilogue(a, r, o0, len, q, 0, kEmpty, kEmpty, kEmpty, kEmpty, kEmpty, false);
-        return;
+        answered = true;
     }
     // (len >= WindowSize: only then does the read cover whole WindowSize-mers of a text, whose sketches are proven; a shorter
     // read is a substring with FEWER k-mers -- its minima may differ below the 27 signature bits -- and takes the full-width kernel)
-    bool fast = in_lds && len >= k && len >= ix.w && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
+    bool fast = !answered && in_lds && len >= k && len >= ix.w && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
     if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch
     if (fast) {
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         // the reads left to the list pass (other lengths, bytes other than ACGT, the LSH-Forest branch): counted per workgroup -- one
         // LDS atomic per wavefront, ONE global atomic per workgroup.  (One global atomic per wavefront on the single counter cost
         // 0.9 of the kernel's 1.9 ms on 8 M mixed-length reads, where every wavefront has such reads: ~7 ns each.)  Every thread
-        // still here takes part; wavefronts that have left do not count at the barrier.
-        const unsigned long long here = __ballot(1), mb = __ballot(!fast);
+        // takes part in the barriers.
+        const unsigned long long here = __ballot(1), mb = __ballot(!fast && !answered);
         const unsigned lane = tid & 63u;
         const int leader = __ffsll(here) - 1;
         uint32_t wave_base = 0;
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(kBlock, GROOT_SIG_WAVES) void sketch_sig_kernel(See
         __syncthreads();
         if ((int)lane == leader && mb && wave_base == 0) list_base = atomicAdd(a.todo_count, list_cnt);
         __syncthreads();
+        if (answered) return;
         if (!fast) {
             a.todo_list[list_base + wave_base + (uint32_t)__popcll(mb & ((1ULL << lane) - 1ULL))] = r;
             return;

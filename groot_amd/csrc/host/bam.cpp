@@ -302,7 +302,7 @@ struct ReadRef {
 // traversals; blocks are written in traversal order = read order.  read(r, ref) fills the read's fields, false if r is
 // out of range.
 template <class ReadFn>
-static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn read, const groot_trav *travs, const uint64_t *masks,
+static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn read, const groot_trav *travs, const void *masks_v,
                             const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records)
 {
     if (n_records) *n_records = 0;
@@ -359,9 +359,18 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                 bool first = (tr.flags & GROOT_TRAV_FIRST) != 0;
                 recs.clear();
                 const uint32_t np0 = ix->node_np_off[tr.node], np1 = ix->node_np_off[tr.node + 1];
-                const uint32_t gw = mask_ckpt ? std::max<uint32_t>(1, (ix->graph_path_off[tr.graph_id + 1] - ix->graph_path_off[tr.graph_id] + 63) / 64) : pw;
-                const uint64_t *mk = mask_ckpt ? masks + moff : masks + t * pw;
-                moff += gw;
+                // (compact path sets: max(1, ceil(paths / 8)) bytes per traversal, widened here; else path_words words)
+                uint64_t wide[16];
+                uint32_t gw = pw;
+                const uint64_t *mk = static_cast<const uint64_t *>(masks_v) + t * pw;
+                if (mask_ckpt) {
+                    const uint32_t nb = std::min<uint32_t>(sizeof wide, std::max<uint32_t>(1, (ix->graph_path_off[tr.graph_id + 1] - ix->graph_path_off[tr.graph_id] + 7) / 8));
+                    gw = (nb + 7) / 8;
+                    wide[gw - 1] = 0;
+                    memcpy(wide, static_cast<const uint8_t *>(masks_v) + moff, nb);
+                    mk = wide;
+                    moff += nb;
+                }
                 uint32_t jn = np0;                                   // the node's (path, position) pairs ascend by path: walked along with the set bits
                 for (uint32_t w = 0; w < gw; w++) {
                     uint64_t m = mk[w];
@@ -487,7 +496,7 @@ int groot_bam_write_travs(groot_bam *b, const groot_index_view *ix, const groot_
 }
 
 int groot_bam_write_batch(groot_bam *b, const groot_index_view *ix, const groot_reads_view *rv, uint32_t first_read_id, const groot_trav *travs,
-                          const uint64_t *masks, const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records)
+                          const void *masks, const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records)
 {
     if (!b || !ix || !rv || (n_trav && (!travs || !masks))) return set_error(GROOT_E_INVALID, "null argument");
     auto read = [rv, first_read_id](uint32_t read_id, ReadRef &o) -> bool {

@@ -97,7 +97,7 @@ int groot_host_weights(const groot_index_view *ix, const uint32_t *attempts, uin
     return GROOT_OK;
 }
 
-int groot_host_unpack_masks(const groot_index_view *ix, const groot_trav *travs, uint64_t n_trav, const uint64_t *compact, uint64_t *out)
+int groot_host_unpack_masks(const groot_index_view *ix, const groot_trav *travs, uint64_t n_trav, const uint8_t *compact, uint64_t *out)
 {
     if (!ix || (n_trav && (!travs || !compact || !out))) return set_error(GROOT_E_INVALID, "null argument");
     const uint32_t pw = ix->path_words;
@@ -105,9 +105,10 @@ int groot_host_unpack_masks(const groot_index_view *ix, const groot_trav *travs,
     for (uint64_t i = 0; i < n_trav; i++) {
         const uint32_t g = travs[i].graph_id;
         if (g >= ix->n_graphs) return set_error(GROOT_E_INVALID, "traversal %llu: graph id out of range", (unsigned long long)i);
-        const uint32_t w = std::max<uint32_t>(1, (ix->graph_path_off[g + 1] - ix->graph_path_off[g] + 63) / 64);
-        for (uint32_t x = 0; x < pw; x++) out[i * pw + x] = x < w ? compact[o + x] : 0;
-        o += w;
+        const uint32_t nb = std::min<uint32_t>(8 * pw, std::max<uint32_t>(1, (ix->graph_path_off[g + 1] - ix->graph_path_off[g] + 7) / 8));
+        for (uint32_t x = 0; x < pw; x++) out[i * pw + x] = 0;
+        memcpy(out + i * pw, compact + o, nb);             // (little endian: byte b of the set is bits 8b.. of word b / 8)
+        o += nb;
     }
     return GROOT_OK;
 }

@@ -55,7 +55,7 @@ class BatchBuffers(C.Structure):
 class BatchResult(C.Structure):
     """groot_batch_result"""
     _fields_ = [("ticket", C.c_uint64), ("first_read_id", C.c_uint32), ("n_reads", C.c_uint32), ("counts", Counts),
-                ("travs", C.c_void_p), ("masks", C.c_void_p), ("mask_ckpt", C.c_void_p), ("n_mask_words", C.c_uint64),
+                ("travs", C.c_void_p), ("masks", C.c_void_p), ("mask_ckpt", C.c_void_p), ("n_mask_bytes", C.c_uint64),
                 ("n_travs", C.c_uint64), ("d_travs", C.c_void_p),
                 ("d_masks", C.c_void_p), ("path_words", C.c_uint32), ("status", C.c_int32), ("ms", StageMs)]
 
@@ -87,10 +87,10 @@ def device_count():
 def unpack_masks(index, travs, compact_masks):
     """groot_host_unpack_masks: the compact path sets of collect(copy=False) -> [n, path_words]"""
     travs = np.ascontiguousarray(travs, dtype=TRAV_DTYPE)
-    cm = np.ascontiguousarray(compact_masks, dtype=np.uint64)
+    cm = np.ascontiguousarray(compact_masks, dtype=np.uint8)
     out = np.zeros((len(travs), index.view.path_words), dtype=np.uint64)
     host._check(host.lib().groot_host_unpack_masks(C.byref(index.view), travs.ctypes.data_as(C.c_void_p), C.c_uint64(len(travs)),
-                                                   _ffi.as_ptr(cm, C.c_uint64), _ffi.as_ptr(out, C.c_uint64)))
+                                                   _ffi.as_ptr(cm, C.c_uint8), _ffi.as_ptr(out, C.c_uint64)))
     return out
 
 
@@ -207,11 +207,11 @@ class Aligner:
                                                                _ffi.as_ptr(m, C.c_uint64)))
                 t = t.copy()
             else:
-                m = _ffi._np_view(C.cast(r.masks, C.POINTER(C.c_uint64)), int(r.n_mask_words), np.uint64)   # compact, as handed out
+                m = _ffi._np_view(C.cast(r.masks, C.POINTER(C.c_uint8)), int(r.n_mask_bytes), np.uint8)   # compact (bytes), as handed out
         else:
             t, m = np.zeros(0, dtype=TRAV_DTYPE), np.zeros((0, self.path_words), dtype=np.uint64)
         return {"ticket": int(r.ticket), "first_read_id": int(r.first_read_id), "n_reads": int(r.n_reads), "counts": r.counts.as_dict(),
-                "status": int(r.status), "n_travs": n, "travs": t, "masks": m, "n_mask_words": int(r.n_mask_words), "d_travs": r.d_travs,
+                "status": int(r.status), "n_travs": n, "travs": t, "masks": m, "n_mask_bytes": int(r.n_mask_bytes), "d_travs": r.d_travs,
                 "d_masks": r.d_masks,
                 "ms": {k: float(getattr(r.ms, k)) for k, _ in StageMs._fields_}}
 

@@ -183,12 +183,12 @@ typedef struct groot_batch_result {
     uint32_t first_read_id, n_reads;
     groot_counts counts;
     const groot_trav *travs;   /* [n_travs] in (read, ord) order; pinned host memory (NULL with results_on_device) */
-    /* Path sets, COMPACT: traversal i owns words(travs[i].graph_id) = max(1, ceil(paths of that graph / 64)) consecutive
-     * words, traversal after traversal; mask_ckpt[j] = index of the first word of traversal 256*j.  (12 instead of 24
-     * bytes per traversal over PCIe on arg-annot.90.)  groot_host_unpack_masks widens them to path_words words each. */
-    const uint64_t *masks;
+    /* Path sets, COMPACT: traversal i owns max(1, ceil(paths of graph travs[i].graph_id / 8)) consecutive BYTES (path p = bit
+     * p % 8 of byte p / 8), traversal after traversal; mask_ckpt[j] = offset of the first byte of traversal 256*j.  (1 to 2
+     * instead of 24 bytes per traversal over PCIe on arg-annot.90.)  groot_host_unpack_masks widens them to path_words words each. */
+    const uint8_t *masks;
     const uint32_t *mask_ckpt;
-    uint64_t n_mask_words;
+    uint64_t n_mask_bytes;
     uint64_t n_travs;
     const void *d_travs;       /* in HBM: the records and their path sets at path_words words per traversal */
     const void *d_masks;

@@ -140,9 +140,9 @@ typedef struct groot_aln {
 int groot_host_expand_alns(const groot_index_view *idx, const groot_trav *travs, const uint64_t *masks, uint64_t n_trav,
                            groot_aln *out, uint64_t cap, uint64_t *n_out);
 
-/* Path sets as groot_hip_collect hands them out (compact: max(1, ceil(paths of the traversal's graph / 64)) words per
+/* Path sets as groot_hip_collect hands them out (compact: max(1, ceil(paths of the traversal's graph / 8)) bytes per
  * traversal, back to back) -> path_words words per traversal, the layout groot_host_expand_alns takes. */
-int groot_host_unpack_masks(const groot_index_view *idx, const groot_trav *travs, uint64_t n_trav, const uint64_t *compact_masks,
+int groot_host_unpack_masks(const groot_index_view *idx, const groot_trav *travs, uint64_t n_trav, const uint8_t *compact_masks,
                             uint64_t *masks /*[n_trav * path_words]*/);
 
 /* ---- graph weighting after alignment ------------------------------------------------------------ */
@@ -242,10 +242,10 @@ void groot_reads_batch_free(groot_reads_batch *b);
 uint64_t groot_reads_count(const groot_reads *r);
 void groot_reads_close(groot_reads *r);
 /* collector for such a batch: traversal records -> sam.Records -> BGZF, parallel like groot_bam_write_travs */
-/* mask_ckpt != NULL: masks are the compact path sets of groot_hip_collect with their checkpoints (every 256th traversal);
- * NULL: path_words words per traversal */
+/* mask_ckpt != NULL: masks are the compact path sets of groot_hip_collect (bytes) with their checkpoints (every 256th traversal);
+ * NULL: masks points at uint64_t words, path_words of them per traversal */
 int groot_bam_write_batch(groot_bam *bam, const groot_index_view *idx, const groot_reads_view *reads, uint32_t first_read_id,
-                          const groot_trav *travs, const uint64_t *masks, const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records);
+                          const groot_trav *travs, const void *masks, const uint32_t *mask_ckpt, uint64_t n_trav, uint64_t *n_records);
 
 /* ---- packing reads for groot_hip_submit_packed (include/groot_hip.h) ------------------------------------ */
 /* packed[(n_bases+3)/4]; exceptions (bytes other than A C G T, e.g. N or lower case) in ascending position, at most

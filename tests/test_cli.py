@@ -241,7 +241,7 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     single = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert single["n_gpus"] == 1 and single["config"]["per_step_counts"]["received"] == 300000
     # the PCIe- and host-inclusive legs ride on the same line
-    assert single["host_fed"].get("value", 0) > 0 and single["host_fed"]["d2h_bytes_per_read"] > 20, single["host_fed"]
+    assert single["host_fed"].get("value", 0) > 0 and single["host_fed"]["d2h_bytes_per_read"] > 10, single["host_fed"]
     # ... and the legs for the inputs the memo does not answer, the threshold sweep and configs[4] in miniature
     assert single["robustness"]["substitutions_1pct"]["value"] > 0 and single["robustness"]["background_99pct"]["value"] > 0, single["robustness"]
     assert set(single["thresholds"]) == {"t=0.97", "t=0.95", "t=0.90"} and all(v["value"] > 0 for v in single["thresholds"].values())
