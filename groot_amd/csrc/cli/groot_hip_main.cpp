@@ -364,9 +364,13 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     logf("\tprocessors: %d", a.proc);
     for (auto &f : a.fastq) logf("\tinput file: %s", f.c_str());
     logf("loading the index information...");
+    // (the HIP runtime starts up on a thread of its own while the index is read: a few tenths of a second each)
+    int n_dev = 0, dev_rc = 0;
+    std::thread hip_init([&]() { dev_rc = groot_hip_device_count(&n_dev); });
     groot_index *idx = nullptr;
-    if (is_file(gidx) ? groot_index_load(gidx.c_str(), &idx) : groot_index_load_gob(gg.c_str(), lshe.c_str(), &idx))
-        die("%s", groot_host_last_error());
+    const int load_rc = is_file(gidx) ? groot_index_load(gidx.c_str(), &idx) : groot_index_load_gob(gg.c_str(), lshe.c_str(), &idx);
+    hip_init.join();
+    if (load_rc) die("%s", groot_host_last_error());
     groot_index_view v;
     groot_index_get_view(idx, &v);
     logf("\tk-mer size: %u", v.kmer_size);
@@ -376,8 +380,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     logf("\tnumber of variation graphs: %u", v.n_graphs);
     logf("rebuilding the LSH Ensemble...");
     // ---- one ctx per GPU (index replicated), opened concurrently ----
-    int n_dev = 0;
-    if (groot_hip_device_count(&n_dev) || n_dev == 0) die("no HIP device available (groot-hip align has no CPU fallback): %s", groot_hip_last_error(nullptr));
+    if (dev_rc || n_dev == 0) die("no HIP device available (groot-hip align has no CPU fallback): %s", groot_hip_last_error(nullptr));
     std::vector<int> devices;
     if (a.gpus > 0) {
         if (a.gpus > n_dev) die("--gpus %d but only %d device(s) visible", a.gpus, n_dev);

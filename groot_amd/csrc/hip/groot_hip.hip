@@ -1883,7 +1883,15 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->max_q = c->prm.max_read_len - c->k + 1;
 
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->astream, hipStreamNonBlocking));
+    {
+        // the align stream gets a priority of its own: streams of different priorities never share a hardware queue (two streams on one
+        // queue run their kernels in turn -- seen once in a while as a headline of 5.3 instead of 9 Greads/s), and the latency-bound
+        // graph walk is the stage that should get its few wavefronts placed first
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->astream, hipStreamNonBlocking, hi) != hipSuccess)
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->astream, hipStreamNonBlocking));
+    }
     for (WorkSet &w : c->ws) HIP_TRY(c, hipEventCreateWithFlags(&w.ev_free, hipEventDisableTiming));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));

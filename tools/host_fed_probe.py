@@ -1,5 +1,5 @@
 """bench.py's host_fed leg alone (pinned host -> GPU -> pinned host, several batches in flight), for tuning the copy-out:
-    GROOT_COPYOUT_BLOCKS=32 python tools/host_fed_probe.py [steps] [depth]"""
+    python tools/host_fed_probe.py [steps] [depth]"""
 import json
 import os
 import sys
@@ -24,5 +24,5 @@ for c0 in range(0, R, 1_000_000):
     parts.append(p[: n * bench.READ_LEN])
 d_seq = torch.cat(parts)
 hf, _ = bench.host_fed(index, d_seq, R, steps, depth)
-print(json.dumps({"blocks": os.environ.get("GROOT_COPYOUT_BLOCKS"), "depth": depth, "value": hf["value"], "ms_per_batch": hf["ms_per_batch"],
+print(json.dumps({"depth": depth, "value": hf["value"], "ms_per_batch": hf["ms_per_batch"],
                   "stage": {k: round(v, 2) for k, v in hf["stage_ms_per_batch"].items()}}))

@@ -27,14 +27,19 @@ def short(name):
     return base.split("<")[0]
 
 
-def loop_rows(rows, n_batches, key_start, key_id):
-    """the dispatches of the last n_batches batches: from the first kernel after the (n_batches + 1)-th last order_ovf_kernel"""
-    rows = sorted(rows, key=key_start)
+OPEN_ONLY = ("text_argmin_kernel", "sketch_equal_kernel", "text_table_fill_kernel")    # launched by groot_hip_open only
+
+
+def loop_rows(rows, n_batches, key):
+    """the dispatches of the last n_batches batches: every batch ends with one order_ovf_kernel, so the loop starts behind the
+    (n_batches + 1)-th last of them (a capture batch of groot_hip_open) -- or, for a ctx without memo, behind the last kernel that only
+    groot_hip_open launches, whichever comes later"""
+    rows = sorted(rows, key=key)
     ends = [i for i, r in enumerate(rows) if "order_ovf_kernel" in r["Kernel_Name"]]
-    if len(ends) <= n_batches:
-        return rows
-    cut = ends[-(n_batches + 1)]
-    # (with the results on the device the batch ends with order_ovf_kernel; the next batch's first kernels follow)
+    cut = ends[-(n_batches + 1)] if len(ends) > n_batches else -1
+    for i, r in enumerate(rows):
+        if any(k in r["Kernel_Name"] for k in OPEN_ONLY):
+            cut = max(cut, i)
     return rows[cut + 1:]
 
 
@@ -43,7 +48,7 @@ pmc_out = {}
 for w in workloads:
     for f in glob.glob(os.path.join(P, w, "trace", "**", "*kernel_trace.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if "groot" in r["Kernel_Name"] or "rocprim" in r["Kernel_Name"]]
-        rows = loop_rows(rows, STEPS["trace"], lambda r: int(r["Start_Timestamp"]), None)
+        rows = loop_rows(rows, STEPS["trace"], lambda r: int(r["Start_Timestamp"]))
         per = collections.OrderedDict()
         for r in rows:
             per.setdefault(short(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -57,10 +62,13 @@ for w in workloads:
     for d in ("sq", "fetch", "write", "tcc"):
         for f in glob.glob(os.path.join(P, w, d, "**", "*counter_collection.csv"), recursive=True):
             rows = [r for r in csv.DictReader(open(f)) if "groot" in r["Kernel_Name"]]
-            ids = sorted({int(r["Dispatch_Id"]) for r in rows if "order_ovf_kernel" in r["Kernel_Name"]})
-            first = ids[-(STEPS["pmc"] + 1)] + 1 if len(ids) > STEPS["pmc"] else 0
+            # (one row per dispatch and counter: cut on the dispatch ids)
+            per_dispatch = {}
             for r in rows:
-                if int(r["Dispatch_Id"]) < first:
+                per_dispatch.setdefault(int(r["Dispatch_Id"]), r)
+            keep = {int(r["Dispatch_Id"]) for r in loop_rows(list(per_dispatch.values()), STEPS["pmc"], lambda r: int(r["Dispatch_Id"]))}
+            for r in rows:
+                if int(r["Dispatch_Id"]) not in keep:
                     continue
                 k = short(r["Kernel_Name"])
                 pmc[k][r["Counter_Name"]] += float(r["Counter_Value"])
