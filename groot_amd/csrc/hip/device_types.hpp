@@ -166,6 +166,11 @@ struct DeviceIndex {
     // record = two uint4: bytes 0..23 the node's first 24 bases (0 past its end), dword 6 the global node index, dword 7 its length --
     // level 2 of AlignRead (alignment.go:47-70: offsets 0..10 of every contained node) reads nothing else until a start position matches
     const uint4 *cn_pre;
+    // per (node, start offset 0..10): a 64-bit set (two bits per member, l2_bloom_bits) of the 8-mers a DFS from there can spell --
+    // following every out-edge, the graph's 'N' and everything behind a sink counting as any base (dfsRecursive, alignment.go:193-254).
+    // A start position whose set lacks the read's first eight bases cannot produce a traversal: level 2 tries offsets 0..10 of every
+    // contained node, and on nodes of a few bases the in-node comparison lets most of them through.  [n_nodes][11]; null = none
+    const uint64_t *node_l2b;
     // lookup structures
     const ExactEntry *exact;        // open addressing, exact_mask+1 slots
     uint32_t exact_mask;

@@ -166,6 +166,7 @@ struct groot_ctx {
     // index in HBM
     DevBuf<uint32_t> graph_win_end;
     DevBuf<uint4> cn_pre;                  // DeviceIndex::cn_pre
+    DevBuf<uint64_t> node_l2b;             // DeviceIndex::node_l2b
     DevBuf<uint32_t> win_prefix, edges, win_graph, cn_node,
         band_keys, band_ids;
     DevBuf<ExactEntry> band_hash;
@@ -1113,7 +1114,9 @@ static int finish_counters(groot_ctx *c, Slot *s)
     fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", h.dbg[63]);
 #if GROOT_WORK_COUNTERS == 2
     fprintf(stderr, "[groot work] slow reads (%llu):", h.dbg[128]);
-    for (int i = 0; i < 60 && (unsigned long long)i < h.dbg[128]; i++) fprintf(stderr, " %llu:%llu", h.dbg[129 + i] & 0xFFFFFFFFull, h.dbg[129 + i] >> 32);
+    for (int i = 0; i < 30 && (unsigned long long)i < h.dbg[128]; i++)
+        fprintf(stderr, " %llu:%llu:%llu/%llu/%llu", h.dbg[129 + 2 * i] & 0xFFFFFFFFull, h.dbg[129 + 2 * i] >> 32, h.dbg[130 + 2 * i] & 0xFFFFFull,
+                (h.dbg[130 + 2 * i] >> 20) & 0xFFFFFull, h.dbg[130 + 2 * i] >> 40);
     fprintf(stderr, "\n");
 #endif
     for (int i = 0; i < 5; i++) fprintf(stderr, "[groot work] FETCH part %d: %.1f ms summed over wavefronts\n", i, (double)h.dbg[40 + i] / 1e5);
@@ -1884,12 +1887,12 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
 
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     {
-        // the align stream gets a priority of its own: streams of different priorities never share a hardware queue (two streams on one
-        // queue run their kernels in turn -- seen once in a while as a headline of 5.3 instead of 9 Greads/s), and the latency-bound
-        // graph walk is the stage that should get its few wavefronts placed first
+        // the align stream gets a priority of its own (the lowest): streams of different priorities never share a hardware queue -- two
+        // streams on one queue run their kernels in turn, seen once as a headline of 5.3 instead of 9 Greads/s -- and the hashing
+        // kernels, which are the longer stage on most workloads, get their workgroups placed first
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->astream, hipStreamNonBlocking, hi) != hipSuccess)
+        if (hipStreamCreateWithPriority(&c->astream, hipStreamNonBlocking, lo) != hipSuccess)
             HIP_TRY(c, hipStreamCreateWithFlags(&c->astream, hipStreamNonBlocking));
     }
     for (WorkSet &w : c->ws) HIP_TRY(c, hipEventCreateWithFlags(&w.ev_free, hipEventDisableTiming));
@@ -1947,6 +1950,64 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         }
         HIP_TRY(c, upload(c->cn_pre, reinterpret_cast<const uint4 *>(pre.data()), pre.size() / 4));
         c->dix.cn_pre = c->cn_pre.p;
+    }
+    {   // DeviceIndex::node_l2b: which 8-mers a DFS from (node, offset 0..10) can spell
+        std::vector<uint64_t> sets((size_t)v->n_nodes * 11, 0);
+        const unsigned nt = std::max(1u, std::min(32u, granted_cpus()));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                struct Walk {
+                    const groot_index_view *v;
+                    uint64_t set = 0;
+                    uint32_t budget = 0;
+                    // the strings of length 8 that start with `code` (d bases so far) and go on at (node, off)
+                    void go(uint32_t node, uint32_t off, uint32_t d, uint32_t code)
+                    {
+                        if (set == ~0ull) return;
+                        if (++budget > 4096) { set = ~0ull; return; }               // (a thicket of N and branches: anything goes)
+                        const uint32_t s0 = v->node_seq_off[node], len = v->node_seq_off[node + 1] - s0;
+                        if (off >= len) return;                                      // alignment.go:199-201 (also: an empty node ends the path)
+                        for (uint32_t i = off; i < len; i++) {
+                            if (d == 8) { set |= l2_bloom_bits(code); return; }
+                            const uint8_t b = v->bases[s0 + i];
+                            if (b == 'N') {                                          // :212-216 the graph's wildcard
+                                for (uint32_t x = 0; x < 4; x++) rest(node, i + 1, d + 1, code | (x << (2 * d)));
+                                return;
+                            }
+                            if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return;   // never equals a base of the read
+                            code |= (uint32_t)((b >> 1) & 3u) << (2 * d);
+                            d++;
+                        }
+                        rest_at_end(node, d, code);
+                    }
+                    // ... continuing inside the node at i (after a wildcard)
+                    void rest(uint32_t node, uint32_t i, uint32_t d, uint32_t code)
+                    {
+                        const uint32_t s0 = v->node_seq_off[node], len = v->node_seq_off[node + 1] - s0;
+                        if (i < len) { go(node, i, d, code); return; }
+                        rest_at_end(node, d, code);
+                    }
+                    void rest_at_end(uint32_t node, uint32_t d, uint32_t code)
+                    {
+                        if (d == 8) { set |= l2_bloom_bits(code); return; }
+                        const uint32_t e0 = v->node_edge_off[node], deg = v->node_edge_off[node + 1] - e0;
+                        if (!deg) { set = ~0ull; return; }                           // :229-236 a sink reports the traversal whatever the read goes on with
+                        for (uint32_t e = 0; e < deg; e++) go(v->edges[e0 + e], 0, d, code);
+                    }
+                };
+                for (uint32_t nd = t; nd < v->n_nodes; nd += nt) {
+                    const uint32_t len = v->node_seq_off[nd + 1] - v->node_seq_off[nd];
+                    for (uint32_t o = 0; o < std::min(len, 11u); o++) {
+                        Walk w{v};
+                        w.go(nd, o, 0, 0);
+                        sets[(size_t)nd * 11 + o] = w.set;
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+        HIP_TRY(c, upload(c->node_l2b, sets.data(), sets.size(), 2));
+        c->dix.node_l2b = c->node_l2b.p;
     }
     lap("node records + prefix tables");
     HIP_TRY(c, upload(c->win_graph, v->win_graph, v->n_windows));

@@ -22,6 +22,12 @@ namespace groot {
 // instruction runs at the best available lane fill.  A wavefront takes 64 consecutive reads of the processing order
 // at a time (they share a seed window, hence the graph nodes they walk) and asks for more when all lanes are done.
 enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
+constexpr uint32_t kCoopMin = 6;       // contained nodes from which level 2 of AlignRead asks its wavefront for a cooperative scan
+constexpr uint32_t kCoopWant = 0xFFFFFFFEu;
+#ifndef GROOT_COOP_MAX_ASK
+#define GROOT_COOP_MAX_ASK 8
+#endif
+constexpr uint32_t kCoopMaxAsk = GROOT_COOP_MAX_ASK;     // lanes of a wavefront that may ask in the same iteration
 constexpr uint32_t kWaveChunk = 128;   // consecutive slots a wave takes before asking for more (multiple of 64)
 
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
@@ -82,6 +88,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     uint32_t wc_iter = 0, wc_round0 = 0;                   // wave iterations so far / at the last refill
     unsigned long long wc_t[3] = {0, 0, 0};                // wall-clock ticks (100 MHz) per phase, wave-uniform
     uint32_t wc_n[3] = {0, 0, 0};                          // steps per phase
+    uint32_t wc_n0[3] = {0, 0, 0};                         // ... when the lane's current read began
 #define GROOT_EV(i) (ev |= 1u << (i))
 #else
 #define GROOT_EV(i) ((void)0)
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         bool no;
         if (cls & 0x40u) no = verdict(kRecNo12F);
         else no = prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff >= 12 ? dfs_chunk(8) : 0, eff);
-        if (no) { level = 2; cn_cur = cn_end; sc_pos = sc_end = 0; }
+        if (no) { level = 2; cn_cur = cn_end; sc_pos = sc_end = 0; sc_node = kEmpty; }
         return no;
     };
     // the current scan range is used up: move through the hierarchy until a non-empty range or the end
@@ -209,6 +216,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         for (;;) {
             if (level == 1) {                               // 2. seed node shuffling (:47-70): offsets 0..10 of every contained node
                 level = 2; cn_cur = cn_begin; sc_pos = 0; sc_end = 11;
+                // (sc_node / sc_s0 / sc_len are free during level 2: a window with many contained nodes asks the wavefront to look at 64 of
+                // them at once -- sc_node = kCoopWant, then the first entry of the block; sc_s0 | sc_len << 32 = the entries worth a visit)
+                sc_node = cn_end - cn_cur >= kCoopMin ? kCoopWant : kEmpty;
                 if (cn_cur < cn_end) return;
             } else if (level == 2) {
                 level = 3;                                  // 3. hard clip the first base (:72-85)
@@ -239,23 +249,35 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     };
     // which of the start offsets [0, npos) of a base string (w0, w1, w2 = its first 24 bytes; `room` of them lie inside the node) can
     // spell the first min(4, eff) read bases?  0x80 per surviving offset: offsets 0..7 in lo, 8..15 in hi
-    auto filter16 = [&](const uint64_t w0, const uint64_t w1, const uint64_t w2, const int npos, const int room, uint64_t &c_lo, uint64_t &c_hi) {
+    auto filter16x = [](const uint64_t pre, const uint32_t ef, const uint64_t w0, const uint64_t w1, const uint64_t w2, const int npos, const int room,
+                        uint64_t &c_lo, uint64_t &c_hi) {
         c_lo = low_bytes(npos); c_hi = low_bytes(npos - 8);
-        const uint32_t kf = min(4u, eff);
+        const uint32_t kf = min(4u, ef);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             if ((uint32_t)b >= kf) break;
-            const unsigned rb = (unsigned)(pre8 >> (8 * b)) & 0xFF;
+            const unsigned rb = (unsigned)(pre >> (8 * b)) & 0xFF;
             // positions whose base b lies inside the node must match it; past the node end the DFS decides
             const uint64_t need_lo = low_bytes(room - b), need_hi = low_bytes(room - b - 8);
             c_lo &= match_or_n(window8(w0, w1, b), rb) | ~need_lo;
             c_hi &= match_or_n(window8(w1, w2, b), rb) | ~need_hi;
         }
     };
+    auto filter16 = [&](const uint64_t w0, const uint64_t w1, const uint64_t w2, const int npos, const int room, uint64_t &c_lo, uint64_t &c_hi) {
+        filter16x(pre8, eff, w0, w1, w2, npos, room, c_lo, c_hi);
+    };
     auto first16 = [](const uint64_t c_lo, const uint64_t c_hi) -> uint32_t {
         if (c_lo) return (uint32_t)__builtin_ctzll(c_lo) >> 3;
         if (c_hi) return 8u + ((uint32_t)__builtin_ctzll(c_hi) >> 3);
         return 16u;
+    };
+    // can no DFS from (node, off) spell the first eight bases of the current view?  (DeviceIndex::node_l2b; sound: false when in doubt)
+    auto cannot_start = [&](uint32_t node, uint32_t off) -> bool {
+        if (!ix.node_l2b || off > 10u || eff < 8u) return false;
+        const int c8 = kmer8_code(pre8);
+        if (c8 < 0) return false;
+        const uint64_t need = l2_bloom_bits((uint32_t)c8);
+        return (ix.node_l2b[(size_t)node * 11 + off] & need) != need;
     };
     auto begin_dfs = [&](uint32_t node, uint32_t off) {
         node0 = node; noff0 = off; cur = node; coff = off; dist = 0; sp = 0; emitted = 0;
@@ -279,6 +301,45 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
 #ifdef GROOT_WORK_COUNTERS
         wc_iter++;
 #endif
+        // ---- cooperative level-2 scans: all 64 lanes look at one lane's contained nodes, an entry each ----
+        // A read that fails at a window of a variant-dense region walks 50-65 contained nodes of a few bases, eleven start offsets each, in
+        // both orientations: two entries per SCAN step and a step per start position that survives the 4-base filter -- it was the slowest
+        // read of its batch (130-500 SCAN steps), and the launch lasts as long as it does.  Here every lane, whatever it is doing for
+        // its own read, applies the requester's filters (4 bases, the in-node bases, the start position's 8-mer set) to entry
+        // cn_cur + lane; the ballot of the entries with a start position left is all the requester visits afterwards.
+        // (when many lanes ask at once -- reads that march in step -- each scanning its own entries is the parallel way: they are told so)
+        unsigned long long bh = __ballot(phase == PH_SCAN && level == 2u && sc_node == kCoopWant);
+        if (__popcll(bh) > (int)kCoopMaxAsk) {
+            if (phase == PH_SCAN && level == 2u && sc_node == kCoopWant) sc_node = kEmpty;
+            bh = 0;
+        }
+        for (; bh; bh &= bh - 1) {
+            const int L = __ffsll(bh) - 1;
+            const uint32_t q0 = __shfl(cn_cur, L), q1 = __shfl(cn_end, L), qeff = __shfl(eff, L);
+            const uint64_t qpre = (uint64_t)(uint32_t)__shfl((int)(uint32_t)pre8, L) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pre8 >> 32), L) << 32);
+            const int c8 = qeff >= 8u && ix.node_l2b ? kmer8_code(qpre) : -1;
+            const uint64_t need8 = c8 >= 0 ? l2_bloom_bits((uint32_t)c8) : 0ull;
+            const uint32_t e = q0 + (threadIdx.x & 63u);
+            bool has = false;
+            if (e < q1) {
+                const uint4 *ep = ix.cn_pre + 2 * (size_t)e;
+                const uint4 a0 = ep[0], a1 = ep[1];
+                const uint64_t w0 = (uint64_t)a0.x | ((uint64_t)a0.y << 32), w1 = (uint64_t)a0.z | ((uint64_t)a0.w << 32), w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
+                const uint32_t node = a1.z, nlen = a1.w;
+                uint64_t c_lo, c_hi;
+                filter16x(qpre, qeff, w0, w1, w2, (int)min(nlen, 11u), (int)nlen, c_lo, c_hi);
+                for (uint32_t j = first16(c_lo, c_hi); j < 16u; j = first16(c_lo, c_hi)) {
+                    if (j < 8) c_lo &= ~(0x80ull << (8 * j)); else c_hi &= ~(0x80ull << (8 * (j - 8)));
+                    const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
+                    if (!prefix_ok(g8, qpre, min(min(nlen - j, qeff), 8u))) continue;
+                    if (c8 >= 0 && (ix.node_l2b[(size_t)node * 11 + j] & need8) != need8) continue;
+                    has = true;
+                    break;
+                }
+            }
+            const unsigned long long bits = __ballot(has);
+            if ((int)(threadIdx.x & 63u) == L) { sc_node = q0; sc_s0 = (uint32_t)bits; sc_len = (uint32_t)(bits >> 32); }
+        }
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
         {
@@ -337,6 +398,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
 #endif
             if (!have_read) {
                 GROOT_EV(3);
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
+                wc_n0[0] = wc_n[0]; wc_n0[1] = wc_n[1]; wc_n0[2] = wc_n[2];
+#endif
                 const bool virt = slot < nv;                   // an item of a split read: seed positions [vlo, vhi) of its ascending list
                 uint32_t vlo = 0, vhi = 0;
                 if (virt) {
@@ -431,9 +495,12 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 atomicAdd(&a.ctr->dbg[64 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // when in its round the lane finished
 #endif
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
-                if (wc_iter - wc_round0 >= 100) {              // slow reads, by name (meaningful with GROOT_ROUND_LANES=1)
+                if (wc_iter - wc_round0 >= 300) {              // slow reads, by name (meaningful with one read per round): read | iterations, then its FETCH / SCAN / DFS steps
                     const unsigned long long sl = atomicAdd(&a.ctr->dbg[128], 1ull);
-                    if (sl < 60) a.ctr->dbg[129 + sl] = (unsigned long long)r | ((unsigned long long)(wc_iter - wc_round0) << 32);
+                    if (sl < 30) {
+                        a.ctr->dbg[129 + 2 * sl] = (unsigned long long)r | ((unsigned long long)(wc_iter - wc_round0) << 32);
+                        a.ctr->dbg[130 + 2 * sl] = (unsigned long long)(wc_n[0] - wc_n0[0]) | ((unsigned long long)(wc_n[1] - wc_n0[1]) << 20) | ((unsigned long long)(wc_n[2] - wc_n0[2]) << 40);
+                    }
                 }
 #endif
                 a.trav_cnt[(cls & 0x400u) ? a.n_reads + slot : r] = ord;
@@ -485,10 +552,25 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             if (level == 2) {
                 // 2. seed node shuffling: offsets sc_pos..10 of ContainedNodes entry cn_cur and 0..10 of the next one, from their
                 // 32-byte prefix records (24 bases, node, length) -- no trip to the node list, the node records or the graph bases
+                bool visit = true;
+                if (cn_cur < cn_end && sc_node != kEmpty) {
+                    // after a cooperative scan: only the entries of the block [sc_node, sc_node + 64) whose bit is set
+                    const uint32_t rel = cn_cur - sc_node;
+                    unsigned long long bits = (unsigned long long)sc_s0 | ((unsigned long long)sc_len << 32);
+                    bits = rel < 64u ? bits & ~((1ull << rel) - 1ull) : 0ull;
+                    if (!bits) {
+                        cn_cur = min(sc_node + 64u, cn_end); sc_pos = 0;
+                        sc_node = kCoopWant;                     // (the next block, if there is one)
+                        visit = false;
+                    } else {
+                        const uint32_t en = sc_node + (uint32_t)__builtin_ctzll(bits);
+                        if (en != cn_cur) { cn_cur = en; sc_pos = 0; }
+                    }
+                }
                 if (cn_cur >= cn_end) { GROOT_EV(6); advance = true; }
-                else {
+                else if (visit) {
                     const uint4 *e = ix.cn_pre + 2 * (size_t)cn_cur;
-                    const bool two = cn_cur + 1 < cn_end;
+                    const bool two = cn_cur + 1 < cn_end && sc_node == kEmpty;
                     uint4 a0 = e[0], a1 = e[1], b0 = make_uint4(0, 0, 0, 0), b1 = make_uint4(0, 0, 0, 0);
                     if (two) { b0 = e[2]; b1 = e[3]; }
                     uint64_t c_lo, c_hi;
@@ -512,7 +594,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                         // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
                         const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
                         sc_pos = j + 1; sc_end = min(nlen, 11u);
-                        if (!prefix_ok(g8, pre8, min(min(nlen - j, eff), 8u))) {
+                        if (!prefix_ok(g8, pre8, min(min(nlen - j, eff), 8u)) || cannot_start(node, j)) {
                             GROOT_EV(8);
                             if (sc_pos >= sc_end) { cn_cur++; sc_pos = 0; advance = cn_cur >= cn_end; }
                         } else {
@@ -539,7 +621,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                     // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
                     const uint32_t off = sc_pos + j;
                     sc_pos = off + 1;
-                    if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u))) {
+                    if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u)) || cannot_start(sc_node, off)) {
                         GROOT_EV(8);
                         advance = sc_pos >= sc_end;
                     } else {

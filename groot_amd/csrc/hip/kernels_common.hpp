@@ -82,6 +82,23 @@ __host__ __device__ __forceinline__ int kmer4_code(uint64_t r8)
     }
     return code;
 }
+// DeviceIndex::node_l2b: the two bits an 8-mer (2 bits per base, base i at bits 2i) sets / tests in a start position's 64-bit set
+__host__ __device__ __forceinline__ uint64_t l2_bloom_bits(uint32_t code16)
+{
+    const uint32_t x = code16 * 0x9E3779B1u;
+    return (1ull << (x >> 26)) | (1ull << ((x >> 20) & 63u));
+}
+// 16-bit code of the first 8 bases of r8, or -1 if one of them is not ACGT
+__host__ __device__ __forceinline__ int kmer8_code(uint64_t r8)
+{
+    int code = 0;
+    for (int i = 0; i < 8; i++) {
+        const unsigned b = (unsigned)(r8 >> (8 * i)) & 0xFF;
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') return -1;
+        code |= (int)((b >> 1) & 3) << (2 * i);
+    }
+    return code;
+}
 // DeviceIndex::win_prefix of one window: can no level-1/2 start position spell oriented read bases [0,12) = (c0, c1)?
 __device__ __forceinline__ bool prefix_absent(const uint32_t *tab, uint64_t c0, uint64_t c1, uint32_t eff)
 {

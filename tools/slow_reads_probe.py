@@ -34,9 +34,13 @@ c = al.wait()
 print("align ms", al.stage_ms()["align"], "walked", c["walked_reads"])
 if len(sys.argv) > 2:
     txt = open(sys.argv[2]).read()
-    m = re.findall(r"slow reads \((\d+)\):((?: \d+:\d+)*)", txt)
+    m = re.findall(r"slow reads \((\d+)\):((?: \d+:\d+:\d+/\d+/\d+)*)", txt)
     n, lst = m[-1]
-    pairs = [tuple(map(int, x.split(":"))) for x in lst.split()]
+    pairs, steps = [], {}
+    for x in lst.split():
+        r_, it_, fsd = x.split(":")
+        pairs.append((int(r_), int(it_)))
+        steps[int(r_)] = fsd
     sd = al.seeds()
     per = np.bincount(sd["read_id"], minlength=R)
     tr = al.travs()[0]
@@ -49,7 +53,7 @@ if len(sys.argv) > 2:
     for r, it in sorted(pairs, key=lambda p: -p[1])[:30]:
         ws = sd["window_id"][sd["read_id"] == r]
         cn = (cn_off[ws + 1] - cn_off[ws]) if len(ws) else np.zeros(0)
-        print("read %7d iterations %5d len %3d seeds %3d graphs %d traversals %d contained nodes per window: max %d mean %.1f  node len of first seed %d merge_span %d" % (
-            r, it, L[r], per[r], len(np.unique(wg[ws])), ntr[r], cn.max() if len(cn) else 0, cn.mean() if len(cn) else 0,
+        print("read %7d iterations %5d (FETCH/SCAN/DFS steps %s) len %3d seeds %3d graphs %d traversals %d contained nodes per window: max %d mean %.1f  node len of first seed %d merge_span %d" % (
+            r, it, steps[r], L[r], per[r], len(np.unique(wg[ws])), ntr[r], cn.max() if len(cn) else 0, cn.mean() if len(cn) else 0,
             (arr["node_seq_off"][arr["win_node"][ws[0]] + 1] - arr["node_seq_off"][arr["win_node"][ws[0]]]) if len(ws) else 0, arr["win_merge_span"][ws[0]] if len(ws) else 0))
 al.close()
