@@ -327,11 +327,12 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
         uint64_t tb = 0, tf = 0, te = 0;
         std::vector<uint8_t> raw, blk, rcs, rcq, padq;
         std::vector<uint32_t> starts, rel;                       // record starts in raw (structural BGZF only)
+        std::vector<uint8_t> follow;                             // ... and: the record is a patched copy of the one before it (bgzf_struct.hpp)
         std::vector<groot_aln_record> recs;
         for (;;) {
             const size_t c = next.fetch_add(1);
             if (c >= n_chunks) { ns_build += tb; ns_format += tf; ns_encode += te; break; }
-            raw.clear(); starts.clear();
+            raw.clear(); starts.clear(); follow.clear();
             const uint64_t t0 = c * kChunk, t1 = std::min<uint64_t>(n_trav, t0 + kChunk);
             uint64_t moff = mask_ckpt ? mask_ckpt[c] : 0;        // compact path sets: a checkpoint per chunk (kChunk = 256 traversals)
             for (uint64_t t = t0; t < t1; t++) {
@@ -358,6 +359,7 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                 const uint8_t sc = (tr.flags & GROOT_TRAV_START_CLIP) ? 1 : 0, ec = (tr.flags & GROOT_TRAV_END_CLIP) ? 1 : 0;
                 bool first = (tr.flags & GROOT_TRAV_FIRST) != 0;
                 recs.clear();
+                uint64_t n_here = 0;                                  // records of this traversal so far (structural path: formatted as they come)
                 const uint32_t np0 = ix->node_np_off[tr.node], np1 = ix->node_np_off[tr.node + 1];
                 // (compact path sets: max(1, ceil(paths / 8)) bytes per traversal, widened here; else path_words words)
                 uint64_t wide[16];
@@ -383,25 +385,49 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                         else
                             for (uint32_t j = np0; j < np1; j++)           // (pairs not in path order: look through all of them)
                                 if (ix->np_path[j] == p) { pos = ix->np_pos[j] + tr.offset; break; }
+                        const uint32_t ref_id = ix->graph_path_off[tr.graph_id] + p;
+                        const uint32_t seq_len = (uint32_t)len - sc - ec;                                // alignment.go:117-122
+                        if (rd.name_len > 254 || ref_id >= b->n_ref) { errs[c] = GROOT_E_FORMAT; break; }
+                        if (level == kBamStructural && n_here) {
+                            // the next path of the same traversal: the record before it with refID, pos, bin and the Secondary flag
+                            // patched (alignment.go:113-156 builds them from the same read and the same CIGAR) -- no field-by-field assembly
+                            const size_t prev_at = starts.back(), L = raw.size() - prev_at, at2 = raw.size();
+                            raw.resize(at2 + L);
+                            uint8_t *q = raw.data() + at2;
+                            memcpy(q, raw.data() + prev_at, L);
+                            const uint16_t bin = (uint16_t)reg2bin(pos, (int64_t)pos + (seq_len ? seq_len : 1));
+                            uint16_t flag;
+                            memcpy(&flag, q + 18, 2);
+                            flag |= 0x100;                                                               // alignment.go:147-149
+                            memcpy(q + 4, &ref_id, 4); memcpy(q + 8, &pos, 4); memcpy(q + 14, &bin, 2); memcpy(q + 18, &flag, 2);
+                            starts.push_back((uint32_t)at2); follow.push_back(1);
+                            n_here++;
+                            continue;
+                        }
                         groot_aln_record rec;
                         rec.name = rd.name;
                         rec.name_len = rd.name_len;
                         rec.seq = sq; rec.qual = ql;
-                        rec.seq_len = (uint32_t)len - sc - ec;                                    // alignment.go:117-122
-                        rec.ref_id = ix->graph_path_off[tr.graph_id] + p;
+                        rec.seq_len = seq_len;
+                        rec.ref_id = ref_id;
                         rec.pos = pos; rec.start_clip = sc; rec.end_clip = ec;
                         rec.reverse = (tr.flags & GROOT_TRAV_RC) ? 1 : 0;
                         rec.secondary = first ? 0 : 1;                                            // alignment.go:147-149
                         first = false;
-                        if (rec.name_len > 254 || rec.ref_id >= b->n_ref) { errs[c] = GROOT_E_FORMAT; break; }
+                        if (level == kBamStructural) {
+                            format_records(&rec, 0, 1, raw, &starts);
+                            follow.push_back(0);
+                            n_here++;
+                            continue;
+                        }
                         recs.push_back(rec);
                     }
                 }
                 if (errs[c]) break;
-                nrec[c] += recs.size();
+                nrec[c] += level == kBamStructural ? n_here : recs.size();
                 const uint64_t q1 = bam_stats ? now_ns() : 0;
                 tb += q1 - q0;
-                format_records(recs.data(), 0, recs.size(), raw, level == kBamStructural ? &starts : nullptr);   // rcs/rcq/padq stay valid until here
+                if (level != kBamStructural) format_records(recs.data(), 0, recs.size(), raw, nullptr);   // rcs/rcq/padq stay valid until here
                 if (bam_stats) tf += now_ns() - q1;
             }
             if (errs[c]) continue;
@@ -413,13 +439,16 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
                 while (r0 < starts.size()) {
                     size_t r1 = r0 + 1;
                     const size_t a = starts[r0];
-                    while (r1 < starts.size() && (r1 + 1 < starts.size() ? starts[r1 + 1] : raw.size()) - a <= kBgzfBlock) r1++;
+                    // (0xd000, not the 0xff00 a member may inflate to: first records go out as stored blocks, so the member is a little
+                    // LARGER than its contents when few records follow another -- 5 bytes per stored block -- and must stay below 64 KB)
+                    const size_t kCap = 0xd000;
+                    while (r1 < starts.size() && (r1 + 1 < starts.size() ? starts[r1 + 1] : raw.size()) - a <= kCap) r1++;
                     const size_t e = r1 < starts.size() ? starts[r1] : raw.size();
                     bool ok = e - a <= kBgzfBlock;
                     if (ok) {
                         rel.resize(r1 - r0);
                         for (size_t x = r0; x < r1; x++) rel[x - r0] = starts[x] - (uint32_t)a;
-                        ok = bgzf_member_structural(raw.data() + a, e - a, rel.data(), rel.size(), outs[c]);
+                        ok = bgzf_member_structural(raw.data() + a, e - a, rel.data(), rel.size(), outs[c], follow.data() + r0);
                     }
                     if (!ok)
                         for (size_t o = a; o < e; o += kBgzfBlock) {

@@ -148,20 +148,35 @@ struct BitWriter {
     inline uint8_t *finish()
     {
         while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
+        n = 0; acc = 0;
         return p;
+    }
+    // a stored block's payload starts at a byte boundary: pad with zero bits, then the bytes as they are
+    inline void bytes(const uint8_t *src, size_t len)
+    {
+        finish();
+        memcpy(p, src, len);
+        p += len;
     }
 };
 
 // data[0..n) with record starts rec[0..n_rec) (ascending, rec[0] == 0, the last record ends at n) -> one BGZF member appended to
 // out.  false: the block cannot be written this way (a record of 32 KB or more, output larger than a member may be).
-static inline bool bgzf_member_structural(const uint8_t *data, size_t n, const uint32_t *rec, size_t n_rec, std::vector<uint8_t> &out)
+// follow (optional, one byte per record): the writer's own knowledge of the records.  follow[r] = 1: record r is a copy of record
+// r - 1 in which only bytes [4, 20) may differ (refID, pos, bin, flag: the next path of the same traversal, bam.cpp) -- no comparison
+// of the ~200 bytes behind them; follow[r] = 0: a record of its own (the first of a traversal: another read's name, bases and
+// qualities) -- it goes out as a STORED deflate block, a memcpy instead of ~230 Huffman-coded literals (which fixed codes would
+// not make any smaller).  The member is then a sequence of stored and fixed-Huffman blocks closed by an empty final block.
+static inline bool bgzf_member_structural(const uint8_t *data, size_t n, const uint32_t *rec, size_t n_rec, std::vector<uint8_t> &out,
+                                          const uint8_t *follow = nullptr)
 {
     static const DeflateTables T;
     if (n == 0 || n > 0xff00) return false;
     const size_t at = out.size();
-    out.resize(at + 18 + n + n / 8 + 64 + 8);                      // literals cost at most 9 bits
+    out.resize(at + 18 + n + n / 8 + 8 * n_rec + 64 + 8);          // literals cost at most 9 bits; a stored block 5-6 bytes
     BitWriter bw(out.data() + at + 18);
-    bw.put(3, 3);                                                  // BFINAL = 1, BTYPE = 01 (fixed Huffman)
+    bool in_huff = false;                                          // a fixed-Huffman block is open
+    if (!follow) { bw.put(3, 3); in_huff = true; }                 // BFINAL = 1, BTYPE = 01 (fixed Huffman): the whole member is one block
     auto lit = [&](uint8_t b) { bw.put(T.lit_code[b], T.lit_bits[b]); };
     auto match = [&](uint32_t len, uint32_t dist) {                // 3 <= len <= 258, 1 <= dist <= 32768
         bw.put(T.lit_code[T.len_sym[len]], T.lit_bits[T.len_sym[len]]);
@@ -197,13 +212,27 @@ static inline bool bgzf_member_structural(const uint8_t *data, size_t n, const u
         const size_t a = rec[r], b = r + 1 < n_rec ? rec[r + 1] : n;
         const size_t len = b - a;
         const uint8_t *cur = data + a;
-        if (r > 0 && len == a - rec[r - 1] && len < 32768 && len >= 36) {
+        const bool trusted = follow && follow[r] && r > 0 && len == a - rec[r - 1] && len < 32768 && len >= 36;
+        if (follow && !trusted) {                                  // stored block (BTYPE = 00): header bits, pad to a byte, LEN, ~LEN, the bytes
+            if (in_huff) { bw.put(T.lit_code[256], T.lit_bits[256]); in_huff = false; }
+            bw.put(0, 3);
+            const uint16_t l16 = (uint16_t)len, nl16 = (uint16_t)~l16;
+            uint8_t hdr4[4] = {(uint8_t)l16, (uint8_t)(l16 >> 8), (uint8_t)nl16, (uint8_t)(nl16 >> 8)};
+            bw.bytes(hdr4, 4);
+            bw.bytes(cur, len);
+            continue;
+        }
+        if (follow && !in_huff) { bw.put(2, 3); in_huff = true; }   // BFINAL = 0, BTYPE = 01
+        if (trusted || (r > 0 && len == a - rec[r - 1] && len < 32768 && len >= 36)) {
             // same size as the record before it: whatever equals it comes from there
             const uint8_t *prev = data + rec[r - 1];
             // (the records of a read differ in their first 36 bytes only -- refID, pos, bin, flag: everything behind the last
             // difference there is one comparison and one run of matches, not a loop over ~200 bytes)
             size_t tail = len;                                     // [tail, len) equals the previous record
-            if (!memcmp(cur + 36, prev + 36, len - 36)) {
+            if (trusted) {
+                tail = 20;
+                while (tail > 0 && cur[tail - 1] == prev[tail - 1]) tail--;
+            } else if (!memcmp(cur + 36, prev + 36, len - 36)) {
                 tail = 36;
                 while (tail > 0 && cur[tail - 1] == prev[tail - 1]) tail--;
             }
@@ -219,7 +248,8 @@ static inline bool bgzf_member_structural(const uint8_t *data, size_t n, const u
             }
         } else plain(cur, len);
     }
-    bw.put(T.lit_code[256], T.lit_bits[256]);                      // end of block
+    if (in_huff) bw.put(T.lit_code[256], T.lit_bits[256]);         // end of block
+    if (follow) { bw.put(3, 3); bw.put(T.lit_code[256], T.lit_bits[256]); }   // ... and an empty final block (BFINAL = 1, fixed Huffman, end of block)
     uint8_t *end = bw.finish();
     const size_t clen = (size_t)(end - (out.data() + at + 18));
     const size_t total = 18 + clen + 8;

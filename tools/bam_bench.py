@@ -33,6 +33,21 @@ node = node_s[j]
 offset = st - pos_s[j]
 pw = v.path_words
 masks = a["node_mask"].reshape(v.n_nodes, pw)[node].copy()
+max_paths = int(sys.argv[4]) if len(sys.argv) > 4 else 17          # (arg-annot.90 reads: 17 records each on average)
+if max_paths:
+    for w in range(pw):                                             # keep at most max_paths set bits per traversal (lowest first), word by word
+        m = masks[:, w].copy()
+        out = np.zeros_like(m)
+        left = np.full(len(m), max_paths, dtype=np.int64) if w == 0 else left
+        for _ in range(64):
+            low = m & (~m + np.uint64(1))
+            take = (low != 0) & (left > 0)
+            out |= np.where(take, low, np.uint64(0))
+            left = left - take.astype(np.int64)
+            m = m & ~low
+            if not take.any():
+                break
+        masks[:, w] = out
 tr = np.zeros(n, dtype=device.TRAV_DTYPE)
 tr["read_id"] = np.arange(n); tr["graph_id"] = g_of_node[node]; tr["node"] = node; tr["offset"] = offset
 tr["flags"] = 8 | (truth["strand"] & 1).astype(np.uint8)
