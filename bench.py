@@ -154,14 +154,18 @@ def kernel_blocks(workload, ms, counts, R, mean_len, pw):
         if t_ms > 0:
             e["achieved"] = b / (t_ms * 1e-3) / 1e9
             e["frac"] = e["achieved"] / HBM_PEAK_GBS
-        p = pmc_of(workload, k.split("<")[0])
+        p = pmc_of(workload, k) or pmc_of(workload, k.split("<")[0])
         if p:
             e["traffic"] = p.get("hbm_bytes_per_launch")
             pl = p.get("per_launch", {})
+            if pl.get("SQ_INSTS_VALU") and p.get("avg_ms"):
+                # share of the chip's VALU issue slots the kernel used: wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x duration);
+                # duration = the kernel's average in the trace of the same workload (it runs beside the other stage's kernels there too)
+                e["valu_issue"] = 4.0 * pl["SQ_INSTS_VALU"] / (1024 * 2.4e9 * p["avg_ms"] * 1e-3)
             if pl.get("SQ_WAVE_CYCLES"):
-                # share of the resident waves' cycles in which a VALU instruction issued (4 cycles each)
-                e["valu_issue"] = 4.0 * pl.get("SQ_INSTS_VALU", 0.0) / pl["SQ_WAVE_CYCLES"] if pl.get("SQ_INSTS_VALU") else None
-                e["wait_frac"] = pl.get("SQ_WAIT_ANY", 0.0) / pl["SQ_WAVE_CYCLES"]
+                e["wait_frac"] = pl.get("SQ_WAIT_ANY", 0.0) / pl["SQ_WAVE_CYCLES"]     # share of the resident waves' cycles spent waiting
+            if p.get("l2_hit_rate") is not None:
+                e["l2_hit_rate"] = p.get("l2_hit_rate")
             e["pmc_kernel_ms"] = p.get("avg_ms")
             e["traffic_source"] = "profiles/r04_pmc.json[%s]" % workload
         out[k] = e
