@@ -113,6 +113,9 @@ type Params struct {
 	// MemoBudgetMB: 0 = the library's default budget for the memo of groot_hip_open, MemoOff = no memo (a run over a few
 	// million reads: the memo costs more at open than it saves), else MiB
 	MemoBudgetMB uint32
+	// Background: GROOT_OPEN_BACKGROUND -- Open returns once the ctx can take batches and builds the prefix tables and the signature
+	// index on a thread of its own (the Index must stay alive, which the Ctx sees to)
+	Background bool
 }
 
 // MemoOff is GROOT_MEMO_OFF
@@ -149,7 +152,11 @@ func Open(device int, idx *Index, p Params) (*Ctx, error) {
 	if c.params.MaxReadLen == 0 {
 		c.params.MaxReadLen = uint32(prm.max_read_len)
 	}
-	if rc := C.groot_hip_open(&c.h, C.int(device), &idx.view, &prm); rc != 0 {
+	var flags C.uint32_t
+	if p.Background {
+		flags = C.GROOT_OPEN_BACKGROUND
+	}
+	if rc := C.groot_hip_open_flags(&c.h, C.int(device), &idx.view, &prm, flags); rc != 0 {
 		return nil, fmt.Errorf("groot_hip_open: %s", C.GoString(C.groot_hip_last_error(nil)))
 	}
 	return c, nil

@@ -427,7 +427,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         for (size_t i = 0; i < gpus.size(); i++)
             th.emplace_back([&, i]() {
                 groot_params prm = params_for(gpus[i]->max_read_len);
-                if (groot_hip_open(&gpus[i]->ctx, gpus[i]->device, &v, &prm)) errs[i] = groot_hip_last_error(nullptr);
+                if (groot_hip_open_flags(&gpus[i]->ctx, gpus[i]->device, &v, &prm, GROOT_OPEN_BACKGROUND)) errs[i] = groot_hip_last_error(nullptr);
             });
         for (auto &t : th) t.join();
         for (auto &e : errs) if (!e.empty()) die("%s", e.c_str());
@@ -530,7 +530,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
                 g.max_read_len = std::min<uint32_t>(65535, need + need / 2);
                 groot_params prm = params_for(g.max_read_len);
                 logf("\tread of %u bases: reopening the GPU context for reads up to %u bases", need, g.max_read_len);
-                if (groot_hip_open(&g.ctx, g.device, &v, &prm)) { fail_with(groot_hip_last_error(nullptr)); return false; }
+                if (groot_hip_open_flags(&g.ctx, g.device, &v, &prm, GROOT_OPEN_BACKGROUND)) { fail_with(groot_hip_last_error(nullptr)); return false; }
                 if (n_rows && groot_hip_attempts_import(g.ctx, qv.data(), cnt.data(), n_rows)) { fail_with(groot_hip_last_error(g.ctx)); return false; }
                 return true;
             };
@@ -655,7 +655,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
             g->max_read_len = longest;
             groot_params prm = params_for(longest);
             logf("\tGPU %d: reopening its context for reads up to %u bases (another context met one) before the call counts are summed", g->device, longest);
-            if (groot_hip_open(&g->ctx, g->device, &v, &prm)) die("%s", groot_hip_last_error(nullptr));
+            if (groot_hip_open_flags(&g->ctx, g->device, &v, &prm, GROOT_OPEN_BACKGROUND)) die("%s", groot_hip_last_error(nullptr));
             if (n_rows && groot_hip_attempts_import(g->ctx, qv.data(), cnt.data(), n_rows)) die("%s", groot_hip_last_error(g->ctx));
         }
         std::vector<groot_ctx *> ctxs;
@@ -690,12 +690,27 @@ int run_align(const Args &a)   // cmd/align.go:54-163
             logf("\ttotal number of graphs remaining: %u", kept_graphs);
             logf("\ttotal number of possible haplotypes found: %u", kept_paths);
             logf("saving graphs...");                                                            // cmd/align.go:153-161
-            for (uint32_t g = 0; g < v.n_graphs; g++) {
-                if (!gk[g]) continue;
-                const std::string fn = graph_dir + "/groot-graph-" + std::to_string(g) + ".gfa";
-                int written = 0;
-                if (groot_host_save_gfa(&v, g, kf.data(), pk.data(), nr.data(), total_kmers, nullptr, fn.c_str(), &written)) die("%s", groot_host_last_error());
-            }
+            // (one file per graph, independent of each other: written side by side)
+            std::atomic<uint32_t> next_g{0};
+            std::atomic<bool> gfa_failed{false};
+            std::mutex gfa_mu;
+            std::string gfa_err;
+            auto save = [&]() {
+                for (uint32_t g = next_g.fetch_add(1); g < v.n_graphs; g = next_g.fetch_add(1)) {
+                    if (!gk[g]) continue;
+                    const std::string fn = graph_dir + "/groot-graph-" + std::to_string(g) + ".gfa";
+                    int written = 0;
+                    if (groot_host_save_gfa(&v, g, kf.data(), pk.data(), nr.data(), total_kmers, nullptr, fn.c_str(), &written)) {
+                        std::lock_guard<std::mutex> lk(gfa_mu);
+                        if (!gfa_failed.exchange(true)) gfa_err = groot_host_last_error();
+                    }
+                }
+            };
+            std::vector<std::thread> savers;
+            for (int t = 1; t < std::max(1, std::min(a.proc, 16)); t++) savers.emplace_back(save);
+            save();
+            for (auto &t : savers) t.join();
+            if (gfa_failed) die("%s", gfa_err.c_str());
         }
     }
     for (auto &g : gpus) groot_hip_close(g->ctx);

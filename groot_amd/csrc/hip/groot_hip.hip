@@ -196,6 +196,22 @@ struct groot_ctx {
     uint32_t sig_disabled = 0;             // windows whose text did not reproduce Key.Sketch (they cannot confirm reads)
     DeviceIndex dix{};
 
+    // groot_hip_open_flags(GROOT_OPEN_BACKGROUND): the prefix tables and the signature index are built on a thread of its own while the
+    // first batches already run (through the full-width kernel, without the seed stage's verdicts: same results, a little slower);
+    // what it builds is described in bg_dix and moves into dix between two batches (install_background)
+    std::thread bg;
+    std::atomic<int> bg_state{0};          // 0 nothing pending, 1 running, 2 finished, 3 failed
+    int bg_rc = 0;
+    std::string bg_err;
+    DeviceIndex bg_dix{};
+    hipStream_t bg_stream = nullptr;
+    DevBuf<unsigned long long> bg_shards;
+    // where the table builders of groot_hip_open work: the ctx's own index description / compute stream / shard counters, or the
+    // background thread's
+    DeviceIndex *build_dix = nullptr;
+    hipStream_t build_stream = nullptr;
+    unsigned long long *build_shards = nullptr;
+
     // pipeline
     std::vector<std::unique_ptr<Slot>> slots;
     std::deque<Slot *> inflight;           // submission order: IN_FLIGHT / D2H_ISSUED
@@ -249,6 +265,8 @@ __attribute__((constructor)) static void groot_hw_queues() { setenv("GPU_MAX_HW_
 
 static thread_local std::string g_open_err;
 
+static thread_local bool tl_background = false;       // this thread is a ctx's background builder
+
 static int fail(groot_ctx *ctx, int code, const char *fmt, ...)
 {
     char buf[1024];
@@ -256,7 +274,7 @@ static int fail(groot_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) (tl_background ? ctx->bg_err : ctx->err) = buf;
     else g_open_err = buf;
     return code;
 }
@@ -337,120 +355,6 @@ uint32_t round_pw(uint32_t pw)
         if (pw <= c) return c;
     return 0;
 }
-
-// Per window: every 5-base prefix a read must start with for AlignRead's level 1 (seed node, offsets
-// OffSet..OffSet+MergeSpan+WindowSize inside the node, alignment.go:34-45) or level 2 (ContainedNodes,
-// offsets 0..10, :47-70) to have any chance: the spellings of 5 bases from each such start position,
-// following every OutEdge at node ends ('N' spells anything; a sink before 5 bases accepts anything, as
-// dfsRecursive reports a traversal that runs off the graph, :229).  Sound: never clears a spellable prefix.
-// Which read prefixes can AlignRead's levels 1-2 start on?  Two tables per window: 6-mer codes (2 bits per base,
-// A=0 C=1 T=2 G=3) of oriented read bases [0,6) and [6,12) that some level-1 / level-2 start position of the window
-// (alignment.go:34-70) can spell -- following every out-edge, with the graph's 'N' and the graph ends (a read may
-// hang off a sink, alignment.go:229-236) as wildcards.  Sound filters: a read whose code is absent from either table
-// cannot pass performAlignment from any of those starts.
-struct PrefixTables {
-    static constexpr int K = 6, T = 2;
-    const groot_index_view *v;
-    // per table and graph position: the codes spelled from there, as (code | have << 12); have < K = the walk fell off
-    // a sink after `have` coded bases and every completion counts
-    std::vector<uint32_t> start[T];      // [n_bases + 1]
-    std::vector<uint16_t> ent[T];
-
-    struct Walker {
-        const groot_index_view *v;
-        int d0;                          // first coded depth of this table
-        std::vector<uint16_t> *out;
-        void walk(uint32_t node, uint32_t off, int depth, int code)
-        {
-            const uint32_t s0 = v->node_seq_off[node], len = v->node_seq_off[node + 1] - s0;
-            while (off < len && depth < d0 + K) {
-                if (depth >= d0) {
-                    const uint8_t b = v->bases[s0 + off];
-                    if (b == 'N') {
-                        for (int c = 0; c < 4; c++) walk(node, off + 1, depth + 1, code | (c << (2 * (depth - d0))));
-                        return;
-                    }
-                    code |= (int)((b >> 1) & 3) << (2 * (depth - d0));
-                }
-                depth++; off++;
-            }
-            if (depth == d0 + K) { out->push_back((uint16_t)(code | (K << 12))); return; }
-            const uint32_t e0 = v->node_edge_off[node], e1 = v->node_edge_off[node + 1];
-            if (e0 == e1) { out->push_back((uint16_t)(code | (std::max(0, depth - d0) << 12))); return; }
-            for (uint32_t e = e0; e < e1; e++) walk(v->edges[e], 0, depth, code);
-        }
-    };
-
-    void positions(unsigned nt)
-    {
-        // pass 1 per node (threads take nodes round-robin), then stitched into one CSR per table
-        std::vector<std::vector<uint16_t>> per_node[T];
-        std::vector<std::vector<uint32_t>> per_node_cnt[T];
-        for (int t = 0; t < T; t++) { per_node[t].resize(v->n_nodes); per_node_cnt[t].resize(v->n_nodes); }
-        std::vector<std::thread> th;
-        for (unsigned x = 0; x < nt; x++)
-            th.emplace_back([&, x]() {
-                for (uint32_t n = x; n < v->n_nodes; n += nt) {
-                    const uint32_t len = v->node_seq_off[n + 1] - v->node_seq_off[n];
-                    for (int t = 0; t < T; t++) {
-                        Walker wk{v, t * K, &per_node[t][n]};
-                        per_node_cnt[t][n].resize(len);
-                        for (uint32_t o = 0; o < len; o++) {
-                            const size_t before = per_node[t][n].size();
-                            wk.walk(n, o, 0, 0);
-                            auto &e = per_node[t][n];
-                            std::sort(e.begin() + before, e.end());
-                            e.erase(std::unique(e.begin() + before, e.end()), e.end());
-                            per_node_cnt[t][n][o] = (uint32_t)(e.size() - before);
-                        }
-                    }
-                }
-            });
-        for (auto &x : th) x.join();
-        for (int t = 0; t < T; t++) {
-            start[t].assign(v->n_bases + 1, 0);
-            size_t total = 0;
-            for (uint32_t n = 0; n < v->n_nodes; n++) total += per_node[t][n].size();
-            ent[t].reserve(total);
-            for (uint32_t n = 0; n < v->n_nodes; n++) {      // node order = order of `bases`
-                const uint32_t s0 = v->node_seq_off[n];
-                uint32_t run = (uint32_t)ent[t].size();
-                for (size_t o = 0; o < per_node_cnt[t][n].size(); o++) { start[t][s0 + o] = run; run += per_node_cnt[t][n][o]; }
-                ent[t].insert(ent[t].end(), per_node[t][n].begin(), per_node[t][n].end());
-            }
-            start[t][v->n_bases] = (uint32_t)ent[t].size();
-        }
-    }
-    // nodes are stored back to back in `bases` and the CSR was filled in that order: p's entries end where p+1's begin
-    void add(int t, size_t pos, uint32_t *bits) const
-    {
-        for (uint32_t i = start[t][pos]; i < start[t][pos + 1]; i++) {
-            const int code = ent[t][i] & 0xFFF, have = ent[t][i] >> 12;
-            if (have >= K) { bits[code >> 5] |= 1u << (code & 31); continue; }
-            const int free_bits = 2 * (K - have);
-            for (int x = 0; x < (1 << free_bits); x++) {
-                const int c = (code & ((1 << (2 * have)) - 1)) | (x << (2 * have));
-                bits[c >> 5] |= 1u << (c & 31);
-            }
-        }
-    }
-    void window(uint32_t w, uint32_t *out) const     // out: T * 128 words
-    {
-        const uint32_t seed = v->win_node[w], off0 = v->win_offset[w];
-        const uint32_t seed_len = v->node_seq_off[seed + 1] - v->node_seq_off[seed];
-        const uint64_t last = (uint64_t)off0 + v->win_merge_span[w] + v->window_size;
-        const uint32_t hi = (uint32_t)std::min<uint64_t>(seed_len, last + 1);
-        for (int t = 0; t < T; t++) {
-            uint32_t *bits = out + t * 128;
-            for (uint32_t o = off0; o < hi; o++) add(t, (size_t)v->node_seq_off[seed] + o, bits);
-            for (uint32_t c = v->win_cn_off[w]; c < v->win_cn_off[w + 1]; c++) {
-                const uint32_t n = v->cn_node[c];
-                const uint32_t nlen = v->node_seq_off[n + 1] - v->node_seq_off[n];
-                for (uint32_t o = 0; o < std::min(nlen, 11u); o++) add(t, (size_t)v->node_seq_off[n] + o, bits);
-            }
-        }
-    }
-};
 
 template <int PW> void build_node_records(const groot_index_view *v, std::vector<unsigned char> &out)
 {
@@ -901,10 +805,13 @@ static Slot *free_slot(groot_ctx *c)
     return nullptr;
 }
 
+static int install_background(groot_ctx *c, bool wait);
+
 // copy-in, decode, kernels, counter copy-out of slot s: everything asynchronous
 static int enqueue(groot_ctx *c, Slot *s)
 {
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = install_background(c, false)) return rc;
     s->status = GROOT_OK; s->status_msg.clear();
     s->n_trav = 0; s->host_results = false;
     memset(&s->counts, 0, sizeof s->counts);
@@ -1251,6 +1158,8 @@ void groot_hip_close(groot_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->bg.joinable()) ctx->bg.join();
+    if (ctx->bg_stream) { (void)hipStreamSynchronize(ctx->bg_stream); (void)hipStreamDestroy(ctx->bg_stream); }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->astream) (void)hipStreamSynchronize(ctx->astream);
     if (ctx->h2d_stream) (void)hipStreamSynchronize(ctx->h2d_stream);
@@ -1296,31 +1205,32 @@ static int text_pass(groot_ctx *c, const uint8_t *seqs, const uint32_t *owner, u
     HIP_TRY(c, win.alloc((size_t)c->seed_slots * n));
     HIP_TRY(c, key.alloc(n));
     HIP_TRY(c, rec.alloc(n));
-    HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(own.p, owner, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->build_stream));
+    HIP_TRY(c, hipMemcpyAsync(own.p, owner, (size_t)n * 4, hipMemcpyHostToDevice, c->build_stream));
+    HIP_TRY(c, hipMemsetAsync(ctr.p, 0, sizeof(DeviceCounters), c->build_stream));
     const dim3 grid((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->stream, off.p, n, len);
+    hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->build_stream, off.p, n, len);
     SeedArgs a{};
-    a.ix = c->dix;
+    a.ix = *c->build_dix;
     a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, c->prm.max_read_len);
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * len + 32, kMaxLdsReadBytes);
     a.seed_slots = c->seed_slots; a.seed_count = cnt.p; a.seed_win = win.p;
-    a.ctr = ctr.p; a.shards = c->seed_shards.p;
+    a.ctr = ctr.p; a.shards = c->build_shards;
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
     SeedArgs d = a;                                         // sketches only: no lookup
     d.ix.max_q = 0; d.sketch_out = sk.p;
-    launch_seed(c->s, c->max_k, d, true, grid, lds, c->stream);
-    hipLaunchKernelGGL(sketch_equal_kernel, grid, dim3(kBlock), 0, c->stream, sk.p, own.p, c->win_sketch.p, c->s, n, bad.p);
+    launch_seed(c->s, c->max_k, d, true, grid, lds, c->build_stream);
+    hipLaunchKernelGGL(sketch_equal_kernel, grid, dim3(kBlock), 0, c->build_stream, sk.p, own.p, c->win_sketch.p, c->s, n, bad.p);
     a.sort_key = key.p; a.sort_span_bits = 0; a.read_rec = rec.p;
-    launch_seed(c->s, c->max_k, a, false, grid, lds, c->stream);
+    launch_seed(c->s, c->max_k, a, false, grid, lds, c->build_stream);
     HIP_TRY(c, hipGetLastError());
     std::vector<ReadRec> h(n);
-    HIP_TRY(c, hipMemcpyAsync(h.data(), rec.p, (size_t)n * sizeof(ReadRec), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(keys, key.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(differs, bad.p, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));   // (nobody folds them here)
+    HIP_TRY(c, hipMemcpyAsync(h.data(), rec.p, (size_t)n * sizeof(ReadRec), hipMemcpyDeviceToHost, c->build_stream));
+    HIP_TRY(c, hipMemcpyAsync(keys, key.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->build_stream));
+    HIP_TRY(c, hipMemcpyAsync(differs, bad.p, n, hipMemcpyDeviceToHost, c->build_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->build_stream));
+    HIP_TRY(c, hipMemsetAsync(c->build_shards, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long), c->build_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->build_stream));   // (nobody folds them here)
     for (uint32_t i = 0; i < n; i++) cnt_flags[i] = h[i].cnt_flags;
     return GROOT_OK;
 }
@@ -1800,10 +1710,10 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
         HIP_TRY(c, upload(d_text, text.data(), text.size()));
         HIP_TRY(c, upload(d_len, tlen.data(), tlen.size()));
         HIP_TRY(c, d_pos.alloc((size_t)n * 2));
-        hipLaunchKernelGGL(text_argmin_kernel, dim3((2 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, d_text.p, d_len.p, 2 * n, k, d_pos.p);
+        hipLaunchKernelGGL(text_argmin_kernel, dim3((2 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->build_stream, d_text.p, d_len.p, 2 * n, k, d_pos.p);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(argmin.data(), d_pos.p, argmin.size(), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyAsync(argmin.data(), d_pos.p, argmin.size(), hipMemcpyDeviceToHost, c->build_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->build_stream));
     }
     std::vector<uint8_t> packed((size_t)n * 2 * (kTextMax / 4) + 64, 0);
     for (uint32_t i = 0; i < n; i++)
@@ -1833,15 +1743,15 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));
     HIP_TRY(c, upload(c->sig_info, verdict.data(), verdict.size()));
     HIP_TRY(c, upload(c->win_nodes, nodes.data(), nodes.size(), 4));
-    c->dix.sig_info = c->sig_info.p;
-    c->dix.sig_verdict_stride = vstride;
-    c->dix.win_nodes = c->win_nodes.p;
+    c->build_dix->sig_info = c->sig_info.p;
+    c->build_dix->sig_verdict_stride = vstride;
+    c->build_dix->win_nodes = c->win_nodes.p;
     lap("tables + uploads");
-    c->dix.sig = c->sig.p;
-    c->dix.sig_mask = cap - 1;
-    c->dix.win_text = c->win_text.p;
+    c->build_dix->sig = c->sig.p;
+    c->build_dix->sig_mask = cap - 1;
+    c->build_dix->win_text = c->win_text.p;
     // 5. outcome table: the align stage itself, once, on every string that confirms reads
-    if (c->dix.sig_info && !c->kn.no_outcome_table && c->prm.memo_budget_mb != GROOT_MEMO_OFF && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
+    if (c->build_dix == &c->dix && c->dix.sig_info && !c->kn.no_outcome_table && c->prm.memo_budget_mb != GROOT_MEMO_OFF && !c->prm.no_exact_align && !c->prm.keep_sketches && w <= c->prm.max_read_len && v->n_graphs < (1u << 20)) {
         const auto t0 = std::chrono::steady_clock::now();
         if (int rc = build_outcome_table(c, v, text, tlen, verdict, w, vstride)) return rc;
         c->out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1850,7 +1760,68 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     return GROOT_OK;
 }
 
-static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, const groot_params *p)
+// DeviceIndex::win_prefix: per window, which 6-mers its level-1 / level-2 start positions can spell as read bases [0, 6) and [6, 12)
+// (kernels_misc.hpp prefix_positions_kernel / prefix_windows_kernel; on the host this took three core-seconds for arg-annot.90)
+static int build_prefix_tables(groot_ctx *c, const groot_index_view *v)
+{
+    if (!v->n_windows || !v->n_nodes || !v->n_bases) return GROOT_OK;      // (an index without windows: groot_hip_sketch only)
+    DevBuf<uint32_t> d_seq_off, d_edge_off, pos_bits;
+    HIP_TRY(c, upload(d_seq_off, v->node_seq_off, (size_t)v->n_nodes + 1));
+    HIP_TRY(c, upload(d_edge_off, v->node_edge_off, (size_t)v->n_nodes + 1));
+    HIP_TRY(c, c->win_prefix.alloc((size_t)v->n_windows * kPrefixWords));
+    static_assert(kPrefixWords == kBlock, "a thread per word of a window's two tables");
+    // a pass per run of whole graphs holding up to 2 M bases (1 KB of sets per base position): the windows of a graph only start in its
+    // own nodes, and nodes and windows are stored graph by graph (else: one pass over everything)
+    bool grouped = true;
+    for (uint32_t w = 1; w < v->n_windows; w++) grouped &= v->win_graph[w] >= v->win_graph[w - 1];
+    const uint64_t kPassBases = 2u << 20;
+    uint32_t g0 = 0, w0 = 0;
+    while (g0 < v->n_graphs) {
+        uint32_t g1 = g0 + 1;
+        const uint32_t p0 = v->node_seq_off[v->graph_node_off[g0]];
+        if (!grouped) g1 = v->n_graphs;
+        else while (g1 < v->n_graphs && (uint64_t)v->node_seq_off[v->graph_node_off[g1 + 1]] - p0 <= kPassBases) g1++;
+        const uint32_t p1 = v->node_seq_off[v->graph_node_off[g1]];
+        uint32_t w1 = w0;
+        if (!grouped) w1 = v->n_windows;
+        else while (w1 < v->n_windows && v->win_graph[w1] < g1) w1++;
+        if (p1 > p0 && w1 > w0) {
+            const size_t words = (size_t)(p1 - p0) * 256 + 256;
+            HIP_TRY(c, pos_bits.reserve(words));
+            HIP_TRY(c, hipMemsetAsync(pos_bits.p, 0, words * sizeof(uint32_t), c->build_stream));
+            PrefixBuildArgs a{};
+            a.bases = c->bases.p; a.seq_off = d_seq_off.p; a.edge_off = d_edge_off.p; a.edges = c->edges.p;
+            a.n_nodes = v->n_nodes; a.p0 = p0; a.p1 = p1; a.pos_bits = pos_bits.p;
+            hipLaunchKernelGGL(prefix_positions_kernel, dim3((unsigned)((2 * (uint64_t)(p1 - p0) + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->build_stream, a);
+            hipLaunchKernelGGL(prefix_windows_kernel, dim3(w1 - w0), dim3(kBlock), 0, c->build_stream, c->win_rec.p, c->cn_pre.p, d_seq_off.p, pos_bits.p, p0, w0, w1, c->win_prefix.p);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->build_stream));
+        } else if (w1 > w0) HIP_TRY(c, hipMemsetAsync(c->win_prefix.p + (size_t)w0 * kPrefixWords, 0, (size_t)(w1 - w0) * kPrefixWords * sizeof(uint32_t), c->build_stream));
+        g0 = g1; w0 = w1;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->build_stream));
+    c->build_dix->win_prefix = c->win_prefix.p;
+    return GROOT_OK;
+}
+
+// what a background open has finished moves into the ctx's index description: between two batches, on the caller's thread
+static int install_background(groot_ctx *c, bool wait)
+{
+    const int st0 = c->bg_state.load(std::memory_order_acquire);
+    if (st0 == 0 || (st0 == 1 && !wait)) return GROOT_OK;
+    if (c->bg.joinable()) c->bg.join();
+    const int st = c->bg_state.load(std::memory_order_acquire);
+    c->bg_state.store(0);
+    c->build_dix = &c->dix; c->build_stream = c->stream; c->build_shards = c->seed_shards.p;
+    if (st == 3) return fail(c, c->bg_rc ? c->bg_rc : GROOT_E_DEVICE, "background part of groot_hip_open: %s", c->bg_err.c_str());
+    const DeviceIndex &b = c->bg_dix;
+    c->dix.win_prefix = b.win_prefix;
+    c->dix.sig = b.sig; c->dix.sig_mask = b.sig_mask; c->dix.win_text = b.win_text;
+    c->dix.sig_info = b.sig_info; c->dix.sig_verdict_stride = b.sig_verdict_stride; c->dix.win_nodes = b.win_nodes;
+    return GROOT_OK;
+}
+
+static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, const groot_params *p, uint32_t flags)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1899,6 +1870,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    c->build_dix = &c->dix; c->build_stream = c->stream;
     for (uint32_t i = 0; i < c->prm.pipeline_depth; i++) {
         std::unique_ptr<Slot> s(new Slot());
         for (hipEvent_t *e : {&s->ev_seed, &s->ev_h2d0, &s->ev_h2d, &s->ev_compute, &s->ev_ctr, &s->ev_d2h0, &s->ev_d2h}) HIP_TRY(c, hipEventCreate(e));
@@ -1924,20 +1896,6 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         if (c->pw == 3) build_node_records<3>(v, recs);
         else build_node_records<11>(v, recs);
         HIP_TRY(c, upload(c->node_rec, recs.data(), recs.size()));
-    }
-    {
-        std::vector<uint32_t> k5((size_t)v->n_windows * kPrefixWords, 0);
-        const unsigned nt = std::min(32u, granted_cpus());
-        PrefixTables pt;
-        pt.v = v;
-        pt.positions(nt);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t]() {
-                for (uint32_t w = t; w < v->n_windows; w += nt) pt.window(w, k5.data() + (size_t)w * kPrefixWords);
-            });
-        for (auto &x : th) x.join();
-        HIP_TRY(c, upload(c->win_prefix, k5.data(), k5.size()));
     }
     {   // level 2 of AlignRead: the first 24 bases, index and length of every ContainedNodes entry, in list order (DeviceIndex::cn_pre)
         std::vector<uint32_t> pre((size_t)v->n_cn * 8 + 8, 0);
@@ -2251,10 +2209,41 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     HIP_TRY(c, hipMemset(c->seed_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));
     HIP_TRY(c, hipDeviceSynchronize());
     lap("work buffers");
+    c->build_shards = c->seed_shards.p;
     // WindowSize-mers on the every-slot-equal branch of Query never touch the LSH-Forest tables: the signature index and the memo
     // (both run window-sized strings through the kernels) are built while the band tables are still being sorted
     const uint32_t q_w = v->window_size >= v->kmer_size ? v->window_size - v->kmer_size + 1 : 0;
     const bool w_exact = q_w && q_w < c->h_q_min_eq.size() && c->h_q_min_eq[q_w] == s;
+    // The memo needs the signature index and the ctx's whole pipeline: with it everything is built here and now.
+    const bool memo_wanted = !c->kn.no_outcome_table && c->prm.memo_budget_mb != GROOT_MEMO_OFF && !c->prm.no_exact_align && !c->prm.keep_sketches;
+    if ((flags & GROOT_OPEN_BACKGROUND) && !memo_wanted) {
+        // prefix tables (0.2 s on arg-annot.90) and signature index (0.4 s) on a thread of their own: the ctx takes batches at once --
+        // through the full-width kernel and without the seed stage's verdicts until they are there (same results)
+        if (int rc = finish_lsh()) return rc;
+        lap("LSH forest tables (waited for)");
+        c->bg_dix = c->dix;
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->bg_stream, hipStreamNonBlocking));
+        HIP_TRY(c, c->bg_shards.alloc((size_t)kSeedShards * kSeedShardStride));
+        HIP_TRY(c, hipMemset(c->bg_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));
+        c->build_dix = &c->bg_dix; c->build_stream = c->bg_stream; c->build_shards = c->bg_shards.p;
+        c->bg_state.store(1);
+        c->bg = std::thread([c, v, sc = std::move(sketch_class)]() {
+            tl_background = true;
+            int rc = GROOT_OK;
+            try {
+                if (hipSetDevice(c->device) != hipSuccess) rc = fail(c, GROOT_E_DEVICE, "hipSetDevice");
+                if (!rc) rc = build_prefix_tables(c, v);
+                if (!rc) rc = build_signature_index(c, v, sc);
+            } catch (const std::exception &e) {
+                rc = fail(c, GROOT_E_NOSPACE, "%s", e.what());
+            }
+            c->bg_rc = rc;
+            c->bg_state.store(rc ? 3 : 2, std::memory_order_release);
+        });
+        return GROOT_OK;
+    }
+    if (int rc = build_prefix_tables(c, v)) return rc;
+    lap("prefix tables");
     if (!w_exact) { if (int rc = finish_lsh()) return rc; lap("LSH forest tables (waited for)"); }
     if (int rc = build_signature_index(c, v, sketch_class)) return rc;
     if (int rc = finish_lsh()) return rc;
@@ -2274,13 +2263,25 @@ int groot_hip_open_stats(const groot_ctx *c, groot_open_stats *out)
 
 int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p)
 {
+    return groot_hip_open_flags(out, device_id, idx, p, 0);
+}
+
+int groot_hip_open_wait(groot_ctx *c)
+{
+    if (!c) return GROOT_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return install_background(c, true);
+}
+
+int groot_hip_open_flags(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p, uint32_t flags)
+{
     if (!out) return fail(nullptr, GROOT_E_INVALID, "null out pointer");
     *out = nullptr;
     groot_ctx *c = new groot_ctx();
     const auto t_open0 = std::chrono::steady_clock::now();
     int rc;
     try {
-        rc = open_impl(c, device_id, idx, p);
+        rc = open_impl(c, device_id, idx, p, flags);
     } catch (const std::bad_alloc &) {      // (host tables of the index / the memo: nothing may unwind through the C boundary)
         rc = fail(c, GROOT_E_NOSPACE, "out of host memory while building the device tables");
     } catch (const std::exception &e) {

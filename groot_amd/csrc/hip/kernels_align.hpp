@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         phase = PH_SCAN;
         bool no;
         if (cls & 0x40u) no = verdict(kRecNo12F);
-        else no = prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff >= 12 ? dfs_chunk(8) : 0, eff);
+        else no = ix.win_prefix && prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff >= 12 ? dfs_chunk(8) : 0, eff);   // (null: the tables are still being built, groot_hip_open_flags)
         if (no) { level = 2; cn_cur = cn_end; sc_pos = sc_end = 0; sc_node = kEmpty; }
         return no;
     };

@@ -273,6 +273,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
                 const uint32_t c12 = t ? code_r : code_f;
                 bool no12;
                 if (pre) no12 = !(((t ? ahead->tr_a : ahead->tf_a) >> (c12 & 31)) & 1u) || !(((t ? ahead->tr_b : ahead->tf_b) >> ((c12 >> 12) & 31)) & 1u);
+                else if (!ix.win_prefix) no12 = false;            // (the tables are still being built: groot_hip_open_flags)
                 else no12 = have_codes ? prefix_absent_codes(tab, c12 & 0xFFFu, c12 >> 12) : prefix_absent(tab, c0, c1, len);
                 uint32_t vt = no12 ? kRecNo12F : 0u;
                 if (!in_node || !prefix_ok(g8, (c0 >> 8) | (c1 << 56), m34)) vt |= kRecNo3F;    // read[1:] at (seed, OffSet)

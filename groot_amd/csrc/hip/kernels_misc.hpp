@@ -583,3 +583,115 @@ __global__ __launch_bounds__(kBlock) void mask_compact_kernel(const groot_trav *
 
 
 } // namespace groot
+
+namespace groot {
+
+// ---- DeviceIndex::win_prefix, built on the device (groot_hip_open) ------------------------------------------------------------------
+// Which read prefixes can AlignRead's levels 1-2 start on?  Two tables per window: the 6-mer codes (2 bits per base, A=0 C=1 T=2 G=3) of
+// oriented read bases [0,6) and [6,12) that some level-1 / level-2 start position of the window (alignment.go:34-70) can spell --
+// following every out-edge, with the graph's 'N' and the graph ends (a read may hang off a sink, alignment.go:229-236) as wildcards.
+// Sound filters: a read whose code is absent from either table cannot pass performAlignment from any of those starts.
+// Two steps: (1) per graph base position and table the 4096-bit set of codes a walk from there spells (a thread per position and table,
+// depth-first with explicit frames: a frame per node entered and per 'N' branched on, at most two dozen); (2) per window the union over
+// its start positions (a workgroup per window, a thread per 32-bit word, the positions' sets read as whole 512-byte rows).
+struct PrefixBuildArgs {
+    const uint8_t *bases;
+    const uint32_t *seq_off, *edge_off, *edges;   // [n_nodes + 1], [n_nodes + 1], [n_edges]
+    uint32_t n_nodes, p0, p1;                      // the positions of this pass: [p0, p1) -- the bases of a run of whole graphs
+    uint32_t *pos_bits;                            // [p1 - p0][2][128]
+};
+constexpr int kPrefixK = 6, kPrefixFrames = 40;
+__global__ __launch_bounds__(kBlock) void prefix_positions_kernel(PrefixBuildArgs a)
+{
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= 2u * (a.p1 - a.p0)) return;
+    const uint32_t pos = a.p0 + (gid >> 1), tb = gid & 1u;
+    const int d0 = (int)tb * kPrefixK;
+    uint32_t *bits = a.pos_bits + (size_t)gid * 128;
+    // the node holding the position: the last node whose first base is at or before it (empty nodes hold none)
+    uint32_t lo = 0, hi = a.n_nodes;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.seq_off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    while (lo + 1 < a.n_nodes && a.seq_off[lo + 1] <= pos) lo++;
+    // frames: {node, offset, depth | code << 8, cursor}; cursor = next out-edge (or next base of an 'N') to try, kEmpty = the frame has not run yet
+    uint32_t f_node[kPrefixFrames], f_off[kPrefixFrames], f_dc[kPrefixFrames], f_cur[kPrefixFrames];
+    int sp = 0;
+    f_node[0] = lo; f_off[0] = pos - a.seq_off[lo]; f_dc[0] = 0; f_cur[0] = kEmpty; sp = 1;
+    auto set_code = [&](uint32_t code) { bits[code >> 5] |= 1u << (code & 31u); };
+    while (sp > 0) {
+        const int f = sp - 1;
+        const uint32_t node = f_node[f];
+        const uint32_t s0 = a.seq_off[node], len = a.seq_off[node + 1] - s0;
+        if (f_cur[f] == kEmpty) {
+            // first visit: spell the node's bases from the frame's offset
+            uint32_t off = f_off[f];
+            int depth = (int)(f_dc[f] & 0xFFu);
+            uint32_t code = f_dc[f] >> 8;
+            bool wild = false;
+            while (off < len && depth < d0 + kPrefixK) {
+                if (depth >= d0) {
+                    const uint8_t b = a.bases[s0 + off];
+                    if (b == 'N') { wild = true; break; }
+                    code |= (uint32_t)((b >> 1) & 3u) << (2 * (depth - d0));
+                }
+                depth++; off++;
+            }
+            f_off[f] = off; f_dc[f] = (uint32_t)depth | (code << 8);
+            if (wild) { f_cur[f] = 0x80000000u; continue; }             // branch over the four bases at `off`
+            if (depth == d0 + kPrefixK) { set_code(code); sp--; continue; }
+            const uint32_t e0 = a.edge_off[node], e1 = a.edge_off[node + 1];
+            if (e0 == e1) {                                             // a sink: every completion counts
+                const int have = max(0, depth - d0);
+                const uint32_t low = code & ((1u << (2 * have)) - 1u);
+                for (uint32_t x = 0; x < (1u << (2 * (kPrefixK - have))); x++) set_code(low | (x << (2 * have)));
+                sp--;
+                continue;
+            }
+            f_cur[f] = e0;
+            continue;
+        }
+        if (f_cur[f] & 0x80000000u) {                                   // an 'N' at f_off: the next of the four bases
+            const uint32_t c = f_cur[f] & 3u, done = (f_cur[f] >> 2) & 1u;
+            if (done) { sp--; continue; }
+            f_cur[f] = c == 3u ? (0x80000000u | 4u) : (0x80000000u | (c + 1u));
+            const int depth = (int)(f_dc[f] & 0xFFu);
+            const uint32_t code = f_dc[f] >> 8;
+            if (sp < kPrefixFrames) {
+                f_node[sp] = node; f_off[sp] = f_off[f] + 1; f_dc[sp] = (uint32_t)(depth + 1) | ((code | (c << (2 * (depth - d0)))) << 8); f_cur[sp] = kEmpty;
+                sp++;
+            } else for (uint32_t w = 0; w < 128; w++) bits[w] = ~0u;    // (deeper than any real graph: anything goes -- sound)
+            continue;
+        }
+        // out-edges, one per visit
+        const uint32_t e1 = a.edge_off[node + 1];
+        if (f_cur[f] >= e1) { sp--; continue; }
+        const uint32_t child = a.edges[f_cur[f]++];
+        if (sp < kPrefixFrames) {
+            f_node[sp] = child; f_off[sp] = 0; f_dc[sp] = f_dc[f]; f_cur[sp] = kEmpty;
+            sp++;
+        } else for (uint32_t w = 0; w < 128; w++) bits[w] = ~0u;
+    }
+}
+
+// (2) the union over a window's start positions: level 1 = offsets [OffSet, l1_hi) of the seed node, level 2 = offsets 0..10 of every
+// contained node.  One workgroup of 256 threads per window: thread i owns word i of the window's two tables.
+__global__ __launch_bounds__(kBlock) void prefix_windows_kernel(const WinRec *__restrict__ win_rec, const uint4 *__restrict__ cn_pre, const uint32_t *__restrict__ seq_off,
+                                                                const uint32_t *__restrict__ pos_bits, uint32_t p0, uint32_t w0, uint32_t w1, uint32_t *__restrict__ out)
+{
+    const uint32_t w = w0 + blockIdx.x;
+    if (w >= w1) return;
+    const WinRec wr = win_rec[w];
+    const uint32_t i = threadIdx.x;                                     // table (i >> 7), word (i & 127): a position's two tables are 256 consecutive words
+    uint32_t acc = 0;
+    for (uint32_t o = wr.offset; o < wr.l1_hi; o++) acc |= pos_bits[(size_t)(wr.seed_s0 + o - p0) * 256 + i];
+    for (uint32_t c = wr.cn_off; c < wr.cn_end; c++) {
+        const uint4 e1 = cn_pre[2 * (size_t)c + 1];
+        const uint32_t s0 = seq_off[e1.z], n = min(e1.w, 11u);
+        for (uint32_t o = 0; o < n; o++) acc |= pos_bits[(size_t)(s0 + o - p0) * 256 + i];
+    }
+    out[(size_t)w * kPrefixWords + i] = acc;
+}
+
+} // namespace groot

@@ -7,6 +7,7 @@
 #include "host_common.hpp"
 
 #include <algorithm>
+#include <thread>
 
 #include <cstring>
 #include <ctime>
@@ -120,11 +121,38 @@ int groot_host_weights_rows(const groot_index_view *ix, const uint32_t *q_values
         if (q_values[r] <= q_values[r - 1]) return set_error(GROOT_E_INVALID, "kmerCounts must be strictly ascending");
     memset(kf, 0, sizeof(double) * ix->n_nodes);
     memset(kt, 0, sizeof(uint64_t) * ix->n_graphs);
-    for (uint32_t w = 0; w < ix->n_windows; w++)
-        for (uint32_t r = 0; r < n_rows; r++) {
-            const uint32_t c = counts[(size_t)r * ix->n_windows + w];
-            for (uint32_t i = 0; i < c; i++) increment_sub_path(ix, w, double(q_values[r]), kf, kt);
-        }
+    // canonical order of the float additions: windows ascending, kmerCounts ascending within a window, one call at a time
+    // (graph.go:401-451 adds a share per call).  A window only touches nodes and the counter of its own graph, so graphs are replayed
+    // side by side when the windows are numbered graph by graph (they are: the index builder emits them so) -- same sums, bit for bit.
+    auto replay = [&](uint32_t w0, uint32_t w1) {
+        for (uint32_t w = w0; w < w1; w++)
+            for (uint32_t r = 0; r < n_rows; r++) {
+                const uint32_t c = counts[(size_t)r * ix->n_windows + w];
+                for (uint32_t i = 0; i < c; i++) increment_sub_path(ix, w, double(q_values[r]), kf, kt);
+            }
+    };
+    bool grouped = true;
+    for (uint32_t w = 1; w < ix->n_windows; w++) grouped &= ix->win_graph[w] >= ix->win_graph[w - 1];
+    const unsigned nt = grouped ? std::min<unsigned>(usable_cpus(), 16) : 1;
+    if (nt <= 1 || ix->n_windows < 4096) { replay(0, ix->n_windows); return GROOT_OK; }
+    // cut points at graph boundaries, about equal numbers of calls per piece
+    std::vector<uint64_t> calls(ix->n_windows + 1, 0);
+    for (uint32_t w = 0; w < ix->n_windows; w++) {
+        uint64_t c = 0;
+        for (uint32_t r = 0; r < n_rows; r++) c += counts[(size_t)r * ix->n_windows + w];
+        calls[w + 1] = calls[w] + c + 1;
+    }
+    std::vector<uint32_t> cut{0};
+    for (unsigned t = 1; t < nt; t++) {
+        uint32_t w = (uint32_t)(std::lower_bound(calls.begin(), calls.end(), calls.back() * t / nt) - calls.begin());
+        w = std::min(w, ix->n_windows);
+        while (w > 0 && w < ix->n_windows && ix->win_graph[w] == ix->win_graph[w - 1]) w++;       // on to the next graph's first window
+        if (w > cut.back() && w < ix->n_windows) cut.push_back(w);
+    }
+    cut.push_back(ix->n_windows);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i + 1 < cut.size(); i++) th.emplace_back(replay, cut[i], cut[i + 1]);
+    for (auto &x : th) x.join();
     return GROOT_OK;
 }
 

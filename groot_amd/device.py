@@ -114,12 +114,14 @@ class Aligner:
     """One groot_ctx: the replacement for theBoss.mapReads (src/pipeline/boss.go:108-242) on one GPU."""
 
     def __init__(self, index, device=0, threshold=0.99, no_align=False, max_read_len=256, max_batch_reads=1 << 20,
-                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0, pipeline_depth=0, results_on_device=False, memo_budget_mb=0):
+                 max_seeds_per_read=8, keep_sketches=False, max_batch_bases=0, pipeline_depth=0, results_on_device=False, memo_budget_mb=0,
+                 background=False):
         self.index = index
         self.params = Params(threshold, 1 if no_align else 0, max_read_len, max_batch_reads, max_seeds_per_read,
                              max_batch_bases, 1 if keep_sketches else 0, pipeline_depth, 1 if results_on_device else 0, memo_budget_mb)
         self._h = C.c_void_p()
-        rc = lib().groot_hip_open(C.byref(self._h), C.c_int(device), C.byref(index.view), C.byref(self.params))
+        # (background: GROOT_OPEN_BACKGROUND -- the index arrays must outlive the build: self.index holds them)
+        rc = lib().groot_hip_open_flags(C.byref(self._h), C.c_int(device), C.byref(index.view), C.byref(self.params), C.c_uint32(1 if background else 0))
         if rc:
             raise GrootError(rc, lib().groot_hip_last_error(None).decode(errors="replace"))
         self.s = index.view.sketch_size
@@ -138,6 +140,10 @@ class Aligner:
         return rc
 
     # ---- batch API ----------------------------------------------------------------------------
+    def open_wait(self):
+        """groot_hip_open_wait: the background part of the open (prefix tables, signature index) is in place"""
+        self._check(lib().groot_hip_open_wait(self._h))
+
     def open_stats(self):
         """groot_hip_open_stats: what open built besides the uploaded index (the memo) and how long it took"""
         st = OpenStats()

@@ -109,6 +109,17 @@ const char *groot_hip_last_error(const groot_ctx *ctx); /* ctx may be NULL: erro
  * (what ContainmentIndex.Load / BootstrapLshEnsembleEquiDepth do, lshe.go:95-147).  The view is checked first
  * (groot_index_view_check's pass): GROOT_E_FORMAT for one whose indices or offsets do not resolve. */
 int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p);
+/* The same with flags.  GROOT_OPEN_BACKGROUND: return as soon as the ctx can take batches (graphs, window arrays, exact and
+ * LSH-Forest tables in HBM) and build the rest -- per-window prefix tables, the signature index: 0.6 of the 0.75 s an open without
+ * memo takes on arg-annot.90 -- on a thread of the ctx while the first batches run through the full-width kernels; results are the
+ * same whichever kernels a batch met.  The one exception to "no call retains a caller pointer": `idx` must stay valid until
+ * groot_hip_open_wait (or groot_hip_close) has returned.  Ignored when the memo is wanted (it needs everything at once).
+ * groot_hip_open_wait blocks until the background part is in place (0 at once if there is none); its failure is reported there
+ * or by the next submit.  Replaces nothing in the reference: `groot align` rebuilds its LSH forests before the first read
+ * (cmd/align.go:93-111). */
+#define GROOT_OPEN_BACKGROUND 1u
+int groot_hip_open_flags(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p, uint32_t flags);
+int groot_hip_open_wait(groot_ctx *ctx);
 void groot_hip_close(groot_ctx *ctx);
 
 /* What groot_hip_open built besides the uploaded index (diagnostic; times in ms, host wall clock).  The memo: every

@@ -152,3 +152,26 @@ def test_memo_switched_off_by_the_caller_or_by_its_budget(argannot_index, monkey
     al = device.Aligner(argannot_index, max_batch_reads=8192, max_read_len=128)
     assert al.open_stats()["memo_strings"] > 1_000_000
     al.close()
+
+
+def test_background_open(argannot_index, monkeypatch):
+    """groot_hip_open_flags(GROOT_OPEN_BACKGROUND): the ctx takes batches while its prefix tables and signature index are still being
+    built (full-width kernel, no verdicts), then with them -- every batch equals the oracle, and the call counts add up across the switch"""
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+        monkeypatch.delenv(v, raising=False)
+    index = argannot_index
+    al = device.Aligner(index, max_batch_reads=8192, max_read_len=128, memo_budget_mb=device.MEMO_OFF, background=True)
+    att = np.zeros((0, index.view.n_windows), dtype=np.uint32)
+    seq, off = perfect_batch(index, 5000, 11)
+    c0, att = check_batch(al, index, seq, off, att)                    # (most likely before the tables are there)
+    seq2, off2 = mixed_batch(index, 6000, 5)
+    c1, att = check_batch(al, index, seq2, off2, att)
+    al.open_wait()
+    c2, att = check_batch(al, index, seq, off, att)                    # ... and certainly with them: the signature kernel decides most reads
+    assert c2["full_sketch_reads"] < 0.2 * 5000 and c2["mapped"] == c0["mapped"] and c2["alignments"] == c0["alignments"]
+    c3, att = check_batch(al, index, seq2, off2, att)
+    assert c3["alignments"] == c1["alignments"]
+    al.close()
+    # a ctx that is closed while its background part is still running
+    al = device.Aligner(index, max_batch_reads=4096, max_read_len=128, memo_budget_mb=device.MEMO_OFF, background=True)
+    al.close()
