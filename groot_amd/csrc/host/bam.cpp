@@ -10,6 +10,9 @@
 #include "bgzf_struct.hpp"
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <chrono>
 #include <cstring>
 #include <ctime>
@@ -30,8 +33,79 @@ struct groot_bam {
     uint32_t n_ref = 0;
     unsigned threads = 1;         // BGZF workers for large groot_bam_write calls (bam.NewWriter's write concurrency)
     int level = Z_DEFAULT_COMPRESSION;   // biogo's bgzf.NewWriter default = gzip.DefaultCompression
-    uint64_t bytes_out = 0;       // compressed bytes written so far
+    uint64_t bytes_out = 0;       // compressed bytes written so far (handed to the file or to the writer thread)
+    // The compressed chunks of a batch (groot_bam_write_travs / _batch) are written by a thread of their own, in order, while the
+    // workers already build the next batch's records: the gathered writes were 9 of the 31 ms a batch of 4.5 M records kept the
+    // collector busy.  Everything else that touches the file waits for that thread to be through (io_drain).
+    std::thread io;
+    std::mutex io_mu;
+    std::condition_variable io_cv;
+    std::deque<std::vector<std::vector<uint8_t>>> io_q;
+    bool io_busy = false, io_stop = false;
+    int io_err = 0;
 };
+
+// the writer thread: batches of chunks in the order they were queued, gathered writes straight from the workers' buffers
+static void io_loop(groot_bam *b)
+{
+    const int fd = fileno(b->f);
+    std::vector<struct iovec> iov;
+    for (;;) {
+        std::vector<std::vector<uint8_t>> outs;
+        {
+            std::unique_lock<std::mutex> lk(b->io_mu);
+            b->io_cv.wait(lk, [&] { return b->io_stop || !b->io_q.empty(); });
+            if (b->io_q.empty()) return;
+            outs = std::move(b->io_q.front());
+            b->io_q.pop_front();
+            b->io_busy = true;
+        }
+        b->io_cv.notify_all();
+        int err = 0;
+        for (size_t c = 0; c < outs.size() && !err;) {
+            iov.clear();
+            for (; c < outs.size() && iov.size() < 512; c++)
+                if (!outs[c].empty()) iov.push_back({outs[c].data(), outs[c].size()});
+            size_t first = 0;
+            while (first < iov.size()) {
+                const ssize_t w = writev(fd, iov.data() + first, (int)(iov.size() - first));
+                if (w < 0) { if (errno == EINTR) continue; err = GROOT_E_IO; break; }
+                size_t left = (size_t)w;
+                while (first < iov.size() && left >= iov[first].iov_len) { left -= iov[first].iov_len; first++; }
+                if (first < iov.size() && left) { iov[first].iov_base = (char *)iov[first].iov_base + left; iov[first].iov_len -= left; }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(b->io_mu);
+            b->io_busy = false;
+            if (err && !b->io_err) b->io_err = err;
+        }
+        b->io_cv.notify_all();
+    }
+}
+
+// everything queued is in the file (or has failed)
+static int io_drain(groot_bam *b)
+{
+    if (!b->io.joinable()) return GROOT_OK;
+    std::unique_lock<std::mutex> lk(b->io_mu);
+    b->io_cv.wait(lk, [&] { return b->io_q.empty() && !b->io_busy; });
+    return b->io_err ? set_error(b->io_err, "BAM write failed") : GROOT_OK;
+}
+
+static int io_push(groot_bam *b, std::vector<std::vector<uint8_t>> &&outs)
+{
+    if (fflush(b->f) != 0) return set_error(GROOT_E_IO, "BAM write failed");     // (what stdio still holds goes first)
+    if (!b->io.joinable()) b->io = std::thread(io_loop, b);
+    {
+        std::unique_lock<std::mutex> lk(b->io_mu);
+        b->io_cv.wait(lk, [&] { return b->io_q.size() < 2; });               // (at most two batches of chunks waiting)
+        if (b->io_err) return set_error(b->io_err, "BAM write failed");
+        b->io_q.push_back(std::move(outs));
+    }
+    b->io_cv.notify_all();
+    return GROOT_OK;
+}
 
 static const size_t kBgzfBlock = 0xff00;   // max uncompressed payload per block
 static const int kBamStructural = -2;      // groot_bam_set_level: members written from the records' structure (bgzf_struct.hpp)
@@ -68,6 +142,7 @@ static int flush_block(groot_bam *b, const uint8_t *data, size_t n)
 {
     const long total = compress_block(data, n, b->out, b->level);
     if (total < 0) return set_error((int)total, "BGZF compression failed");
+    if (int rc = io_drain(b)) return rc;
     if (fwrite(b->out.data(), 1, (size_t)total, b->f) != (size_t)total) return set_error(GROOT_E_IO, "BAM write failed");
     b->bytes_out += (uint64_t)total;
     return GROOT_OK;
@@ -267,6 +342,7 @@ int groot_bam_write(groot_bam *b, const groot_aln_record *recs, uint64_t n)
         for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
         work();
         for (auto &t : th) t.join();
+        if (int rc = io_drain(b)) return rc;      // (this path writes through stdio: the writer thread has to be through first)
         for (size_t c = 0; c < n_chunks; c++) {
             if (sizes[c] <= -1000) {             // oversized single record: serial path keeps the stream valid
                 std::vector<uint8_t> raw;
@@ -479,25 +555,11 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
         if (errs[c]) return set_error(errs[c], "could not build the BAM records of traversal chunk %zu", c);
         total += nrec[c];
     }
-    // the compressed chunks go out in order with gathered writes straight from the workers' buffers (no stdio copy)
-    if (fflush(b->f) != 0) return set_error(GROOT_E_IO, "BAM write failed");
-    const int fd = fileno(b->f);
-    std::vector<struct iovec> iov;
-    for (size_t c = 0; c < n_chunks;) {
-        iov.clear();
-        size_t bytes = 0;
-        for (; c < n_chunks && iov.size() < 512; c++)
-            if (!outs[c].empty()) { iov.push_back({outs[c].data(), outs[c].size()}); bytes += outs[c].size(); }
-        size_t first = 0;
-        while (first < iov.size()) {
-            const ssize_t w = writev(fd, iov.data() + first, (int)(iov.size() - first));
-            if (w < 0) { if (errno == EINTR) continue; return set_error(GROOT_E_IO, "BAM write failed"); }
-            size_t left = (size_t)w;
-            while (first < iov.size() && left >= iov[first].iov_len) { left -= iov[first].iov_len; first++; }
-            if (first < iov.size() && left) { iov[first].iov_base = (char *)iov[first].iov_base + left; iov[first].iov_len -= left; }
-        }
-        b->bytes_out += bytes;
-    }
+    // the compressed chunks go out in order with gathered writes straight from the workers' buffers (no stdio copy), on the writer thread
+    uint64_t bytes = 0;
+    for (auto &o : outs) bytes += o.size();
+    if (int rc = io_push(b, std::move(outs))) return rc;
+    b->bytes_out += bytes;
     if (bam_stats)
         fprintf(stderr, "[groot bam] %llu records: threads %u, parallel part %.1f ms (summed over threads: records %.1f, format %.1f, encode %.1f ms), write %.1f ms\n",
                 (unsigned long long)total, nt, (t_par - t_begin) / 1e6, ns_build.load() / 1e6, ns_format.load() / 1e6, ns_encode.load() / 1e6, (now_ns() - t_par) / 1e6);
@@ -555,8 +617,13 @@ uint64_t groot_bam_bytes_written(const groot_bam *b) { return b ? b->bytes_out :
 int groot_bam_close(groot_bam *b)
 {
     if (!b) return GROOT_OK;
-    int rc = GROOT_OK;
-    if (!b->block.empty()) rc = flush_block(b, b->block.data(), b->block.size());
+    int rc = io_drain(b);
+    if (!rc && !b->block.empty()) rc = flush_block(b, b->block.data(), b->block.size());
+    if (b->io.joinable()) {
+        { std::lock_guard<std::mutex> lk(b->io_mu); b->io_stop = true; }
+        b->io_cv.notify_all();
+        b->io.join();
+    }
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!rc && fwrite(eof, 1, 28, b->f) != 28) rc = set_error(GROOT_E_IO, "BAM write failed");
     if (b->own) { if (fclose(b->f) != 0 && !rc) rc = set_error(GROOT_E_IO, "BAM close failed"); }
