@@ -239,7 +239,26 @@ struct Nt16 {
 };
 
 // appends the BAM encoding of recs[i0, i1) to buf
-static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i1, std::vector<uint8_t> &buf, std::vector<uint32_t> *starts = nullptr)
+} // extern "C"
+
+// a byte buffer that grows without touching what it does not hold yet (std::vector::resize value-initialises: 230 bytes zeroed only to be
+// overwritten, per record): the interface format_records needs
+struct RawBuf {
+    std::vector<uint8_t> v;
+    size_t n = 0;
+    size_t size() const { return n; }
+    uint8_t *data() { return v.data(); }
+    const uint8_t *data() const { return v.data(); }
+    void clear() { n = 0; }
+    void resize(size_t m)
+    {
+        if (m > v.size()) v.resize(std::max<size_t>(m + m / 2, 1u << 16));
+        n = m;
+    }
+};
+
+template <class Buf>
+static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i1, Buf &buf, std::vector<uint32_t> *starts = nullptr)
 {
     static const Nt16 nt;
     const uint8_t *nt16 = nt.t;
@@ -289,6 +308,8 @@ static void format_records(const groot_aln_record *recs, uint64_t i0, uint64_t i
         else memset(p, 0xff, r.seq_len);
     }
 }
+
+extern "C" {
 
 int groot_bam_set_threads(groot_bam *b, uint32_t n_threads)
 {
@@ -401,7 +422,8 @@ static int write_travs_impl(groot_bam *b, const groot_index_view *ix, ReadFn rea
     const uint64_t t_begin = now_ns();
     auto work = [&]() {
         uint64_t tb = 0, tf = 0, te = 0;
-        std::vector<uint8_t> raw, blk, rcs, rcq, padq;
+        RawBuf raw;
+        std::vector<uint8_t> blk, rcs, rcq, padq;
         std::vector<uint32_t> starts, rel;                       // record starts in raw (structural BGZF only)
         std::vector<uint8_t> follow;                             // ... and: the record is a patched copy of the one before it (bgzf_struct.hpp)
         std::vector<groot_aln_record> recs;

@@ -149,6 +149,17 @@ struct PackLut {
     }
 };
 const PackLut g_lut;
+struct PackLut2 {
+    uint8_t t[65536];    // two bases at once (little endian: first base in the low byte): code of the first | code of the second << 2, bit 7 set if either is not A C G T
+    PackLut2()
+    {
+        for (int c = 0; c < 65536; c++) {
+            const int a = c & 0xFF, b = c >> 8;
+            t[c] = (uint8_t)(g_lut.t[a] & 3) | (uint8_t)((g_lut.t[b] & 3) << 2) | (uint8_t)((g_lut.t[a] | g_lut.t[b]) & 0x80);
+        }
+    }
+};
+const PackLut2 g_lut2;
 
 } // namespace
 
@@ -371,11 +382,30 @@ static int parse_block(groot_reads *r, std::unique_ptr<RawBlock> blk, bool last_
                 b->seq_pos[j] = p; b->seq_len[j] = (uint16_t)l;
                 lmx = std::max(lmx, l);
                 const uint8_t *s = reinterpret_cast<const uint8_t *>(text + p);
-                for (uint32_t x = 0; x < l; x++, bpos++) {
-                    const uint8_t c = lut[s[x]];
-                    if (c & 0x80) exc[t].emplace_back(bpos, s[x]);
-                    acc |= (uint8_t)((c & 3) << (2 * (bpos & 3)));
-                    if ((bpos & 3) == 3) flush(bpos / 4);
+                uint32_t x = 0;
+                const uint8_t *lut2 = g_lut2.t;
+                while (x < l) {
+                    // whole packed bytes away from the bytes this task shares with its neighbours: four bases per step, two table
+                    // look-ups (reads of a multiple of four bases -- the usual 100 or 150 -- go this way from their first base to their last)
+                    if ((bpos & 3) == 0) {
+                        while (x + 4 <= l && bpos / 4 > first_byte && bpos / 4 < last_byte) {
+                            uint16_t h0, h1;
+                            memcpy(&h0, s + x, 2); memcpy(&h1, s + x + 2, 2);
+                            const uint8_t c0 = lut2[h0], c1 = lut2[h1];
+                            if ((c0 | c1) & 0x80) break;              // a byte other than A C G T: base by base, with the exception list
+                            out[bpos / 4] = (uint8_t)((c0 & 15) | ((c1 & 15) << 4));
+                            x += 4; bpos += 4;
+                        }
+                        if (x >= l) break;
+                    }
+                    // base by base up to the next byte boundary
+                    do {
+                        const uint8_t c = lut[s[x]];
+                        if (c & 0x80) exc[t].emplace_back(bpos, s[x]);
+                        acc |= (uint8_t)((c & 3) << (2 * (bpos & 3)));
+                        if ((bpos & 3) == 3) flush(bpos / 4);
+                        x++; bpos++;
+                    } while (x < l && (bpos & 3));
                 }
             }
             if (bpos & 3 && bpos > tb[t]) flush((bpos - 1) / 4);
