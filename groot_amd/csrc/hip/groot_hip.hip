@@ -665,7 +665,8 @@ static int launch_order_stage(groot_ctx *c, Slot *s, bool update_weights)
     const uint32_t n = s->n_reads;
     size_t tmp_bytes = 0;
     // split reads: their items' counts become the read's count, every item learns where its records go in the read's run
-    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(256), dim3(kBlock), 0, c->astream, w->split_list.p, w->vcount.p, w->vitem.p, w->trav_cnt.p, n, s->d_ctr.p);
+    if (c->vcap) hipLaunchKernelGGL(split_fix_kernel, dim3(256), dim3(kBlock), 0, c->astream, w->split_list.p, w->vcount.p, w->vitem.p, w->trav_cnt.p, n, s->d_ctr.p,
+                                    w->trav_first.p, w->mask_first.p, c->pw, s->first_read_id);
     HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp_bytes, w->trav_cnt.p, c->trav_off.p, 0u, n, rocprim::plus<uint32_t>(), c->astream));
     if (tmp_bytes > c->scan_tmp.n) {
         HIP_TRY(c, hipStreamSynchronize(c->astream));

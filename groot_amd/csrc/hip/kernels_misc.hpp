@@ -293,18 +293,31 @@ __global__ __launch_bounds__(kBlock) void sort_seed_lists_kernel(SplitArgs a)
 // after the align stage: the records of a split read's items follow each other in the read's (read, ord) run -- every item learns
 // how many records the read's earlier items made, the read's count becomes the sum
 __global__ __launch_bounds__(kBlock) void split_fix_kernel(const uint4 *__restrict__ split_list, const uint32_t *__restrict__ vcount, uint4 *__restrict__ vitem,
-                                                           uint32_t *__restrict__ trav_cnt, uint32_t n_reads, DeviceCounters *ctr)
+                                                           uint32_t *__restrict__ trav_cnt, uint32_t n_reads, DeviceCounters *ctr, groot_trav *__restrict__ first,
+                                                           uint64_t *__restrict__ mask_first, uint32_t pw, uint32_t first_read_id)
 {
     const uint32_t ns = min(vcount[1], kLongListCap);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
         const uint4 sl = split_list[i];
-        uint32_t base = trav_cnt[sl.x];
+        const uint32_t own = trav_cnt[sl.x];
+        uint32_t base = own, first_with = kEmpty;
         for (uint32_t j = sl.y; j < sl.y + sl.z; j++) {
+            const uint32_t n = trav_cnt[n_reads + j];
             vitem[j].w = base;
-            base += trav_cnt[n_reads + j];
+            if (n && first_with == kEmpty) first_with = j;
+            base += n;
         }
         if (base > 0xFFFFu) atomicOr(&ctr->flags, kFlagOrdOverflow);
         trav_cnt[sl.x] = base;
+        // order_first_kernel copies slot r of every read with records: when the read's own item made none, that slot must hold the
+        // read's first record -- the first record of its first item that has any -- and not whatever an earlier batch left there
+        if (!own && first_with != kEmpty) {
+            groot_trav t = first[n_reads + first_with];
+            t.read_id = first_read_id + sl.x;
+            t.ord = 0;
+            first[sl.x] = t;
+            for (uint32_t w = 0; w < pw; w++) mask_first[(size_t)sl.x * pw + w] = mask_first[(size_t)(n_reads + first_with) * pw + w];
+        }
     }
 }
 
