@@ -394,7 +394,7 @@ def host_fed(index, d_seq, R, steps, depth=4):
     lens = np.full(R, READ_LEN, dtype=np.uint16)
     al = device.Aligner(index, device=torch.cuda.current_device(), max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
                         pipeline_depth=depth)
-    al.set_profiling(True)
+    al.set_profiling(os.environ.get("GROOT_BENCH_HF_EVENTS", "1") != "0")
     stage = {}
     bufs = [al.acquire() for _ in range(depth)]
     for b in bufs:
@@ -414,11 +414,16 @@ def host_fed(index, d_seq, R, steps, depth=4):
     t0 = time.perf_counter()
     done = 0
     trav_bytes = 0
+    host_s = {"submit": 0.0, "collect": 0.0}         # where the calling thread spends the batch period
     for i in range(steps):
         b = al.acquire()                             # a free slot: its staging still holds the packed batch
+        ta = time.perf_counter()
         al.submit_acquired(b["ticket"], R, len(exc_pos))
+        tb = time.perf_counter()
+        host_s["submit"] += tb - ta
         if al.in_flight()[0] == depth:
             r = al.collect(copy=False)
+            host_s["collect"] += time.perf_counter() - tb
             trav_bytes += r["n_travs"] * 12 + r["n_mask_bytes"] + (r["n_travs"] // 256 + 1) * 4   # (12-byte records on the wire)
             for k, v in r["ms"].items():
                 stage[k] = stage.get(k, 0.0) + v
@@ -436,6 +441,7 @@ def host_fed(index, d_seq, R, steps, depth=4):
            "h2d_bytes_per_read": (len(packed) + 9 * len(exc_pos)) / R,   # (all reads are 100 bp: the length array stays at home)
            "d2h_bytes_per_read": trav_bytes / (steps * R),
            "stage_ms_per_batch": {k: v / steps for k, v in stage.items()},
+           "caller_ms_per_batch": {k: v / steps * 1e3 for k, v in host_s.items()},
            "what": "one ctx, one index replica: pinned staging -> H2D (2-bit bases + u16 lengths) -> kernels -> D2H of the traversal "
                    "records (12 bytes each, expanded to groot_trav by collect) into pinned host memory; first submit -> last collect"}
     # the plain-ASCII entry point with pageable caller memory (what a cgo caller handing over Go slices gets)

@@ -108,8 +108,9 @@ struct Slot {
     PinBuf<uint64_t> h_off, h_exc_pos;
     PinBuf<uint8_t> h_exc_byte;
     // HBM inputs
-    DevBuf<uint32_t> d_packed;
     DevBuf<uint16_t> d_len;
+    DevBuf<uint32_t> d_packed;
+    bool exc_at_home = false;                      // the batch's exception list is read from the pinned staging by the kernel that applies it
     DevBuf<uint8_t> d_seq, d_exc_byte;
     DevBuf<uint64_t> d_off, d_exc_pos;
     // outputs
@@ -160,6 +161,7 @@ struct groot_ctx {
     groot_params prm{};
     Knobs kn;
     uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
+    hipEvent_t h2d_last = nullptr;         // the copy-in of the newest host-fed batch (its slot's event)
     hipStream_t own_stream = nullptr, stream = nullptr, astream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;   // stream: seed stage (the caller's, if given); astream: align + order stage
     bool profiling = false;
 
@@ -742,6 +744,8 @@ struct LenToU64 {
     __host__ __device__ uint64_t operator()(uint16_t v) const { return (uint64_t)v; }
 };
 
+constexpr uint64_t kExcAtHomeBytes = 2u << 20;
+
 static void par_copy(void *dst, const void *src, size_t bytes)
 {
     const size_t kMin = 8u << 20;
@@ -827,6 +831,13 @@ static int enqueue(groot_ctx *c, Slot *s)
     }
     if (s->input != Slot::IN_DEVICE) {
         hipStream_t h = c->h2d_stream;
+        // One copy-in at a time: the caller waits here for the copy-in of the batch before.  (Every copy queued on a stream is given an SDMA
+        // engine when it is submitted and waits THERE for the copy before it; the copy-out of a finished batch then lands behind such a
+        // waiting copy-in and takes 11-15 ms instead of 3.5.  A host-fed stream ran at 1 950 Mreads/s with three batches in flight, 1 600
+        // with four, 1 250 with five; with this wait it runs at 1 900-1 950 whatever the depth.  Reading the staging from a kernel instead
+        // of the copy engine was tried as well: its 64-byte read requests crowd the link's upstream direction and the copy-out halves.)
+        if (c->h2d_last) HIP_TRY(c, hipEventSynchronize(c->h2d_last));
+        c->h2d_last = s->ev_h2d;
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev_h2d0, h));
         if (s->input == Slot::IN_ASCII) {
             HIP_TRY(c, hipMemcpyAsync(s->d_seq.p, s->h_bases.p, s->n_bases, hipMemcpyHostToDevice, h));
@@ -837,7 +848,11 @@ static int enqueue(groot_ctx *c, Slot *s)
                 HIP_TRY(c, hipMemcpyAsync(s->d_off.p, s->h_off.p, ((size_t)s->n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h));
             else if (!s->uniform_len)
                 HIP_TRY(c, hipMemcpyAsync(s->d_len.p, s->h_len.p, (size_t)s->n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, h));
-            if (s->n_exc) {
+            // A short exception list stays at home: patch_reads_kernel reads it through the pinned mapping.  (Copies of that size are done by
+            // blit kernels, and the two of them kept the copy-in stream busy for 0.5 ms between one batch's bases and the next batch's: a
+            // tenth of the batch period of a host-fed stream.)
+            s->exc_at_home = s->n_exc * 9 <= kExcAtHomeBytes;
+            if (s->n_exc && !s->exc_at_home) {
                 HIP_TRY(c, hipMemcpyAsync(s->d_exc_pos.p, s->h_exc_pos.p, s->n_exc * sizeof(uint64_t), hipMemcpyHostToDevice, h));
                 HIP_TRY(c, hipMemcpyAsync(s->d_exc_byte.p, s->h_exc_byte.p, s->n_exc, hipMemcpyHostToDevice, h));
             }
@@ -853,7 +868,7 @@ static int enqueue(groot_ctx *c, Slot *s)
                                n_words, reinterpret_cast<uint4 *>(s->d_seq.p));
         if (s->n_exc)
             hipLaunchKernelGGL(patch_reads_kernel, dim3((unsigned)((s->n_exc + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                               s->d_exc_pos.p, s->d_exc_byte.p, s->n_exc, s->d_seq.p);
+                               s->exc_at_home ? s->h_exc_pos.p : s->d_exc_pos.p, s->exc_at_home ? s->h_exc_byte.p : s->d_exc_byte.p, s->n_exc, s->d_seq.p);
         HIP_TRY(c, hipGetLastError());
         if (s->input == Slot::IN_PACKED16 && s->uniform_len) {
             hipLaunchKernelGGL(uniform_offsets_kernel, dim3((s->n_reads + kBlock) / kBlock), dim3(kBlock), 0, c->stream, s->d_off.p, s->n_reads,
@@ -2352,11 +2367,34 @@ static int check_offsets(groot_ctx *c, const uint64_t *seq_off, uint32_t n_reads
     return GROOT_OK;
 }
 
+// (ten million lengths are 4.6 ms of one core: the batch period of a host-fed stream is 4.9 ms -- the scan is dealt over the granted cores)
 static int check_lengths(groot_ctx *c, const uint16_t *len, uint32_t n_reads, uint64_t *total, uint32_t *max_len, uint32_t *min_len)
 {
+    struct Part { uint64_t sum = 0; uint32_t longest = 0, shortest = 0xFFFFu; char pad[48]; };
+    auto scan = [len](uint32_t lo, uint32_t hi, Part *p) {
+        uint64_t sum = 0;
+        uint32_t longest = 0, shortest = 0xFFFFu;
+        for (uint32_t i0 = lo; i0 < hi; i0 += 4096) {            // (32-bit partial sums: the inner loop vectorises)
+            const uint32_t i1 = std::min(hi, i0 + 4096);
+            uint32_t part = 0;
+            for (uint32_t i = i0; i < i1; i++) { const uint32_t v = len[i]; part += v; longest = v > longest ? v : longest; shortest = v < shortest ? v : shortest; }
+            sum += part;
+        }
+        p->sum = sum; p->longest = longest; p->shortest = shortest;
+    };
+    const unsigned nt = std::max(1u, (unsigned)std::min<size_t>(std::min(16u, granted_cpus()), n_reads >> 19));
+    std::vector<Part> parts(nt);
+    if (nt == 1) scan(0, n_reads, &parts[0]);
+    else {
+        std::vector<std::thread> th;
+        const uint32_t per = (n_reads + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(scan, std::min(n_reads, t * per), std::min(n_reads, (t + 1) * per), &parts[t]);
+        for (auto &x : th) x.join();
+    }
     uint64_t sum = 0;
     uint32_t longest = 0, shortest = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < n_reads; i++) { sum += len[i]; longest = std::max<uint32_t>(longest, len[i]); shortest = std::min<uint32_t>(shortest, len[i]); }
+    for (const Part &p : parts) { sum += p.sum; longest = std::max(longest, p.longest); shortest = std::min(shortest, p.shortest); }
+    if (!n_reads) shortest = 0xFFFFFFFFu;
     *min_len = shortest;
     if (sum > c->prm.max_batch_bases)
         return fail(c, GROOT_E_NOSPACE, "batch of %llu bases exceeds max_batch_bases=%llu", (unsigned long long)sum, (unsigned long long)c->prm.max_batch_bases);

@@ -25,4 +25,5 @@ for c0 in range(0, R, 1_000_000):
 d_seq = torch.cat(parts)
 hf, _ = bench.host_fed(index, d_seq, R, steps, depth)
 print(json.dumps({"depth": depth, "value": hf["value"], "ms_per_batch": hf["ms_per_batch"],
-                  "stage": {k: round(v, 2) for k, v in hf["stage_ms_per_batch"].items()}}))
+                  "stage": {k: round(v, 2) for k, v in hf["stage_ms_per_batch"].items()},
+                  "caller": {k: round(v, 2) for k, v in hf["caller_ms_per_batch"].items()}}))
