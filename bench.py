@@ -247,7 +247,7 @@ def resident_rate(al, d_seq_ptr, d_off_ptr, R, max_len, steps, warmup, mixed=Fal
         if i < steps:
             al.submit_device(d_seq_ptr, d_off_ptr, R, first_read_id=0, max_len=max_len, mixed=mixed)
             pending += 1
-        if pending == 2 or (i == steps and pending):
+        if pending == int(os.environ.get("GROOT_PROBE_INFLIGHT", "2")) or (i == steps and pending):   # (1: a batch at a time -- every stage alone on the chip, for tools/)
             counts = al.wait()
             pending -= 1
             for k, v in al.stage_ms().items():

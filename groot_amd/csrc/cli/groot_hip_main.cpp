@@ -363,6 +363,53 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     logf("\tminimum k-mer coverage: %.0f", a.min_kmer_cov);
     logf("\tprocessors: %d", a.proc);
     for (auto &f : a.fastq) logf("\tinput file: %s", f.c_str());
+    // ---- the FASTQ parser starts NOW, before the index is read and the GPU context opened: inflating and packing the first batches
+    // takes as long as those do (a gzip FASTQ inflates on one thread, as bufio over gzip.Reader does in the reference), and neither
+    // needs the other; up to kParsedAhead batches wait for the mappers ----
+    constexpr size_t kParsedAhead = 8;
+    const uint32_t cores = a.proc > 0 ? (uint32_t)a.proc : 0;
+    const uint64_t max_batch_bases = (uint64_t)a.batch * std::min<uint32_t>(a.max_read_len, 512);
+    std::vector<const char *> files;
+    for (auto &f : a.fastq) files.push_back(f.c_str());
+    groot_reads *reads = nullptr;
+    if (groot_reads_open(files.empty() ? nullptr : files.data(), (uint32_t)files.size(), cores, a.block_bytes, a.batch, max_batch_bases, &reads))
+        die("%s", groot_host_last_error());
+    std::vector<std::unique_ptr<Gpu>> gpus;
+    std::atomic<bool> gpus_ready{false};
+    BoundedQueue<WorkItem> parsed(kParsedAhead);
+    BoundedQueue<WorkItem> mapped(4);                 // (its real capacity is set once the contexts are known, before anyone uses it)
+    std::mutex fatal_mu;
+    std::string fatal;
+    std::atomic<bool> failed{false};
+    auto fail_with = [&](const std::string &msg) {
+        std::lock_guard<std::mutex> lk(fatal_mu);
+        if (fatal.empty()) fatal = msg;
+        failed = true;
+        parsed.close(); mapped.close();
+        if (gpus_ready)
+            for (auto &g : gpus) { std::lock_guard<std::mutex> l2(g->mu); g->cv.notify_all(); }
+    };
+
+    std::atomic<uint64_t> length_total{0};
+    double parse_s = 0, bam_s = 0;                    // busy time of the producer / the writer
+    std::atomic<uint64_t> collect_wait_us{0}, n_batches{0};
+    std::thread producer([&]() {
+        uint64_t seq = 0;
+        for (;;) {
+            if (failed) break;
+            WorkItem w;
+            auto tp = std::chrono::steady_clock::now();
+            const int prc = groot_reads_next(reads, &w.batch);
+            parse_s += seconds_since(tp);
+            if (prc) { fail_with(groot_host_last_error()); break; }
+            if (!w.batch) break;
+            groot_reads_batch_view(w.batch, &w.view);
+            length_total += w.view.n_bases;
+            w.seq = seq++;
+            parsed.push(std::move(w));
+        }
+        parsed.close();
+    });
     logf("loading the index information...");
     // (the HIP runtime starts up on a thread of its own while the index is read: a few tenths of a second each)
     int n_dev = 0, dev_rc = 0;
@@ -415,7 +462,6 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         prm.memo_budget_mb = memo_budget;
         return prm;
     };
-    std::vector<std::unique_ptr<Gpu>> gpus;
     for (int d : devices) {
         std::unique_ptr<Gpu> g(new Gpu());
         g->device = d; g->max_read_len = a.max_read_len;
@@ -432,7 +478,6 @@ int run_align(const Args &a)   // cmd/align.go:54-163
         for (auto &t : th) t.join();
         for (auto &e : errs) if (!e.empty()) die("%s", e.c_str());
     }
-    const uint64_t max_batch_bases = (uint64_t)a.batch * std::min<uint32_t>(a.max_read_len, 512);
     logf("\tcontainment threshold: %.2f", a.threshold);
     if (a.no_align) logf("\tprevent exact alignments and using approximated mapping only");
     logf("initialising alignment pipeline...");
@@ -444,50 +489,12 @@ int run_align(const Args &a)   // cmd/align.go:54-163
 
     groot_bam *bam = nullptr;
     if (!a.no_align && groot_bam_open(a.bam_out.empty() ? nullptr : a.bam_out.c_str(), &v, nullptr, &bam)) die("%s", groot_host_last_error());
-    const uint32_t cores = a.proc > 0 ? (uint32_t)a.proc : 0;
     if (bam) { groot_bam_set_threads(bam, cores); if (groot_bam_set_level(bam, a.bam_level)) die("%s", groot_host_last_error()); }
 
-    std::vector<const char *> files;
-    for (auto &f : a.fastq) files.push_back(f.c_str());
-    groot_reads *reads = nullptr;
-    if (groot_reads_open(files.empty() ? nullptr : files.data(), (uint32_t)files.size(), cores, a.block_bytes, a.batch, max_batch_bases, &reads))
-        die("%s", groot_host_last_error());
     logf("now streaming reads...");
     auto t_stream = std::chrono::steady_clock::now();
-
-    BoundedQueue<WorkItem> parsed(gpus.size() + 2);
-    BoundedQueue<WorkItem> mapped(gpus.size() * depth + 2);
-    std::mutex fatal_mu;
-    std::string fatal;
-    std::atomic<bool> failed{false};
-    auto fail_with = [&](const std::string &msg) {
-        std::lock_guard<std::mutex> lk(fatal_mu);
-        if (fatal.empty()) fatal = msg;
-        failed = true;
-        parsed.close(); mapped.close();
-        for (auto &g : gpus) { std::lock_guard<std::mutex> l2(g->mu); g->cv.notify_all(); }
-    };
-
-    std::atomic<uint64_t> length_total{0};
-    double parse_s = 0, bam_s = 0;                    // busy time of the producer / the writer
-    std::atomic<uint64_t> collect_wait_us{0}, n_batches{0};
-    std::thread producer([&]() {
-        uint64_t seq = 0;
-        for (;;) {
-            if (failed) break;
-            WorkItem w;
-            auto tp = std::chrono::steady_clock::now();
-            const int prc = groot_reads_next(reads, &w.batch);
-            parse_s += seconds_since(tp);
-            if (prc) { fail_with(groot_host_last_error()); break; }
-            if (!w.batch) break;
-            groot_reads_batch_view(w.batch, &w.view);
-            length_total += w.view.n_bases;
-            w.seq = seq++;
-            parsed.push(std::move(w));
-        }
-        parsed.close();
-    });
+    mapped.cap = gpus.size() * depth + 2;
+    gpus_ready = true;
 
     std::atomic<int> mappers_left{(int)gpus.size()};
     std::vector<std::thread> mappers;

@@ -635,7 +635,9 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     uint32_t blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, c->align_threads / kBlock);
     // (few reads left for the walk -- the latest batch says so: half the persistent grid starts and drains 0.05 ms sooner and the
     // slowest read, not the number of wavefronts, sets the duration anyway)
-    if (c->dfs_frac < kSparseBelow) blocks = std::max(1u, blocks / 2);
+    // (... unless there are reads enough to give every wavefront of the whole grid a round of 16: reads that fail -- reads with an error that
+    // kept their minimisers -- do not march in step, and more wavefronts with fewer of them each end sooner)
+    if (c->dfs_frac < kSparseBelow && c->dfs_frac * (double)s->n_reads < 16.0 * (double)(blocks * (kBlock / 64))) blocks = std::max(1u, blocks / 2);
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB
@@ -1031,7 +1033,24 @@ static int finish_counters(groot_ctx *c, Slot *s)
             s->status_msg = buf;
         }
     }
-#ifdef GROOT_WORK_COUNTERS
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+    if (h.dbg[4]) {
+        fprintf(stderr, "[groot timeline] wavefronts with work %llu, rounds %llu, iterations: mean %.0f max %llu; wave duration: mean %.3f ms max %.3f ms\n", h.dbg[4], h.dbg[5],
+                (double)h.dbg[0] / (double)h.dbg[4], h.dbg[1], (double)h.dbg[2] / (double)h.dbg[4] / 1e5, (double)h.dbg[3] / 1e5);
+        for (unsigned long long i = 0; i < 14 && i < h.dbg[17]; i++)
+            fprintf(stderr, "[groot timeline] late read %llu%s: %llu windows, %llu graphs, %llu traversals, from %llu to %llu us, %llu wave iterations, %llu steps of its own\n", h.dbg[18 + 3 * i] & 0xFFFFFFFFull,
+                    (h.dbg[18 + 3 * i] >> 63) ? " (item)" : "", (h.dbg[18 + 3 * i] >> 32) & 0x7FFFFFFFull, h.dbg[20 + 3 * i] >> 56, (h.dbg[20 + 3 * i] >> 48) & 0xFFull, h.dbg[19 + 3 * i] & 0xFFFFFFFFull, h.dbg[19 + 3 * i] >> 32,
+                    h.dbg[20 + 3 * i] & 0xFFFFFFFFull, (h.dbg[20 + 3 * i] >> 32) & 0xFFFFull);
+        fprintf(stderr, "[groot timeline] late reads in all: %llu\n", h.dbg[17]);
+        fprintf(stderr, "[groot timeline] ms summed over wavefronts: all %.1f = cooperative scans %.1f (%llu services) + fork/join %.1f + FETCH %.1f (%llu steps) + SCAN %.1f (%llu) + DFS %.1f (%llu) + rest\n",
+                (double)h.dbg[2] / 1e5, (double)h.dbg[8] / 1e5, h.dbg[16], (double)h.dbg[9] / 1e5, (double)h.dbg[10] / 1e5, h.dbg[13], (double)h.dbg[11] / 1e5, h.dbg[14], (double)h.dbg[12] / 1e5, h.dbg[15]);
+        for (int hh = 0; hh < 2; hh++) {
+            fprintf(stderr, "[groot timeline] %s (buckets of 50 us):", hh ? "length of a wavefront's last round" : "wavefront ends after");
+            for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", h.dbg[64 + 64 * hh + b]);
+            fprintf(stderr, "\n");
+        }
+    }
+#elif defined(GROOT_WORK_COUNTERS)
     for (int e = 0; e < 32; e++)
         if (h.dbg[e]) fprintf(stderr, "[groot work] event %2d: wave iterations %llu lanes %llu\n", e, h.dbg[e], h.dbg[32 + e]);
     fprintf(stderr, "[groot work] longest round: %llu wave iterations\n", h.dbg[63]);

@@ -21,14 +21,27 @@ namespace groot {
 // lanes in different reads / levels / depths never serialise each other's loops and every executed
 // instruction runs at the best available lane fill.  A wavefront takes 64 consecutive reads of the processing order
 // at a time (they share a seed window, hence the graph nodes they walk) and asks for more when all lanes are done.
-enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE };
+enum : uint32_t { PH_FETCH, PH_SCAN, PH_DFS, PH_WAIT, PH_DONE, PH_FORK, PH_FORKWAIT, PH_JOIN };
+// A read whose window of a graph has failed through the whole hierarchy in both orientations and that brings more windows of that graph
+// asks the idle lanes of its wavefront (PH_FORK) to try those, a window each, as a dry run (PH_FORKWAIT while they do; they end in PH_JOIN)
+#ifndef GROOT_FORK_MIN
+#define GROOT_FORK_MIN 3
+#endif
+constexpr uint32_t kForkMin = GROOT_FORK_MIN;   // windows left in the read's list from which it asks
+constexpr uint32_t kClsHelper = 0x1000u;        // cls bit 12: the lane tries a window for another lane's read (no output, no counts)
 constexpr uint32_t kCoopMin = 6;       // contained nodes from which level 2 of AlignRead asks its wavefront for a cooperative scan
 constexpr uint32_t kCoopWant = 0xFFFFFFFEu;
 #ifndef GROOT_COOP_MAX_ASK
 #define GROOT_COOP_MAX_ASK 8
 #endif
 constexpr uint32_t kCoopMaxAsk = GROOT_COOP_MAX_ASK;     // lanes of a wavefront that may ask in the same iteration
-constexpr uint32_t kWaveChunk = 128;   // consecutive slots a wave takes before asking for more (multiple of 64)
+#ifndef GROOT_TL_LATE_US
+#define GROOT_TL_LATE_US 3000
+#endif
+#ifndef GROOT_WAVE_CHUNK
+#define GROOT_WAVE_CHUNK 128
+#endif
+constexpr uint32_t kWaveChunk = GROOT_WAVE_CHUNK;   // (rounds per trip to the cursor = kWaveChunk / 64; one when the reads do not march in step)   // consecutive slots a wave takes before asking for more (multiple of 64)
 
 // 0x80 in byte j iff byte j of x equals c, or is the 'N' wildcard
 __device__ __forceinline__ uint64_t match_or_n(uint64_t x, unsigned c)
@@ -82,6 +95,14 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     // the seed stage ran out of per-read slots (or the call-count table out of rows): the host grows them and re-runs the whole batch
     if (a.ctr->flags & (kFlagSeedOverflow | kFlagQOverflow)) return;
+#ifndef GROOT_ALIGN_PRIO
+#define GROOT_ALIGN_PRIO 3
+#endif
+    // The walk is a chain of dependent steps with a few hundred instructions between two trips to memory, and it runs beside the next
+    // batch's hashing kernels, which keep every SIMD's issue port busy: at equal priority each instruction of a walking wavefront waits its turn
+    // behind five hashing wavefronts (5-6 us per wave iteration measured with the timeline build).  Raised, the walking wavefronts -- mostly
+    // waiting for memory anyway -- go first when they can go at all.
+    __builtin_amdgcn_s_setprio(GROOT_ALIGN_PRIO);
     unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
 #ifdef GROOT_WORK_COUNTERS
     uint32_t ev = 0;                                       // events of this lane in the current wave iteration
@@ -110,7 +131,13 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     // Lanes per round.  A round lasts as long as its slowest read, so when there are fewer reads than 64 per resident wavefront
     // (most of the batch was answered from the outcome table: what is left are the hard reads) the rounds are made smaller
     // and spread over all wavefronts: the launch then ends with the slowest read instead of the slowest sum of rounds.
-    uint32_t U = 64;
+    // Reads that do not march in step (mixed read lengths: a.head_lanes != 0) get rounds of 32, one round per trip to the cursor: a round
+    // of 64 of them lasts as long as their steps laid end to end, and a wavefront that took 128 such slots just before the cursor ran dry
+    // was still walking at 5.9 ms when all others had ended by 2.5 (timeline build, 8 M reads of 75..150 bases: align stage 5.9 -> 3.4 ms)
+#ifndef GROOT_EXP_MIXED_U
+#define GROOT_EXP_MIXED_U 32
+#endif
+    uint32_t U = a.head_lanes ? (uint32_t)GROOT_EXP_MIXED_U : 64u;
     if (a.round_lanes) U = a.round_lanes;
     else
         while (U > 1u && n_todo < U * (gridDim.x * (uint32_t)(kBlock / 64))) U >>= 1;
@@ -126,13 +153,14 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     const uint32_t head_small = (head_slots + Uh - 1u) / Uh;
     uint32_t chunk_len = 0, chunk_base = 0;                // slots in the current chunk, its first slot (wave-uniform)
     bool head_done = head_small == 0;                      // wave-uniform
+    const uint32_t chunk_rounds = a.head_lanes ? 1u : kWaveChunk / 64u;
     auto take_chunk = [&]() {
         uint32_t c = 0, tail = 0;
         if ((threadIdx.x & 63) == 0) {
             if (!head_done) c = atomicAdd(a.ovf_cnt + kOvfShards, 1u);
             if (head_done || c >= head_small) {
                 tail = 1;
-                c = atomicAdd(a.ovf_cnt + kOvfShards + 1, kWaveChunk / 64u);
+                c = atomicAdd(a.ovf_cnt + kOvfShards + 1, chunk_rounds);
             }
         }
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
@@ -142,13 +170,19 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             // (saturating: past the end the base only has to be >= n_todo)
             const unsigned long long b = (unsigned long long)head_slots + (unsigned long long)c * U;
             chunk_base = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
-            chunk_len = (kWaveChunk / 64u) * U;
+            chunk_len = chunk_rounds * U;
         } else {
             chunk_base = c * Uh;
             chunk_len = min(Uh, head_slots - chunk_base);
         }
     };
     take_chunk();
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+    const unsigned long long tl_start = wall_clock64();    // timeline of the launch: when do the wavefronts end, and how long was their last round?
+    unsigned long long tl_round = tl_start, tl_coop = 0, tl_fork = 0, tl_read0 = 0;
+    uint32_t tl_it0 = 0, tl_st0 = 0;
+    uint32_t tl_rounds = 0, tl_ncoop = 0;
+#endif
     uint32_t chunk_pos = 0;                                // slots of the chunk already handed out (wave-uniform)
     uint32_t slot = 0, r = 0;
     // ---- read ----
@@ -165,7 +199,15 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     uint32_t w = 0, g = 0, seed = 0, seed_s0 = 0, seed_len = 0, off0 = 0, l1_hi = 0, cn_cur = 0, cn_begin = 0, cn_end = 0;
     uint32_t rc = 0, level = 1;
     uint32_t sc_node = 0, sc_s0 = 0, sc_len = 0, sc_pos = 0, sc_end = 0;   // range being scanned
-    uint32_t clip_lo = 0, eff = 0, tflags = 0;
+    // the view of the read a level works on follows from the level: 3 clips the first base, 4 the last (alignment.go:72-103)
+    auto clip_lo = [&]() -> uint32_t { return level == 3u ? 1u : 0u; };
+    auto eff = [&]() -> uint32_t { return len - (level >= 3u ? 1u : 0u); };
+    // upper bound of the read bases any branch of level 1's DFS from (seed, OffSet) has matched, per orientation: level 4 walks the same
+    // nodes from the same position with the last base clipped (alignment.go:87-103), so it can only succeed where level 1 got to len - 1
+    uint32_t reach = 0;
+    // fork / join: a helper keeps its owner's lane (bits 0-5), the phase it goes back to (bits 8-10) and its result (bits 12-13: 0 failed,
+    // 1 aligned, 2 the window belongs to another graph); an owner keeps 1 + the largest window of its list known to fail
+    uint32_t fk = 0;
     uint64_t pre8 = 0;
     // ---- DFS ----
     uint32_t node0 = 0, noff0 = 0, cur = 0, coff = 0, dist = 0, sp = 0, emitted = 0;
@@ -178,8 +220,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     // LDSR: the lane's slice holds 8 zero bytes, then the read as it came (forward), staged when the read was fetched.
     // Oriented bases [i, i+8) are slice bytes [8+i, 16+i) forward, or the reverse complement of slice bytes [len-i, len-i+8).
     auto dfs_chunk = [&](uint32_t d) -> uint64_t {
-        if (!LDSR) return read_chunk(p, len, rc, clip_lo, d);
-        const uint32_t i = d + clip_lo;
+        if (!LDSR) return read_chunk(p, len, rc, clip_lo(), d);
+        const uint32_t i = d + clip_lo();
         const uint32_t o = rc ? len - i : 8u + i;
         const uint32_t *wp = my_lds + (o >> 2);
         const uint32_t x0 = wp[0], x1 = wp[1], x2 = wp[2];
@@ -187,11 +229,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         const uint64_t v = (uint64_t)__funnelshift_r(x0, x1, sh) | ((uint64_t)__funnelshift_r(x1, x2, sh) << 32);
         return rc ? revcomp8(v) : v;
     };
-    auto set_view = [&](uint32_t clip_lo_, uint32_t eff_, uint32_t clip_flag) {
-        clip_lo = clip_lo_; eff = eff_;
-        tflags = (rc ? GROOT_TRAV_RC : 0u) | clip_flag;
-        pre8 = dfs_chunk(0);
-    };
+    auto set_view = [&]() { pre8 = dfs_chunk(0); };           // (after rc / level have been set)
     auto scan_range = [&](uint32_t node, uint32_t s0, uint32_t nlen, uint32_t from, uint32_t to) {
         sc_node = node; sc_s0 = s0; sc_len = nlen; sc_pos = from; sc_end = to;
     };
@@ -200,13 +238,13 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     // 1. seed offset shuffling (alignment.go:34-45).  Returns true when levels 1 and 2 cannot start anywhere for this
     // orientation (prefix tables): the ranges are left empty and the caller moves on through the hierarchy.
     auto start_orientation = [&](uint32_t t) -> bool {
-        rc = t; level = 1;
-        set_view(0, len, 0);
+        rc = t; level = 1; reach = 0;
+        set_view();
         scan_range(seed, seed_s0, seed_len, off0, l1_hi);
         phase = PH_SCAN;
         bool no;
         if (cls & 0x40u) no = verdict(kRecNo12F);
-        else no = ix.win_prefix && prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff >= 12 ? dfs_chunk(8) : 0, eff);   // (null: the tables are still being built, groot_hip_open_flags)
+        else no = ix.win_prefix && prefix_absent(ix.win_prefix + (size_t)w * kPrefixWords, pre8, eff() >= 12 ? dfs_chunk(8) : 0, eff());   // (null: the tables are still being built, groot_hip_open_flags)
         if (no) { level = 2; cn_cur = cn_end; sc_pos = sc_end = 0; sc_node = kEmpty; }
         return no;
     };
@@ -224,14 +262,18 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 level = 3;                                  // 3. hard clip the first base (:72-85)
                 if (off0 >= seed_len) { level = 4; continue; }   // :199-201 holds for levels 3 and 4 alike
                 if (verdict(kRecNo3F)) continue;
-                set_view(1, len - 1, GROOT_TRAV_START_CLIP);
+                set_view();
                 scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
                 return;
             } else if (level == 3) {
                 level = 4;                                  // 4. hard clip the last base (:87-103)
                 if (off0 >= seed_len) continue;
                 if (verdict(kRecNo4F)) continue;            // its single start position fails the first comparison
-                set_view(0, len - 1, GROOT_TRAV_END_CLIP);
+                // Level 4 is level 1's first DFS again, one base shorter: a branch that died (mismatch, no path left, no neighbour for the next
+                // base) before it had matched len - 1 bases dies the same way here, and a sink it reached would have been level 1's alignment.
+                // (start positions the filters turned down matched fewer than 12 bases; len >= 14 keeps both views above that)
+                if (len >= 14u && reach + 1u < len) continue;
+                set_view();
                 scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
                 return;
             } else {
@@ -242,7 +284,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 }
                 if (rc == 0) {
                     if (start_orientation(1)) continue;
-                } else phase = PH_FETCH;                     // both orientations failed: next mapping
+                } else if (cls & kClsHelper) { have_read = false; phase = PH_JOIN; }   // (dry run: result 0 = the window fails)
+                else if ((cls & 0x100u) && (cnt > 4u || (cls & 0x200u)) && sd0 + kForkMin <= cnt) phase = PH_FORK;   // more windows wait in the read's ascending list
+                else phase = PH_FETCH;                       // both orientations failed: next mapping
                 return;
             }
         }
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         }
     };
     auto filter16 = [&](const uint64_t w0, const uint64_t w1, const uint64_t w2, const int npos, const int room, uint64_t &c_lo, uint64_t &c_hi) {
-        filter16x(pre8, eff, w0, w1, w2, npos, room, c_lo, c_hi);
+        filter16x(pre8, eff(), w0, w1, w2, npos, room, c_lo, c_hi);
     };
     auto first16 = [](const uint64_t c_lo, const uint64_t c_hi) -> uint32_t {
         if (c_lo) return (uint32_t)__builtin_ctzll(c_lo) >> 3;
@@ -273,7 +317,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     };
     // can no DFS from (node, off) spell the first eight bases of the current view?  (DeviceIndex::node_l2b; sound: false when in doubt)
     auto cannot_start = [&](uint32_t node, uint32_t off) -> bool {
-        if (!ix.node_l2b || off > 10u || eff < 8u) return false;
+        if (!ix.node_l2b || off > 10u || eff() < 8u) return false;
         const int c8 = kmer8_code(pre8);
         if (c8 < 0) return false;
         const uint64_t need = l2_bloom_bits((uint32_t)c8);
@@ -288,7 +332,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     };
 
     for (;;) {
-#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2     // (2 = phase timing only: the tally itself costs time)
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 1     // (2 = phase timing only: the tally itself costs time)
         for (int e = 0; e < 32; e++) {                         // convergent point: tally the previous iteration
             const unsigned long long b = __ballot((ev >> e) & 1u);
             if (b && (threadIdx.x & 63) == 0) {
@@ -308,14 +352,20 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         // its own read, applies the requester's filters (4 bases, the in-node bases, the start position's 8-mer set) to entry
         // cn_cur + lane; the ballot of the entries with a start position left is all the requester visits afterwards.
         // (when many lanes ask at once -- reads that march in step -- each scanning its own entries is the parallel way: they are told so)
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+        const unsigned long long tl_c0 = wall_clock64();
+#endif
         unsigned long long bh = __ballot(phase == PH_SCAN && level == 2u && sc_node == kCoopWant);
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+        tl_ncoop += (uint32_t)__popcll(bh);
+#endif
         if (__popcll(bh) > (int)kCoopMaxAsk) {
             if (phase == PH_SCAN && level == 2u && sc_node == kCoopWant) sc_node = kEmpty;
             bh = 0;
         }
         for (; bh; bh &= bh - 1) {
             const int L = __ffsll(bh) - 1;
-            const uint32_t q0 = __shfl(cn_cur, L), q1 = __shfl(cn_end, L), qeff = __shfl(eff, L);
+            const uint32_t q0 = __shfl(cn_cur, L), q1 = __shfl(cn_end, L), qeff = __shfl(eff(), L);
             const uint64_t qpre = (uint64_t)(uint32_t)__shfl((int)(uint32_t)pre8, L) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pre8 >> 32), L) << 32);
             const int c8 = qeff >= 8u && ix.node_l2b ? kmer8_code(qpre) : -1;
             const uint64_t need8 = c8 >= 0 ? l2_bloom_bits((uint32_t)c8) : 0ull;
@@ -340,6 +390,63 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             const unsigned long long bits = __ballot(has);
             if ((int)(threadIdx.x & 63u) == L) { sc_node = q0; sc_s0 = (uint32_t)bits; sc_len = (uint32_t)(bits >> 32); }
         }
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+        const unsigned long long tl_c1 = wall_clock64();
+        tl_coop += tl_c1 - tl_c0;
+#endif
+        // ---- fork: the windows a failing read has left in its list are tried by the wavefront's idle lanes, one each, as dry runs ----
+        // graphminion.go:46-102 takes a read's windows of a graph one after the other until one aligns; for a read that fails them all --
+        // 13 windows of one gene family, five hierarchy levels, two orientations -- that chain IS the launch's duration, while most lanes
+        // of its wavefront have nothing to do (rounds of the head of the order fill 16 lanes; the tail of the launch fewer).  The
+        // helpers only answer "would AlignRead succeed on window j" (no records, no counts); the owner then passes over the windows known to
+        // fail with one FETCH step each (IncrementSubPath is still called for them, in order: :60-67) and aligns the first that succeeds itself.
+        if (__ballot(phase >= PH_FORK)) {                       // (one ballot per iteration when nobody forks)
+        for (unsigned long long bq = __ballot(phase == PH_FORK); bq; bq &= bq - 1) {
+            const int L = __ffsll(bq) - 1;
+            const unsigned long long idle = __ballot(phase == PH_WAIT || phase == PH_DONE);
+            const uint32_t q_lo = __shfl(sd0, L), q_cnt = __shfl(cnt, L);
+            const uint32_t nh = min((uint32_t)__popcll(idle), q_cnt - q_lo);
+            if (nh < 2u) {                                     // nobody to help: carry on alone
+                if ((int)(threadIdx.x & 63u) == L) phase = PH_FETCH;
+                continue;
+            }
+            const uint32_t q_r = __shfl(r, L), q_len = __shfl(len, L), q_g = __shfl(g, L), q_hb = __shfl(high_byte, L);
+            const uint32_t q_plo = __shfl((uint32_t)(uintptr_t)p, L), q_phi = __shfl((uint32_t)((uintptr_t)p >> 32), L);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if ((phase == PH_WAIT || phase == PH_DONE) && rank < nh) {
+                fk = (uint32_t)L | (phase << 8);
+                r = q_r; len = q_len; high_byte = q_hb;
+                p = reinterpret_cast<const uint8_t *>((uintptr_t)q_plo | ((uintptr_t)q_phi << 32));
+                if (LDSR) {                                    // the owner's staged read (one LDS address for all helpers: a broadcast)
+                    const uint32_t *src = lds_reads + (size_t)(threadIdx.x - (threadIdx.x & 63u) + (uint32_t)L) * a.lds_stride_dw;
+                    const uint32_t nd = min(a.lds_stride_dw, 2u + 4u * ((q_len + 27u) >> 4));
+                    for (uint32_t i = 0; i < nd; i++) my_lds[i] = src[i];
+                }
+                // a read of ONE window, w: the FETCH phase sets it up like any other (verdicts from the prefix tables)
+                cnt = 1; cls = 0x80u | kClsHelper;
+                sd0 = a.seed_win[(size_t)(q_lo + rank) * a.n_reads + q_r];
+                last = -1; cur_graph = q_g; done_graph = kEmpty; group_rc_called = true;
+                have_read = true;
+                phase = PH_FETCH;
+            }
+            if ((int)(threadIdx.x & 63u) == L) phase = PH_FORKWAIT;
+        }
+        // ---- join: an owner goes on when the lowest helper that did not fail is known and every helper below it has failed ----
+        for (unsigned long long bj = __ballot(phase == PH_FORKWAIT); bj; bj &= bj - 1) {
+            const int L = __ffsll(bj) - 1;
+            const bool mine = (cls & kClsHelper) && (int)(fk & 63u) == L;
+            const unsigned long long bm = __ballot(mine), bdone = __ballot(mine && phase == PH_JOIN), bhit = __ballot(mine && phase == PH_JOIN && (fk >> 12) != 0u);
+            const unsigned long long below = bhit ? bm & ((1ull << (__ffsll(bhit) - 1)) - 1ull) : bm;
+            if (below & ~bdone) continue;                       // someone whose answer matters is still walking
+            // windows of the list up to the last helper below the hit are known to fail (the list ascends: a bound on the window id says it)
+            const uint32_t w_top = below ? __shfl(w, 63 - __builtin_clzll(below)) + 1u : 0u;
+            if (mine) { phase = (fk >> 8) & 7u; cls = 0; have_read = false; fk = 0; }   // (helpers above the first hit are called off)
+            if ((int)(threadIdx.x & 63u) == L) { fk = w_top; phase = PH_FETCH; }
+        }
+        }
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+        tl_fork += wall_clock64() - tl_c1;
+#endif
         // ---- run the phase holding the most lanes (wave-uniform; ballots and popcounts are SALU) ----
         const unsigned long long bf = __ballot(phase == PH_FETCH), bs = __ballot(phase == PH_SCAN), bd = __ballot(phase == PH_DFS);
         {
@@ -350,12 +457,15 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             const int cw = __popcll(bw);
             const uint32_t Uc = max(1u, min(chunk_len, min(U, 64u)));   // lanes a round of the current chunk fills
             if (cw >= (int)((64u - Uc) + max(1u, a.refill * Uc / 64u)) || (cw && !(bf | bs | bd))) {
-#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 1
                 if ((threadIdx.x & 63) == 0 && wc_iter > 1) atomicAdd(&a.ctr->dbg[128 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // round length
                 if ((threadIdx.x & 63) == 0) atomicMax(&a.ctr->dbg[63], (unsigned long long)(wc_iter - wc_round0));          // longest round
                 wc_round0 = wc_iter;
 #elif defined(GROOT_WORK_COUNTERS)
                 wc_round0 = wc_iter;
+#endif
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+                if (chunk_base < n_todo) { tl_round = wall_clock64(); tl_rounds++; }
 #endif
                 const uint64_t base = chunk_base;
                 if (base >= n_todo) {                          // this wave's share is used up
@@ -380,6 +490,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
         const int cf = __popcll(bf), cs = __popcll(bs), cd = __popcll(bd);
         // (running the smaller phases in the same iteration as well -- every lane a step per iteration -- was measured in round 4: the
         // phases' trips to memory then follow each other inside the iteration and nothing is gained: 3.1 -> 3.5 ms on reads with errors)
+        // (a bound on the iterations a lane may wait for its phase -- its phase runs next once it has waited 4 / 8 / 16 -- was measured in
+        // round 4 on all kernel-path workloads: no difference; the wavefronts that end late are not starved, they hold reads that started late)
         const uint32_t run = (cd >= cs && cd >= cf) ? PH_DFS : (cs >= cf ? PH_SCAN : PH_FETCH);
         if (phase != run) continue;
         GROOT_EV(run);                                          // events 0,1,2: a step of FETCH / SCAN / DFS
@@ -400,6 +512,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 GROOT_EV(3);
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
                 wc_n0[0] = wc_n[0]; wc_n0[1] = wc_n[1]; wc_n0[2] = wc_n[2];
+#endif
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+                tl_read0 = wall_clock64(); tl_it0 = wc_iter; tl_st0 = wc_n[0] + wc_n[1] + wc_n[2];
 #endif
                 const bool virt = slot < nv;                   // an item of a split read: seed positions [vlo, vhi) of its ascending list
                 uint32_t vlo = 0, vhi = 0;
@@ -437,7 +552,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 }
                 qrow = ix.q_row[len - ix.k + 1];              // graphminion.go:60 kmerCount -> its row of the call-count table
                 read_id = a.first_read_id + ((cls & 0x400u) ? a.n_reads + slot : r);   // (an item labels its records with its own slot: order_ovf_kernel)
-                n_graphs = 0; ord = 0; last = -1;
+                n_graphs = 0; ord = 0; last = -1; fk = 0;
                 done_graph = kEmpty; cur_graph = kEmpty; group_rc_called = false;
                 have_read = true;
                 if (LDSR) {                                   // stage the read: 64 bytes per pass, the four loads in flight together
@@ -489,9 +604,10 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                     const uint32_t cand = a.seed_win[(size_t)j * a.n_reads + r];
                     if ((long long)cand > last && cand < nw) nw = cand;
                 }
+            if (nw == kEmpty && (cls & kClsHelper)) { have_read = false; phase = PH_JOIN; continue; }   // (not reached: next_range ends a dry run)
             if (nw == kEmpty) {                               // every seed of the read handled
                 GROOT_EV(4);
-#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS != 2
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 1
                 atomicAdd(&a.ctr->dbg[64 + min(63u, (wc_iter - wc_round0) / 2)], 1ull);   // when in its round the lane finished
 #endif
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 2
@@ -500,6 +616,19 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                     if (sl < 30) {
                         a.ctr->dbg[129 + 2 * sl] = (unsigned long long)r | ((unsigned long long)(wc_iter - wc_round0) << 32);
                         a.ctr->dbg[130 + 2 * sl] = (unsigned long long)(wc_n[0] - wc_n0[0]) | ((unsigned long long)(wc_n[1] - wc_n0[1]) << 20) | ((unsigned long long)(wc_n[2] - wc_n0[2]) << 40);
+                    }
+                }
+#endif
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+                {   // reads that end late in the launch, by name: read | windows | item?, start and end (us), wave iterations and own steps meanwhile
+                    const unsigned long long te = wall_clock64();
+                    if (te - tl_start >= (unsigned long long)GROOT_TL_LATE_US * 100ull) {
+                        const unsigned long long sl = atomicAdd(&a.ctr->dbg[17], 1ull);
+                        if (sl < 14) {
+                            a.ctr->dbg[18 + 3 * sl] = (unsigned long long)r | ((unsigned long long)cnt << 32) | ((unsigned long long)((cls >> 10) & 1u) << 63);
+                            a.ctr->dbg[19 + 3 * sl] = ((tl_read0 - tl_start) / 100ull) | (((te - tl_start) / 100ull) << 32);
+                            a.ctr->dbg[20 + 3 * sl] = (unsigned long long)(wc_iter - tl_it0) | ((unsigned long long)(wc_n[0] + wc_n[1] + wc_n[2] - tl_st0) << 32) | ((unsigned long long)ord << 48) | ((unsigned long long)n_graphs << 56);
+                        }
                     }
                 }
 #endif
@@ -517,9 +646,13 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             load32(ix.win_rec + w, wa, wb);
             g = wa.x;
             GROOT_SUBT(2);
+            if (cls & kClsHelper) {
+                if (g != cur_graph) { fk |= 2u << 12; have_read = false; phase = PH_JOIN; continue; }   // another graph's window: its owner takes it as it comes
+            } else {
             if (g != cur_graph) { cur_graph = g; n_graphs++; group_rc_called = false; }
             if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
-            if (a.update_weights) {                            // :67 IncrementSubPath
+            }
+            if (a.update_weights && !(cls & kClsHelper)) {     // :67 IncrementSubPath
                 // neighbouring lanes mostly hold reads of the same window (processing order): one atomic per distinct cell
                 // among the lanes that are here together instead of one per lane (0.44 of 3.15 ms per 10 M reads)
                 const uint64_t cell = (uint64_t)qrow * ix.n_windows + w;
@@ -535,12 +668,13 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 }
             }
             GROOT_SUBT(3);
-            if (a.incr_cnt) {              // capture pass: which windows had IncrementSubPath called, in call order
+            if (a.incr_cnt && !(cls & kClsHelper)) {   // capture pass: which windows had IncrementSubPath called, in call order
                 const uint32_t n = a.incr_cnt[r];
                 a.incr_cnt[r] = n + 1;
                 if (n < a.incr_cap) a.incr_win[(size_t)r * a.incr_cap + n] = w;
             }
             if (a.no_align) continue;                         // :70-72
+            if (!(cls & kClsHelper) && w < fk) continue;       // a helper has found that AlignRead fails on this window in both orientations
             seed = wa.y; off0 = wa.z;
             l1_hi = wa.w;                                     // alignment.go:36 and :199-201, folded at open
             cn_begin = wb.x; cn_end = wb.y;
@@ -594,7 +728,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                         // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
                         const uint64_t g8 = j < 8 ? window8(w0, w1, j) : window8(w1, w2, j - 8);
                         sc_pos = j + 1; sc_end = min(nlen, 11u);
-                        if (!prefix_ok(g8, pre8, min(min(nlen - j, eff), 8u)) || cannot_start(node, j)) {
+                        if (!prefix_ok(g8, pre8, min(min(nlen - j, eff()), 8u)) || cannot_start(node, j)) {
                             GROOT_EV(8);
                             if (sc_pos >= sc_end) { cn_cur++; sc_pos = 0; advance = cn_cur >= cn_end; }
                         } else {
@@ -621,7 +755,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                     // exact 8-base check of the lowest survivor (alignment.go:203-223 would fail here otherwise)
                     const uint32_t off = sc_pos + j;
                     sc_pos = off + 1;
-                    if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff), 8u)) || cannot_start(sc_node, off)) {
+                    if (!prefix_ok(g8, pre8, min(min(sc_len - off, eff()), 8u)) || cannot_start(sc_node, off)) {
                         GROOT_EV(8);
                         advance = sc_pos >= sc_end;
                     } else {
@@ -647,9 +781,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             // is a trip to L2 whatever it computes, and the general step hides some of it.)
             bool fast_done = false;
             {
-                const uint32_t take = min(rec.seq_len(), eff - dist);
+                const uint32_t take = min(rec.seq_len(), eff() - dist);
                 const uint32_t rdeg = rec.deg();
-                if (coff == 0 && take >= 1 && take <= 8 && take == rec.seq_len() && dist + take < eff && !rec.wild() && rdeg >= 1 && rdeg <= 4 &&
+                if (coff == 0 && take >= 1 && take <= 8 && take == rec.seq_len() && dist + take < eff() && !rec.wild() && rdeg >= 1 && rdeg <= 4 &&
                     prefix_eq(rec.first8(), cur8, take)) {
                     uint64_t nm[PW];
                     bool any = false;
@@ -675,7 +809,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             }
             if (!fast_done) {
             if (coff != 0 && !(cur == node0 && coff == noff0 && dist == 0)) GROOT_EV(18);
-            const uint32_t take = min(rec.seq_len() - coff, eff - dist);
+            const uint32_t take = min(rec.seq_len() - coff, eff() - dist);
             const uint32_t nb = min(take, 32u);
             bool ok = true;
             if (nb) {
@@ -698,14 +832,16 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
 #pragma unroll
                     for (int i = 0; i < PW; i++) { mask[i] &= rec.mask(i); any |= mask[i] != 0; }
                     const uint32_t rdeg = rec.deg();
-                    if (dist == eff || rdeg == 0) {             // :229-236 report the traversal
-                        if (any) {
+                    if (dist == eff() || rdeg == 0) {             // :229-236 report the traversal
+                        if (any && (cls & kClsHelper)) {       // dry run: the window aligns -- that is all its owner wants to know
+                            fk |= 1u << 12; sp = 0; emitted = 1;
+                        } else if (any) {
                             GROOT_EV(14);
                             if (ord) GROOT_EV(19);
                             groot_trav t;
                             t.read_id = read_id; t.graph_id = g; t.node = node0; t.offset = noff0;
                             t.ord = (uint16_t)ord;
-                            t.flags = (uint8_t)(tflags | (emitted == 0 ? GROOT_TRAV_FIRST : 0));
+                            t.flags = (uint8_t)((rc ? GROOT_TRAV_RC : 0u) | (level == 3u ? GROOT_TRAV_START_CLIP : level == 4u ? GROOT_TRAV_END_CLIP : 0u) | (emitted == 0 ? GROOT_TRAV_FIRST : 0));
                             t.reserved = 0;
                             if (ord == 0) {                    // the common case: no allocation at all
                                 const uint32_t os = (cls & 0x400u) ? a.n_reads + slot : r;
@@ -765,8 +901,10 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             }
             if (backtrack) {
                 GROOT_EV(16);
+                if (level == 1u && noff0 == off0) reach = max(reach, ok ? dist : dist + nb - 1u);   // (a failed comparison leaves dist where it was)
                 if (sp == 0) {                                 // performAlignment is over
-                    if (emitted) {                             // alignment found for (read, graph)
+                    if (emitted && (cls & kClsHelper)) { have_read = false; phase = PH_JOIN; }
+                    else if (emitted) {                        // alignment found for (read, graph)
                         done_graph = g; phase = PH_FETCH;
                         // graphminion.go:96-98 passes over the graph's other seeds: they are the windows up to the graph's last one
                         // (a read below the window size can bring a hundred of them: one FETCH step instead of one each)
@@ -834,7 +972,21 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
 #endif
     }
 
-#ifdef GROOT_WORK_COUNTERS
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 3
+    if ((threadIdx.x & 63) == 0 && tl_rounds) {
+        const unsigned long long te = wall_clock64(), d = te - tl_start, dl = te - tl_round;   // 100 MHz ticks; buckets of 50 us
+        atomicAdd(&a.ctr->dbg[0], (unsigned long long)wc_iter);
+        atomicMax(&a.ctr->dbg[1], (unsigned long long)wc_iter);
+        atomicAdd(&a.ctr->dbg[2], d);
+        atomicMax(&a.ctr->dbg[3], d);
+        atomicAdd(&a.ctr->dbg[4], 1ull);
+        atomicAdd(&a.ctr->dbg[5], (unsigned long long)tl_rounds);
+        atomicAdd(&a.ctr->dbg[8], tl_coop); atomicAdd(&a.ctr->dbg[9], tl_fork); atomicAdd(&a.ctr->dbg[16], (unsigned long long)tl_ncoop);
+        for (int i = 0; i < 3; i++) { atomicAdd(&a.ctr->dbg[10 + i], wc_t[i]); atomicAdd(&a.ctr->dbg[13 + i], (unsigned long long)wc_n[i]); }
+        atomicAdd(&a.ctr->dbg[64 + min(63ull, d / 5000ull)], 1ull);
+        atomicAdd(&a.ctr->dbg[128 + min(63ull, dl / 5000ull)], 1ull);
+    }
+#elif defined(GROOT_WORK_COUNTERS)
     if ((threadIdx.x & 63) == 0)
         for (int i = 0; i < 3; i++) { atomicAdd(&a.ctr->dbg[24 + i], wc_t[i]); atomicAdd(&a.ctr->dbg[27 + i], (unsigned long long)wc_n[i]); }
 #endif
