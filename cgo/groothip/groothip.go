@@ -162,6 +162,10 @@ func Open(device int, idx *Index, p Params) (*Ctx, error) {
 	return c, nil
 }
 
+// OpenAbandon tells a background open (Params.Background) to stop at its next checkpoint: for an input that has ended before the
+// tables were there.  The ctx keeps working, through the full-width kernels.
+func (c *Ctx) OpenAbandon() { C.groot_hip_open_abandon(c.h) }
+
 // MaxReadLen is the longest read the ctx accepts (a longer one fails its batch with GROOT_E_NOSPACE)
 func (c *Ctx) MaxReadLen() int { return int(c.params.MaxReadLen) }
 

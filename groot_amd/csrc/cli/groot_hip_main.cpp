@@ -622,6 +622,7 @@ int run_align(const Args &a)   // cmd/align.go:54-163
     }
     for (auto &t : mappers) t.join();
     producer.join();
+    for (auto &g : gpus) if (g->ctx) groot_hip_open_abandon(g->ctx);   // (a short input can end before the background part of the open has)
     if (failed) {
         // unblock a producer that may sit in push()
         die("%s", fatal.c_str());

@@ -202,7 +202,8 @@ struct groot_ctx {
     // first batches already run (through the full-width kernel, without the seed stage's verdicts: same results, a little slower);
     // what it builds is described in bg_dix and moves into dix between two batches (install_background)
     std::thread bg;
-    std::atomic<int> bg_state{0};          // 0 nothing pending, 1 running, 2 finished, 3 failed
+    std::atomic<int> bg_state{0};          // 0 nothing pending, 1 running, 2 finished, 3 failed, 4 abandoned
+    std::atomic<bool> bg_cancel{false};    // groot_hip_open_abandon / groot_hip_close: the builder stops at its next checkpoint
     int bg_rc = 0;
     std::string bg_err;
     DeviceIndex bg_dix{};
@@ -1193,6 +1194,7 @@ void groot_hip_close(groot_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    ctx->bg_cancel = true;
     if (ctx->bg.joinable()) ctx->bg.join();
     if (ctx->bg_stream) { (void)hipStreamSynchronize(ctx->bg_stream); (void)hipStreamDestroy(ctx->bg_stream); }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -1698,6 +1700,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
         for (auto &x : th) x.join();
     }
     lap("texts");
+    if (c->bg_cancel) return GROOT_OK;   // (background build abandoned: nothing of it is installed)
     // 2. proof and verdicts, one pass: every WindowSize-mer of both rows must reproduce Key.Sketch through the full-width kernel
     //    (a window whose text does not is left without one: its reads take the full-width kernel), and what the full-width
     //    seed stage's epilogue says about the same strings (the reads the signature kernel confirms ARE these strings) --
@@ -1737,6 +1740,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
             if (!tlen[i]) memset(&text[(size_t)i * 2 * kTextMax], 0, 2 * kTextMax);
     }
     lap("proof + verdicts");
+    if (c->bg_cancel) return GROOT_OK;   // (background build abandoned: nothing of it is installed)
     // 3. where the smallest k-mer of every text row is (first occurrence), and the rows at 2 bits per base
     std::vector<uint8_t> argmin((size_t)n * 2, 0);
     {
@@ -1762,6 +1766,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     std::vector<uint8_t> nodes(n);
     for (uint32_t i = 0; i < n; i++) nodes[i] = (uint8_t)std::min<uint32_t>(255, v->win_cn_off[i + 1] - v->win_cn_off[i]);
     lap("argmin + packing");
+    if (c->bg_cancel) return GROOT_OK;   // (background build abandoned: nothing of it is installed)
     // 4. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
     uint32_t cap = 16;
     while (cap < 2 * (uint64_t)n) cap <<= 1;
@@ -1849,6 +1854,7 @@ static int install_background(groot_ctx *c, bool wait)
     c->bg_state.store(0);
     c->build_dix = &c->dix; c->build_stream = c->stream; c->build_shards = c->seed_shards.p;
     if (st == 3) return fail(c, c->bg_rc ? c->bg_rc : GROOT_E_DEVICE, "background part of groot_hip_open: %s", c->bg_err.c_str());
+    if (st == 4) return GROOT_OK;         // abandoned: the ctx goes on with the full-width kernels (same results)
     const DeviceIndex &b = c->bg_dix;
     c->dix.win_prefix = b.win_prefix;
     c->dix.sig = b.sig; c->dix.sig_mask = b.sig_mask; c->dix.win_text = b.win_text;
@@ -2224,6 +2230,8 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     uint32_t per_cu = c->pw > 3 ? kAlignWavesWide : kAlignWaves;
+    // (3 or 2 workgroups of the persistent grid per CU instead of 4, so that the next batch's hashing kernels find free registers from the start: measured in
+    // round 4 -- 3: no difference on any kernel-path workload, 2: mixed 8 M 1 022 -> 983, configs[2] through the kernels 1 861 -> 1 740 Mreads/s)
     c->align_threads = std::min<uint32_t>(((R + kBlock - 1) / kBlock) * kBlock, (uint32_t)std::max(n_cu, 1) * per_cu * kBlock);
     c->stk_depth = c->prm.max_read_len;
     HIP_TRY(c, c->stk_hdr.alloc((size_t)c->stk_depth * c->align_threads));
@@ -2267,13 +2275,13 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
             int rc = GROOT_OK;
             try {
                 if (hipSetDevice(c->device) != hipSuccess) rc = fail(c, GROOT_E_DEVICE, "hipSetDevice");
-                if (!rc) rc = build_prefix_tables(c, v);
-                if (!rc) rc = build_signature_index(c, v, sc);
+                if (!rc && !c->bg_cancel) rc = build_prefix_tables(c, v);
+                if (!rc && !c->bg_cancel) rc = build_signature_index(c, v, sc);
             } catch (const std::exception &e) {
                 rc = fail(c, GROOT_E_NOSPACE, "%s", e.what());
             }
             c->bg_rc = rc;
-            c->bg_state.store(rc ? 3 : 2, std::memory_order_release);
+            c->bg_state.store(rc ? 3 : (c->bg_cancel ? 4 : 2), std::memory_order_release);
         });
         return GROOT_OK;
     }
@@ -2299,6 +2307,13 @@ int groot_hip_open_stats(const groot_ctx *c, groot_open_stats *out)
 int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p)
 {
     return groot_hip_open_flags(out, device_id, idx, p, 0);
+}
+
+int groot_hip_open_abandon(groot_ctx *c)
+{
+    if (!c) return GROOT_E_INVALID;
+    if (c->bg_state.load(std::memory_order_acquire) == 1) c->bg_cancel = true;   // (a finished build is installed by the next submit as usual)
+    return GROOT_OK;
 }
 
 int groot_hip_open_wait(groot_ctx *c)

@@ -144,6 +144,10 @@ class Aligner:
         """groot_hip_open_wait: the background part of the open (prefix tables, signature index) is in place"""
         self._check(lib().groot_hip_open_wait(self._h))
 
+    def open_abandon(self):
+        """groot_hip_open_abandon: a background open stops at its next checkpoint; the ctx keeps working without what it was building"""
+        self._check(lib().groot_hip_open_abandon(self._h))
+
     def open_stats(self):
         """groot_hip_open_stats: what open built besides the uploaded index (the memo) and how long it took"""
         st = OpenStats()

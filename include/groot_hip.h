@@ -120,6 +120,10 @@ int groot_hip_open(groot_ctx **out, int device_id, const groot_index_view *idx, 
 #define GROOT_OPEN_BACKGROUND 1u
 int groot_hip_open_flags(groot_ctx **out, int device_id, const groot_index_view *idx, const groot_params *p, uint32_t flags);
 int groot_hip_open_wait(groot_ctx *ctx);
+/* Tell a background open to stop at its next checkpoint (a tenth of a second at most): for a caller whose input has ended before
+ * the tables were there -- they would only be built to be freed (groot_hip_close asks the same before it joins the thread).  The ctx
+ * keeps working, through the full-width kernels.  No-op without a background build in progress. */
+int groot_hip_open_abandon(groot_ctx *ctx);
 void groot_hip_close(groot_ctx *ctx);
 
 /* What groot_hip_open built besides the uploaded index (diagnostic; times in ms, host wall clock).  The memo: every

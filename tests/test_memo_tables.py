@@ -175,3 +175,13 @@ def test_background_open(argannot_index, monkeypatch):
     # a ctx that is closed while its background part is still running
     al = device.Aligner(index, max_batch_reads=4096, max_read_len=128, memo_budget_mb=device.MEMO_OFF, background=True)
     al.close()
+    # a ctx whose background part is abandoned (groot_hip_open_abandon: the input ended first) keeps answering, through the full-width kernels
+    al = device.Aligner(index, max_batch_reads=8192, max_read_len=128, memo_budget_mb=device.MEMO_OFF, background=True)
+    al.open_abandon()
+    att = np.zeros((0, index.view.n_windows), dtype=np.uint32)
+    c4, att = check_batch(al, index, seq, off, att)
+    al.open_wait()                                                      # (returns once the builder has stopped; nothing is installed)
+    c5, att = check_batch(al, index, seq2, off2, att)
+    assert c4["alignments"] == c0["alignments"] and c5["alignments"] == c1["alignments"]
+    al.open_abandon()                                                   # (no-op without a build in progress)
+    al.close()
