@@ -656,7 +656,13 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 // neighbouring lanes mostly hold reads of the same window (processing order): one atomic per distinct cell
                 // among the lanes that are here together instead of one per lane (0.44 of 3.15 ms per 10 M reads)
                 const uint64_t cell = (uint64_t)qrow * ix.n_windows + w;
-                for (bool pending = true; pending;) {
+                // (... when they do: if the first lane's cell is shared by fewer than a quarter of the lanes here, the reads are unrelated --
+                // mixed lengths, reads with errors -- and a lane each is cheaper than a trip round this loop per distinct cell)
+                const uint64_t cell0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cell) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cell >> 32)) << 32);
+                const bool together = 4 * __popcll(__ballot(cell == cell0)) >= __popcll(__ballot(1));
+                if (!together) atomicAdd(&a.attempts[cell], 1u);
+                for (bool pending = together; pending;) {
                     const uint64_t first = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cell) |
                                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cell >> 32)) << 32);
                     const unsigned long long same = __ballot(cell == first);

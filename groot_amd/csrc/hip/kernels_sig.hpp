@@ -54,6 +54,10 @@ __device__ __forceinline__ void todo_push(const SeedArgs &a, uint32_t r)
     a.todo_list[base + __popcll(active & ((1ULL << lane) - 1ULL))] = r;
 }
 
+#ifndef GROOT_SIG_MIN_LANES
+#define GROOT_SIG_MIN_LANES 16
+#endif
+constexpr uint32_t kSigMinLanes = GROOT_SIG_MIN_LANES;   // (break-even: ~4 300 wave-instructions of hashing against ~180 per read in the list pass)
 // TW: dwords of a packed read the text comparison handles (reads of up to 16 * TW bases; longer ones take the full-width kernel)
 template <int S, int M5, int TW>
 #ifndef GROOT_SIG_WAVES_LONG
@@ -133,6 +137,10 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
             if (bits) fast = false;
         }
     }
+    // A wavefront hashes at the price of 64 reads however few of its lanes take part: in a batch of mixed read lengths 2-3 % of the reads are
+    // window-sized, four in five wavefronts hold one or two of them, and the kernel cost 1.1 ms per 8 M reads (2.9 beside the align stage) to
+    // answer 0.2 M.  Below kSigMinLanes such lanes the wavefront leaves its reads to the list pass, which takes them packed 64 to a wavefront.
+    if ((uint32_t)__popcll(__ballot(fast)) < kSigMinLanes) fast = false;
     {
         // the reads left to the list pass (other lengths, bytes other than ACGT, the LSH-Forest branch): counted per workgroup -- one
         // LDS atomic per wavefront, ONE global atomic per workgroup.  (One global atomic per wavefront on the single counter cost

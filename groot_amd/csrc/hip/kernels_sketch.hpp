@@ -25,12 +25,15 @@ namespace groot {
 // (the S running minima are 2 S registers: at GROOT_SEED_WAVES waves per SIMD (~100 VGPRs) sketch sizes above 30 spilled them --
 // 20 ms per 2 M reads at S = 64.  Larger sketches get fewer, larger waves: 3 per SIMD up to S = 48, 2 beyond)
 #ifndef GROOT_LIST_WAVES
-#define GROOT_LIST_WAVES 3      // the list instance: 3 waves = up to 168 VGPRs -- no spills (5 waves spilled 25 VGPRs) and room to fetch four rows of the LSH-Forest walk ahead (list pass of a mixed-length batch 4.0 -> 3.6 ms)
+#define GROOT_LIST_WAVES 4      // the list instance: 4 waves = 128 VGPRs, 0 spilled with two rows of the LSH-Forest walk fetched together (126 used; four rows: 7 spilled).
+                                // History: 5 waves spilled 25-50 VGPRs; 3 waves with four rows ahead took the list pass of a mixed-length batch from 4.0 to 3.6 ms; 4 waves x 2 rows,
+                                // measured once the signature kernel left its sparse wavefronts' reads to this pass: mixed t = 0.99 1 093 -> 1 176, t = 0.90 606 -> 653 Mreads/s
+                                // (4 x 4: 1 174 / 649, 4 x 1: 1 154 / 647, 3 x 8: 1 109 / 607, 5 x 2: 1 073 / 611)
 #endif
 #ifndef GROOT_LIST_ROWS_AHEAD
-#define GROOT_LIST_ROWS_AHEAD 4
+#define GROOT_LIST_ROWS_AHEAD 2
 #endif
-constexpr int seed_waves(int S, bool list = false) { return S == 0 ? 1 : (S <= 30 ? (list ? GROOT_LIST_WAVES : GROOT_SEED_WAVES) : (S <= 48 ? 3 : 2)); }
+constexpr int seed_waves(int S, bool list = false) { return S == 0 ? 1 : (S <= 30 ? (list ? (S <= 24 ? GROOT_LIST_WAVES : 3) : GROOT_SEED_WAVES) : (S <= 48 ? 3 : 2)); }
 template <int S, int MAXK, bool DUMP, int M5, bool LIST = false>
 __global__ __launch_bounds__(kBlock, seed_waves(S, LIST)) void sketch_seed_kernel(SeedArgs a)
 {
