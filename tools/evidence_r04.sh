@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-4 evidence in one gpurun call (run from the repo root on the GPU box): parity suite, the driver line, soak, the timeline build of the align
+# kernel (python __graft_entry__.py wc 3 first), then tools/profile_r04.sh (kernel trace + PMC passes) -> gpurun_out/f_*.{txt,json}, r04_*; copy into profiles/
 cd "$GRAFT_REPO_ROOT"
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5 > gpurun_out/f_pytest.txt
 python bench.py --steps 20 > gpurun_out/f_bench.json 2> gpurun_out/f_bench.err
