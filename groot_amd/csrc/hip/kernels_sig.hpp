@@ -98,8 +98,22 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
     const uint64_t base16 = span0 & ~15ULL;
     const uint64_t span_bytes = span1 - base16;
     const bool in_lds = span_bytes <= a.lds_read_bytes;
+    __syncthreads();
+    if (in_lds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
+        const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
+        for (uint32_t i = tid; i < n16; i += kBlock) {
+            const uint4 v = src[i];
+            uint32_t bad = 0;
+            const uint32_t c = codes_of4(v.x, bad) | (codes_of4(v.y, bad) << 8) | (codes_of4(v.z, bad) << 16) | (codes_of4(v.w, bad) << 24);
+            codes[i] = c;
+            if (bad) atomicOr(&badbits[i >> 5], 1u << (i & 31));
+        }
+    }
+    __syncthreads();
     const uint32_t r = r0 + tid;
-    // (no thread leaves before the barriers below: threads without a read, or with one that is answered at once, are predicated off instead)
+    // (no thread leaves before the two barriers of the list bookkeeping below: threads without a read, or with one that is answered
+    // at once, are predicated off instead)
     const bool valid = r < a.n_reads;
     const uint64_t o0 = valid ? a.seq_off[r] : 0;
     const uint32_t len = valid ? (uint32_t)(a.seq_off[r + 1] - o0) : 0;
@@ -114,24 +128,6 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
     // read is a substring with FEWER k-mers -- its minima may differ below the 27 signature bits -- and takes the full-width kernel)
     bool fast = !answered && in_lds && len >= k && len >= ix.w && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
     if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch
-    // A wavefront hashes at the price of 64 reads however few of its lanes take part: in a batch of mixed read lengths 2-3 % of the reads are
-    // window-sized, four in five wavefronts hold one or two of them, and the kernel cost 1.1 ms per 8 M reads (2.9 beside the align stage) to
-    // answer 0.2 M.  Below kSigMinLanes such lanes the wavefront leaves its reads to the list pass, which takes them packed 64 to a wavefront;
-    // a workgroup none of whose wavefronts hashes does not stage its reads either (all this is known from the lengths alone).
-    if ((uint32_t)__popcll(__ballot(fast)) < kSigMinLanes) fast = false;
-    const bool stage = __syncthreads_or(fast ? 1 : 0) != 0;
-    if (in_lds && stage) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
-        const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
-        for (uint32_t i = tid; i < n16; i += kBlock) {
-            const uint4 v = src[i];
-            uint32_t bad = 0;
-            const uint32_t c = codes_of4(v.x, bad) | (codes_of4(v.y, bad) << 8) | (codes_of4(v.z, bad) << 16) | (codes_of4(v.w, bad) << 24);
-            codes[i] = c;
-            if (bad) atomicOr(&badbits[i >> 5], 1u << (i & 31));
-        }
-    }
-    __syncthreads();
     if (fast) {
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
         for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
@@ -141,6 +137,10 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
             if (bits) fast = false;
         }
     }
+    // A wavefront hashes at the price of 64 reads however few of its lanes take part: in a batch of mixed read lengths 2-3 % of the reads are
+    // window-sized, four in five wavefronts hold one or two of them, and the kernel cost 1.1 ms per 8 M reads (2.9 beside the align stage) to
+    // answer 0.2 M.  Below kSigMinLanes such lanes the wavefront leaves its reads to the list pass, which takes them packed 64 to a wavefront.
+    if ((uint32_t)__popcll(__ballot(fast)) < kSigMinLanes) fast = false;
     {
         // the reads left to the list pass (other lengths, bytes other than ACGT, the LSH-Forest branch): counted per workgroup -- one
         // LDS atomic per wavefront, ONE global atomic per workgroup.  (One global atomic per wavefront on the single counter cost
