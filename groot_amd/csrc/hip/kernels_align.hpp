@@ -100,8 +100,8 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
 #endif
     // The walk is a chain of dependent steps with a few hundred instructions between two trips to memory, and it runs beside the next
     // batch's hashing kernels, which keep every SIMD's issue port busy: at equal priority each instruction of a walking wavefront waits its turn
-    // behind five hashing wavefronts (5-6 us per wave iteration measured with the timeline build).  Raised, the walking wavefronts -- mostly
-    // waiting for memory anyway -- go first when they can go at all.
+    // behind five hashing wavefronts.  Raised, the walking wavefronts -- mostly waiting for memory anyway -- go first when they can go at all
+    // (worth a few per cent: the 5-6 us a wave iteration takes are its own dependent instructions and trips to memory).
     __builtin_amdgcn_s_setprio(GROOT_ALIGN_PRIO);
     unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
 #ifdef GROOT_WORK_COUNTERS
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     // Reads that do not march in step (mixed read lengths: a.head_lanes != 0) get rounds of 32, one round per trip to the cursor: a round
     // of 64 of them lasts as long as their steps laid end to end, and a wavefront that took 128 such slots just before the cursor ran dry
     // was still walking at 5.9 ms when all others had ended by 2.5 (timeline build, 8 M reads of 75..150 bases: align stage 5.9 -> 3.4 ms)
-#ifndef GROOT_EXP_MIXED_U
-#define GROOT_EXP_MIXED_U 32
+#ifndef GROOT_MIXED_ROUND_LANES
+#define GROOT_MIXED_ROUND_LANES 32
 #endif
-    uint32_t U = a.head_lanes ? (uint32_t)GROOT_EXP_MIXED_U : 64u;
+    uint32_t U = a.head_lanes ? (uint32_t)GROOT_MIXED_ROUND_LANES : 64u;
     if (a.round_lanes) U = a.round_lanes;
     else
         while (U > 1u && n_todo < U * (gridDim.x * (uint32_t)(kBlock / 64))) U >>= 1;
