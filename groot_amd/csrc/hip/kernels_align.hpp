@@ -272,7 +272,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 // Level 4 is level 1's first DFS again, one base shorter: a branch that died (mismatch, no path left, no neighbour for the next
                 // base) before it had matched len - 1 bases dies the same way here, and a sink it reached would have been level 1's alignment.
                 // (start positions the filters turned down matched fewer than 12 bases; len >= 14 keeps both views above that)
+#ifndef GROOT_NO_LEVEL4_RULE                               // (tools/cross_check.py builds the kernel without the rule and without the fork to compare at scale)
                 if (len >= 14u && reach + 1u < len) continue;
+#endif
                 set_view();
                 scan_range(seed, seed_s0, seed_len, off0, off0 + 1);
                 return;
