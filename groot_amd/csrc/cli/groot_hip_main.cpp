@@ -59,7 +59,8 @@ void logf(const char *fmt, ...)
     va_end(ap);
     logf("%s", buf);
     if (g_log) fprintf(stderr, "%s\n", buf);
-    exit(1);
+    fflush(nullptr);
+    _exit(1);                                           // (parser / mapper / HIP threads may be running: no static destructors under their feet)
 }
 
 struct Args {
