@@ -183,18 +183,32 @@ func (c *Ctx) Reopen(maxReadLen int) error {
 		return c.err("groot_hip_attempts_export")
 	}
 	// close first, then open: the index and the tables of groot_hip_open would otherwise sit in HBM twice
+	old := c.params
 	p := c.params
 	p.MaxReadLen = uint32(maxReadLen)
 	C.groot_hip_close(c.h)
 	c.h = nil
-	bigger, err := Open(c.device, c.idx, p)
-	if err != nil {
-		return err
+	reopen := func(p Params) (*Ctx, error) {
+		n, err := Open(c.device, c.idx, p)
+		if err != nil {
+			return nil, err
+		}
+		if rc := C.groot_hip_attempts_import(n.h, (*C.uint32_t)(unsafe.Pointer(&q[0])), (*C.uint32_t)(unsafe.Pointer(&counts[0])), nRows); rc != 0 {
+			err := n.err("groot_hip_attempts_import")
+			n.Close()
+			return nil, err
+		}
+		return n, nil
 	}
-	if rc := C.groot_hip_attempts_import(bigger.h, (*C.uint32_t)(unsafe.Pointer(&q[0])), (*C.uint32_t)(unsafe.Pointer(&counts[0])), nRows); rc != 0 {
-		err := bigger.err("groot_hip_attempts_import")
-		bigger.Close()
-		return err
+	bigger, err := reopen(p)
+	if err != nil {
+		// the larger ctx could not be had (HBM, a kmerCount outside its range): back to a ctx with the old limit and the counts exported
+		// above, so that the caller still holds a working Ctx and loses nothing; only if that fails too is the Ctx dead (c.h == nil)
+		if back, err2 := reopen(old); err2 == nil {
+			c.h, c.params = back.h, back.params
+			return fmt.Errorf("reopen for reads of %d bases: %v (the ctx keeps its limit of %d)", maxReadLen, err, old.MaxReadLen)
+		}
+		return fmt.Errorf("reopen for reads of %d bases: %v; the ctx could not be restored either and is closed", maxReadLen, err)
 	}
 	c.h, c.params = bigger.h, bigger.params
 	return nil

@@ -451,7 +451,14 @@ int run_align(const Args &a)   // cmd/align.go:54-163
             if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0 ? 4 : 1);
         }
         if (bytes >= (20ull << 30)) memo_budget = 0;
-    } else if (a.memo != "off") memo_budget = (uint32_t)std::max(1L, atol(a.memo.c_str()));
+    } else if (a.memo != "off") {
+        char *end = nullptr;
+        const long mb = strtol(a.memo.c_str(), &end, 10);
+        if (a.memo.empty() || *end || mb < 1 || mb > (1L << 30)) {
+            die("--memo: '%s' is neither auto, on, off nor a number of MiB", a.memo.c_str());
+        }
+        memo_budget = (uint32_t)mb;
+    }
     auto params_for = [&](uint32_t max_read_len) {
         groot_params prm;
         groot_params_default(&prm);

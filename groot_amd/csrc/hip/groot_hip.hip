@@ -162,6 +162,7 @@ struct groot_ctx {
     Knobs kn;
     uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
     hipEvent_t h2d_last = nullptr;         // the copy-in of the newest host-fed batch (its slot's event)
+    hipEvent_t last_compute = nullptr;     // behind the order stage of the newest batch (groot_hip_stream_join)
     hipStream_t own_stream = nullptr, stream = nullptr, astream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;   // stream: seed stage (the caller's, if given); astream: align + order stage
     bool profiling = false;
 
@@ -207,6 +208,7 @@ struct groot_ctx {
     int bg_rc = 0;
     std::string bg_err;
     DeviceIndex bg_dix{};
+    uint32_t bg_seed_slots = 0, bg_max_read_len = 0;   // what the builder thread may know of the ctx's mutable state: copies taken before it starts
     hipStream_t bg_stream = nullptr;
     DevBuf<unsigned long long> bg_shards;
     // where the table builders of groot_hip_open work: the ctx's own index description / compute stream / shard counters, or the
@@ -397,7 +399,8 @@ static constexpr uint32_t kMaxLdsReadBytes = 64 * 1024;
 static int alloc_seed_slots(groot_ctx *c, uint32_t slots)
 {
     c->seed_slots = slots;
-    for (WorkSet &w : c->ws) HIP_TRY(c, w.seed_win.alloc((size_t)slots * c->prm.max_batch_reads));
+    // (both work sets get new buffers with a new stride: whatever seeds they held are gone -- groot_hip_read_seeds must not find an owner)
+    for (WorkSet &w : c->ws) { HIP_TRY(c, w.seed_win.alloc((size_t)slots * c->prm.max_batch_reads)); w.owner = nullptr; w.ticket = 0; }
     return GROOT_OK;
 }
 
@@ -893,6 +896,7 @@ static int enqueue(groot_ctx *c, Slot *s)
     c->next_set ^= 1u;
     if (int rc = run_batch_async(c, s, true)) return rc;
     HIP_TRY(c, hipEventRecord(s->ev_compute, c->astream));
+    c->last_compute = s->ev_compute;
     // Copy-out on its own stream with no host in between.  The record count is only known on the device, and asking for it
     // would put a host round trip between the last kernel and the copy; so the copy engine is given a PREDICTED count now
     // -- records per read of the latest finished batch, plus a margin -- and collect fetches the rest in the rare batch
@@ -1239,7 +1243,9 @@ static int text_pass(groot_ctx *c, const uint8_t *seqs, const uint32_t *owner, u
     HIP_TRY(c, ctr.alloc(1));
     HIP_TRY(c, cnt.alloc(n));
     HIP_TRY(c, own.alloc(n));
-    HIP_TRY(c, win.alloc((size_t)c->seed_slots * n));
+    // (one read of the ctx's seed slots: on the background builder's thread the caller's thread may grow them meanwhile -- finish_counters)
+    const uint32_t seed_slots = tl_background ? c->bg_seed_slots : c->seed_slots;
+    HIP_TRY(c, win.alloc((size_t)seed_slots * n));
     HIP_TRY(c, key.alloc(n));
     HIP_TRY(c, rec.alloc(n));
     HIP_TRY(c, hipMemcpyAsync(seq.p, seqs, total, hipMemcpyHostToDevice, c->build_stream));
@@ -1249,9 +1255,9 @@ static int text_pass(groot_ctx *c, const uint8_t *seqs, const uint32_t *owner, u
     hipLaunchKernelGGL(uniform_offsets_kernel, dim3(n / kBlock + 1), dim3(kBlock), 0, c->build_stream, off.p, n, len);
     SeedArgs a{};
     a.ix = *c->build_dix;
-    a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, c->prm.max_read_len);
+    a.seq = seq.p; a.seq_off = off.p; a.n_reads = n; a.max_read_len = std::max(len, tl_background ? c->bg_max_read_len : c->prm.max_read_len);
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)kBlock * len + 32, kMaxLdsReadBytes);
-    a.seed_slots = c->seed_slots; a.seed_count = cnt.p; a.seed_win = win.p;
+    a.seed_slots = seed_slots; a.seed_count = cnt.p; a.seed_win = win.p;
     a.ctr = ctr.p; a.shards = c->build_shards;
     const size_t lds = kLdsReads + ((a.lds_read_bytes + 15) & ~15u);
     SeedArgs d = a;                                         // sketches only: no lookup
@@ -2269,6 +2275,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, c->bg_shards.alloc((size_t)kSeedShards * kSeedShardStride));
         HIP_TRY(c, hipMemset(c->bg_shards.p, 0, (size_t)kSeedShards * kSeedShardStride * sizeof(unsigned long long)));
         c->build_dix = &c->bg_dix; c->build_stream = c->bg_stream; c->build_shards = c->bg_shards.p;
+        c->bg_seed_slots = c->seed_slots; c->bg_max_read_len = c->prm.max_read_len;
         c->bg_state.store(1);
         c->bg = std::thread([c, v, sc = std::move(sketch_class)]() {
             tl_background = true;
@@ -2357,6 +2364,17 @@ int groot_hip_set_stream(groot_ctx *c, void *hip_stream)
     if (!c) return GROOT_E_INVALID;
     if (!idle(c)) return fail(c, GROOT_E_STATE, "cannot change stream while a batch is in flight");
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GROOT_OK;
+}
+
+int groot_hip_stream_join(groot_ctx *c, void *hip_stream)
+{
+    if (!c) return GROOT_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    // batches run in submission order on the align stream: the newest batch's event covers the ones before it
+    // (the newest batch's event: a slot's event is recorded anew only by a newer batch still, and a finished one makes the wait a no-op)
+    if (c->last_compute) HIP_TRY(c, hipStreamWaitEvent(st, c->last_compute, 0));
     return GROOT_OK;
 }
 

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(kBlock) void fold_tab_hist_kernel(uint32_t *__restr
         const uint32_t v = hist[w];
         if (!v) continue;
         hist[w] = 0;
-        if (row != kEmpty) attempts[(size_t)row * n_windows + w] += v;
+        // (atomic: the align and order stages of the batch before run beside this kernel on the align stream and add to the same cells)
+        if (row != kEmpty) atomicAdd(&attempts[(size_t)row * n_windows + w], v);
     }
 }
 

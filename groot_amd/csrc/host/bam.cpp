@@ -62,7 +62,10 @@ static void io_loop(groot_bam *b)
         }
         b->io_cv.notify_all();
         int err = 0;
-        for (size_t c = 0; c < outs.size() && !err;) {
+        bool broken;
+        { std::lock_guard<std::mutex> lk(b->io_mu); broken = b->io_err != 0; }
+        // (after a failed write the stream is broken for good: what is still queued is dropped, not appended behind the gap)
+        for (size_t c = 0; c < outs.size() && !err && !broken;) {
             iov.clear();
             for (; c < outs.size() && iov.size() < 512; c++)
                 if (!outs[c].empty()) iov.push_back({outs[c].data(), outs[c].size()});

@@ -157,6 +157,10 @@ class Aligner:
     def set_stream(self, hip_stream):
         self._check(lib().groot_hip_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def stream_join(self, hip_stream=None):
+        """device-side: `hip_stream` (None = the stream of set_stream) waits for the results of every batch submitted so far"""
+        self._check(lib().groot_hip_stream_join(self._h, C.c_void_p(hip_stream)))
+
     def set_profiling(self, on=True):
         self._check(lib().groot_hip_set_profiling(self._h, C.c_int(1 if on else 0)))
 

@@ -140,9 +140,20 @@ typedef struct groot_open_stats {
 } groot_open_stats;
 int groot_hip_open_stats(const groot_ctx *ctx, groot_open_stats *out);
 
-/* Run the kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own.
- * Only while nothing is in flight. */
+/* The SEED stage of every batch (decode, hashing, containment look-up, processing order) is enqueued on a caller-owned
+ * hipStream_t (e.g. torch's current stream), so that it starts behind whatever the caller enqueued there (the kernels that
+ * produced an IN_DEVICE batch); NULL = the ctx's own.  Only while nothing is in flight.
+ * The align and order stages, and everything behind them, run on a stream PRIVATE to the ctx beside the next batch's seed
+ * stage (boss.go:134-203: the reference's sketching and graph minions work side by side too).  Work the caller enqueues on
+ * its stream after a submit is therefore NOT ordered behind the batch's results, and the inputs of groot_hip_submit_device
+ * are still being read when the caller's stream has drained.  Three ways to order against a batch: groot_hip_wait /
+ * groot_hip_collect (host side), or groot_hip_stream_join (device side, no host wait). */
 int groot_hip_set_stream(groot_ctx *ctx, void *hip_stream);
+/* Make `hip_stream` (NULL = the stream given to groot_hip_set_stream) wait -- on the device, the call returns at once --
+ * until every batch submitted so far has its results in place (records, path sets, counters, call counts) and no longer
+ * reads its inputs.  For callers that consume results_on_device buffers or recycle groot_hip_submit_device inputs from
+ * kernels of their own. */
+int groot_hip_stream_join(groot_ctx *ctx, void *hip_stream);
 int groot_hip_set_profiling(groot_ctx *ctx, int enable);
 
 /* ---- submitting batches ------------------------------------------------------------------------------------------

@@ -185,3 +185,50 @@ def test_background_open(argannot_index, monkeypatch):
     assert c4["alignments"] == c0["alignments"] and c5["alignments"] == c1["alignments"]
     al.open_abandon()                                                   # (no-op without a build in progress)
     al.close()
+
+
+@pytest.mark.parametrize("tables", ["all", "no_text"])
+def test_call_counts_of_a_stream_with_the_memo_on(argannot_index, monkeypatch, tables):
+    """several batches in flight, each a mix of error-free reads (answered from the memo: their IncrementSubPath calls are counted by
+    the seed stage's histogram / by order_first_kernel) and reads with an error (walked by the align stage), all of ONE length, i.e.
+    one row of the call-count table: the seed stage of batch b+1 (fold_tab_hist_kernel) adds to the cells the align and order stages
+    of batch b are adding to on the other stream -- every addition must be atomic.  The table after the stream equals the oracle's
+    for the whole input (graphminion.go:60-67)."""
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+        monkeypatch.delenv(v, raising=False)
+    if tables == "no_text":
+        monkeypatch.setenv("GROOT_NO_TEXT_TABLE", "1")
+    index = argannot_index
+    cat, o, lens = synth.reference_sequences(index)
+    n_b, per = 10, 40_000
+    seq, off, _ = synth.reads_np(cat, o, lens, n_b * per, 100, first=777)
+    rows = seq[: n_b * per * 100].reshape(-1, 100).copy()
+    rng = np.random.default_rng(21)
+    hit = rng.random(rows.shape) < 0.006                   # about every second read holds a substitution
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    code = np.searchsorted(acgt, np.where(np.isin(rows, acgt), rows, ord("A")))
+    other = acgt[(code + 1 + rng.integers(0, 3, rows.shape)) % 4]
+    rows = np.where(hit & np.isin(rows, acgt), other, rows).astype(np.uint8)
+    al = device.Aligner(index, max_batch_reads=per, max_read_len=128, pipeline_depth=3)
+    o1 = np.arange(per + 1, dtype=np.uint64) * 100
+    pending, mapped = 0, 0
+    for b in range(n_b):
+        al.submit(rows[b * per:(b + 1) * per].reshape(-1).copy(), o1, first_read_id=b * per)
+        pending += 1
+        if pending == 3:
+            r = al.collect(copy=False)
+            mapped += r["counts"]["mapped"]
+            al.release(r["ticket"])
+            pending -= 1
+    while pending:
+        r = al.collect(copy=False)
+        mapped += r["counts"]["mapped"]
+        al.release(r["ticket"])
+        pending -= 1
+    att = al.attempts().copy()
+    al.close()
+    orc = O.Run(index, 0.99)
+    orc.batch(rows.reshape(-1).copy(), np.arange(n_b * per + 1, dtype=np.uint64) * 100)
+    oatt = orc.attempts()
+    assert mapped == orc.counts()["mapped"]
+    assert np.array_equal(att[: oatt.shape[0]], oatt) and not att[oatt.shape[0]:].any()
