@@ -3,14 +3,22 @@
 
 A step = one pass of the whole `groot align` hot path (seed stage -> align stage -> canonical ordering of the traversal
 records) over one batch of synthetic 100 bp reads that is already resident in HBM; the records stay in HBM (`value`, as the
-bench contract asks: inputs resident when the timed region starts).  Reads shard across GPUs (one process per GPU, index
-replicated); the only exchange is one RCCL all-reduce of the IncrementSubPath call counts after the last step (inside the
-timed region).
+bench contract asks: inputs resident when the timed region starts).  **`value` is the rate THROUGH THE KERNELS north_star names**:
+the ctx is opened with the memo of groot_hip_open switched off, so every read is hashed (sketch_sig_kernel; the reads it cannot
+decide: the full-width list pass), looked up and walked through its graph (align_kernel).  Reads shard across GPUs (one process
+per GPU, index replicated); the only exchange is one RCCL all-reduce of the IncrementSubPath call counts after the last step
+(inside the timed region); with --gpus N every rank's own ms per step and its all-reduce time are on the line (per_rank).
+
+`roofline` describes the longest kernel of that step from live HIP events and carries, as FLAT scalars (the driver keeps those):
+kernel_path_mreads / _ms_per_step, the per-kernel ms and fractions, valu_issue_* (wave-instructions against the issue ceiling),
+and the rates of the legs below (memo_mreads, sub1_mreads, mixed99_mreads, host_fed_mreads, cli_e2e_mreads ...).
 
 Beside `value` the same JSON line carries, at N=1:
-  robustness    the same ctx on reads the memo of groot_hip_open cannot answer: 1 % substitutions per base; 99 % random reads
+  kernel_path   the `value` ctx on reads with 1 % substitutions
+  memo_tier     configs[2] on the library's DEFAULT ctx (memo on: error-free window-sized reads are its keys -- a table look-up)
+  robustness    the default ctx on reads the memo cannot answer: 1 % substitutions per base; 99 % random reads
   thresholds    configs[4]'s containment-threshold sweep on the 100 bp reads (t = 0.97, 0.95, 0.90)
-  mixed         configs[4] at single-GPU scale: resfinder.90, 2 M reads of 75..150 bases, both strands, t = 0.99 .. 0.90,
+  mixed         configs[4] at single-GPU scale: resfinder.90, 8 M reads of 75..150 bases, both strands, t = 0.99 .. 0.90,
                 and one gzip-streamed run of build/groot-hip align
   host_fed      pinned host buffers -> groot_hip_submit_acquired (2-bit bases over PCIe) -> kernels -> traversal records
                 back in pinned host memory (groot_hip_collect), several batches in flight in ONE ctx: SURVEY 8d's
@@ -41,7 +49,7 @@ sys.path.insert(0, REPO)
 
 READ_LEN = 100
 HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
-PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc.json")   # {workload: {kernel: per-launch counters}}, tools/profile_r04.sh
+PMC_FILE = next((f for f in (os.path.join(REPO, "profiles", n) for n in ("r05_pmc.json", "r04_pmc.json")) if os.path.exists(f)), "")   # {workload: {kernel: per-launch counters}}, tools/profile_r05.sh
 
 
 def usable_cpus():
@@ -167,7 +175,7 @@ def kernel_blocks(workload, ms, counts, R, mean_len, pw):
             if p.get("l2_hit_rate") is not None:
                 e["l2_hit_rate"] = p.get("l2_hit_rate")
             e["pmc_kernel_ms"] = p.get("avg_ms")
-            e["traffic_source"] = "profiles/r04_pmc.json[%s]" % workload
+            e["traffic_source"] = "profiles/%s[%s]" % (os.path.basename(PMC_FILE), workload)
         out[k] = e
     return out
 
@@ -188,48 +196,6 @@ def substituted(d_seq, R, p, gen):
         other = acgt[(cur + 1 + torch.randint(0, 3, (n, READ_LEN), generator=gen, device=dev)) % 4]
         rows[c0:c0 + n] = torch.where(hit, other, rows[c0:c0 + n])
     return err
-
-
-def kernel_path(index, d_seq, d_off, R, steps, local_rank, pw):
-    """BASELINE configs[2] through the north_star kernels themselves: a ctx WITHOUT the memo of groot_hip_open (no outcome table, no
-    text table), so every read is hashed (sketch_sig_kernel; what it cannot decide: sketch_seed_kernel<LIST>), looked up and walked
-    through its graph (align_kernel) -- khf.go:35-55, lshe.go:153-175, alignment.go:13-254.  Then the same ctx on reads with 1 %
-    substitutions."""
-    import torch
-
-    from groot_amd import device
-
-    env = {"GROOT_NO_OUTCOME_TABLE": "1", "GROOT_NO_TEXT_TABLE": "1"}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        al = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64, results_on_device=True, pipeline_depth=2)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    al.set_profiling(True)
-    out = {"what": "configs[2] with the memo off (GROOT_NO_OUTCOME_TABLE, GROOT_NO_TEXT_TABLE): every read goes through hashing, containment lookup and the graph walk",
-           "open_ms": al.open_stats()["open_ms"]}
-    v, ms, c = resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
-    out["error_free"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "full_sketch_reads": c["full_sketch_reads"], "walked_reads": c["walked_reads"], "mapped": c["mapped"],
-                         "alignments": c["alignments"], "kernels": kernel_blocks("c2_nomemo", ms, c, R, READ_LEN, pw),
-                         "whole_step": {"bytes": R * (READ_LEN + 4) + 4 * R + 8 * c["seeds"] + (20 + 8 * pw) * c["travs"]}}
-    ws = out["error_free"]["whole_step"]
-    ws["ms"] = R / v / 1e3
-    ws["achieved"] = ws["bytes"] / (ws["ms"] * 1e-3) / 1e9
-    ws["frac"] = ws["achieved"] / HBM_PEAK_GBS
-    g = torch.Generator(device=d_seq.device)
-    g.manual_seed(0x67726F6F74)
-    err = substituted(d_seq, R, 0.01, g)
-    v, ms, c = resident_rate(al, err.data_ptr(), d_off.data_ptr(), R, READ_LEN, steps, 2)
-    out["substitutions_1pct"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "full_sketch_reads": c["full_sketch_reads"], "walked_reads": c["walked_reads"],
-                                 "mapped": c["mapped"], "kernels": kernel_blocks("sub1_nomemo", ms, c, R, READ_LEN, pw)}
-    del err
-    al.close()
-    return out
 
 
 def resident_rate(al, d_seq_ptr, d_off_ptr, R, max_len, steps, warmup, mixed=False):
@@ -613,8 +579,11 @@ def main():
     d_off = torch.arange(0, R + 1, dtype=torch.int64, device=dev) * READ_LEN
     torch.cuda.synchronize()
 
+    # `value` is configs[2] THROUGH THE KERNELS north_star names: the ctx is opened without the memo of groot_hip_open (memo_budget_mb = off), so
+    # every read is hashed (sketch_sig_kernel; what it cannot decide: the full-width list pass), looked up and walked through its graph
+    # (align_kernel) -- khf.go:35-55, lshe.go:153-175, alignment.go:13-254.  The memo tier (the library's default ctx) is a leg: memo_tier.
     al = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
-                        no_align=args.no_align, results_on_device=True, pipeline_depth=2)
+                        no_align=args.no_align, results_on_device=True, pipeline_depth=2, memo_budget_mb=device.MEMO_OFF)
     stream = torch.cuda.current_stream(dev)
     al.set_stream(stream.cuda_stream)
     al.set_profiling(True)
@@ -637,7 +606,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k_ms, a_ms, s_ms, g_ms, f_ms, o_ms = [], [], [], [], [], []
+    stage_sum = {}
     open_stats = al.open_stats()
     # the ctx is a pipeline (submit / collect-the-oldest): the next step is enqueued while the GPU works on this one, so
     # the host's launch latency is not part of a step; every step is waited for and its counters are read
@@ -649,111 +618,150 @@ def main():
         if pending == 2 or (i == args.steps and pending):
             counts = al.wait()
             pending -= 1
-            ms = al.stage_ms()
-            k_ms.append(ms["sketch_seed"]); a_ms.append(ms["align"]); s_ms.append(ms["sort"]); g_ms.append(ms["schedule"])
-            f_ms.append(ms["first_seed_kernel"]); o_ms.append(ms["order_kernel"])
+            for k_, v_ in al.stage_ms().items():
+                stage_sum[k_] = stage_sum.get(k_, 0.0) + v_
     while pending:
         counts = al.wait()
         pending -= 1
+    torch.cuda.synchronize()
+    t_steps = time.perf_counter() - t0          # this rank's K steps (before the exchange)
     if dist is not None:
         dist.all_reduce(d_att)  # per-(kmerCount, window) IncrementSubPath counts: the only exchange
     torch.cuda.synchronize()
+    t_reduce = time.perf_counter() - t0 - t_steps
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank's own step time and what the all-reduce took there, so that a scaling run can be read rank by rank
+        mine = torch.tensor([t_steps / args.steps * 1e3, t_reduce * 1e3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x[0].item()), float(x[1].item())] for x in allr]
+        log("rank %d: %.3f ms per step, all-reduce of the call counts %.3f ms" % (rank, t_steps / args.steps * 1e3, t_reduce * 1e3))
 
     if rank == 0:
         total_reads = world * R * args.steps
         value = total_reads / dt / 1e6
-        seed_ms, align_ms, order_ms = float(np.mean(k_ms)), float(np.mean(a_ms)), float(np.mean(s_ms))
-        first_ms, ordk_ms = float(np.mean(f_ms)), float(np.mean(o_ms))
+        stage = {k_: v_ / args.steps for k_, v_ in stage_sum.items()}
         pw = index.view.path_words
-        # Algorithmic bytes per launch (what a kernel must read / write once per read; index, graph and memo-table
-        # traffic is not counted -- DESIGN.md "Measurement" has the per-read figures):
-        #   first seed kernel (text lookup): bases + u64 offset in; scheduling key, table index, traversal count out
-        #   order_first_kernel             : table index, traversal count, offset in; 20 B record + path set per traversal, seed count + seeds out
-        #   align_kernel                   : the reads that need the graph walk only: bases + record in, record + path set + call counts out
-        walked = counts["walked_reads"]
-        kernels = {
-            "text_lookup_kernel (first seed kernel)": (first_ms, R * (READ_LEN + 8) + 12 * R),
-            "order_first_kernel": (ordk_ms, 12 * R + (20 + 8 * pw) * counts["travs"] + 4 * R + 4 * counts["seeds"]),
-            "align_kernel": (align_ms, walked * (READ_LEN + 32 + 4 + 20 + 8 * pw + 8)),
-        }
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        dom_ms, dom_bytes = kernels[dom]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # per-kernel roofline of the step: live HIP-event durations (groot_stage_ms, taken on the streams the kernels run on), SURVEY 8d's
+        # algorithmic bytes for the reads each kernel handles; HBM traffic and VALU instruction counts from the committed rocprofv3 --pmc passes
+        blocks = kernel_blocks("c2_nomemo", stage, counts, R, READ_LEN, pw)
+        dom = max(blocks, key=lambda k_: blocks[k_]["kernel_ms"])
+        b = blocks[dom]
         step_bytes = R * (READ_LEN + 4) + 4 * R + 8 * counts["seeds"] + (20 + 8 * pw) * counts["travs"]     # SURVEY 8d, full pipeline
         step_ms = dt / args.steps * 1e3
-        # HBM traffic / VALU issue need PMC passes (rocprofv3 --pmc), which cannot run inside this process: they are read
-        # from the committed profile of the same command and labelled as such; null when that file is absent
-        traffic = None
-        pmc_key = dom.split(" ")[0]
-        if os.path.exists(PMC_FILE):
-            try:
-                rec = json.load(open(PMC_FILE)).get("headline", {}).get(pmc_key, {})
-                traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # VALU issue ceiling of the two hashing / walking kernels together: wave-instructions of one batch x 4 cycles over 1024 SIMDs at 2.4 GHz,
+        # against the step's duration (they run side by side on two streams): the ceiling SURVEY 7 predicted would bind before HBM does
+        valu_insts = sum((pmc_of("c2_nomemo", k_.split("<")[0]) or {}).get("per_launch", {}).get("SQ_INSTS_VALU", 0.0) for k_ in ("sketch_sig_kernel", "align_kernel"))
+        valu_floor_ms = 4.0 * valu_insts / (1024 * 2.4e9) * 1e3 if valu_insts else None
         line = {
             "metric": "Mreads/s aligned", "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[2]: full pipeline incl. on-GPU graph-traversal alignment, 100 bp error-free reads sampled from arg-annot.90, index k=31 s=21 w=100 x=8 y=4, t=0.99",
+            "config": {"workload": "configs[2], memo OFF: 10M x 100bp error-free reads of arg-annot.90 (k31 s21 w100 t0.99), every read hashed, looked up, walked",
                        "reads_per_gpu_per_step": R, "read_len": READ_LEN, **({"background_fraction": args.background} if args.background > 0 else {}), "parallelism": f"reads sharded x{world}, index replicated",
-                       "residency": "inputs and traversal records in HBM, two batches in flight (host_fed / cli_e2e below carry the PCIe- and host-inclusive rates)",
-                       "per_step_counts": counts,
-                       "stage_ms": {"sketch_seed": seed_ms, "schedule": float(np.mean(g_ms)), "align": align_ms, "order": order_ms,
-                                    "first_seed_kernel": first_ms, "order_kernel": ordk_ms},
-                       "open": open_stats,
-                       "memo_note": "reads that equal a WindowSize-mer of an indexed path are answered from the memo groot_hip_open builds by running this ctx's own "
-                                    "pipeline on every such string (DESIGN.md); robustness.* below is the same ctx on reads the memo cannot answer"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r04_pmc.json[headline] (separate rocprofv3 --pmc passes of this command)" if traffic else None,
-                         "bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
-                         "note": "table lookups and scattered record writes: bound by random 64-byte HBM accesses and call-count atomics, not by streaming bandwidth (DESIGN.md)",
-                         "whole_step": {"bytes": step_bytes, "ms": step_ms, "achieved": step_bytes / (step_ms * 1e-3) / 1e9,
-                                        "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "what": "SURVEY 8d bytes per read x reads / whole step"},
-                         "other": {k: {"kernel_ms": v[0], "bytes_per_launch": v[1], "achieved": v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None}
-                                   for k, v in kernels.items() if k != dom}},
+                       "residency": "inputs and records resident in HBM, two batches in flight (host_fed_mreads / cli_e2e_mreads: PCIe- and host-inclusive)",
+                       "memo": "off for `value` (groot_params.memo_budget_mb = GROOT_MEMO_OFF); the default ctx's memo tier is roofline.memo_mreads",
+                       "full_sketch_reads": counts["full_sketch_reads"], "walked_reads": counts["walked_reads"], "mapped": counts["mapped"],
+                       "alignments": counts["alignments"], "travs": counts["travs"], "seeds": counts["seeds"],
+                       "per_step_counts": counts, "stage_ms": stage, "open": open_stats},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": b.get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b.get("frac"), "traffic": b.get("traffic"), "traffic_source": b.get("traffic_source"),
+                         "bytes_per_launch": b["bytes_per_launch"], "kernel_ms": b["kernel_ms"],
+                         "valu_issue_frac": b.get("valu_issue"), "wait_frac": b.get("wait_frac"),
+                         "kernel_path_mreads": value, "kernel_path_ms_per_step": step_ms,
+                         "sig_kernel_ms": stage.get("first_seed_kernel"), "list_pass_ms": stage.get("list_pass"), "sort_ms": stage.get("schedule"),
+                         "align_kernel_ms": stage.get("align"), "order_ms": stage.get("sort"),
+                         "sig_kernel_frac": blocks["sketch_sig_kernel"].get("frac"), "align_kernel_frac": blocks["align_kernel"].get("frac"),
+                         "sig_kernel_valu_issue": blocks["sketch_sig_kernel"].get("valu_issue"), "align_kernel_valu_issue": blocks["align_kernel"].get("valu_issue"),
+                         "align_kernel_traffic": blocks["align_kernel"].get("traffic"), "sig_kernel_traffic": blocks["sketch_sig_kernel"].get("traffic"),
+                         "whole_step_bytes": step_bytes, "whole_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "valu_wave_insts_per_batch": valu_insts or None, "valu_issue_floor_ms": valu_floor_ms,
+                         "valu_issue_frac_of_step": (valu_floor_ms / step_ms) if valu_floor_ms else None,
+                         "note": "integer hashing + dependent graph walk: VALU issue binds before HBM does (valu_issue_*); frac = algorithmic bytes / live kernel time / 8 TB/s",
+                         "kernels": blocks},
         }
+        if per_rank is not None:
+            line["per_rank"] = {"ms_per_step": [x[0] for x in per_rank], "allreduce_ms": [x[1] for x in per_rank]}
+            line["roofline"]["allreduce_ms_max"] = max(x[1] for x in per_rank)
+            line["roofline"]["rank_ms_per_step_max"] = max(x[0] for x in per_rank)
+            line["roofline"]["rank_ms_per_step_min"] = min(x[0] for x in per_rank)
+        rf = line["roofline"]
         if world == 1:
             if not args.no_legs and args.background == 0:
+                # the same ctx (memo off) on reads with 1 % substitutions
                 try:
-                    line["robustness"] = robustness(al, index, d_seq, d_off, R, args.leg_steps)
+                    g = torch.Generator(device=dev)
+                    g.manual_seed(0x67726F6F74)
+                    err = substituted(d_seq, R, 0.01, g)
+                    v, ms, c = resident_rate(al, err.data_ptr(), d_off.data_ptr(), R, READ_LEN, args.leg_steps, 2)
+                    del err
+                    line["kernel_path"] = {"what": "the `value` ctx (memo off) on other inputs", "substitutions_1pct": {
+                        "value": v, "unit": "Mreads/s", "stage_ms": ms, "full_sketch_reads": c["full_sketch_reads"], "walked_reads": c["walked_reads"],
+                        "mapped": c["mapped"], "kernels": kernel_blocks("sub1_nomemo", ms, c, R, READ_LEN, pw)}}
+                    rf["sub1_nomemo_mreads"] = v
+                    rf["sub1_nomemo_align_ms"] = ms.get("align")
                 except Exception as e:   # the headline must still print
-                    line["robustness"] = {"error": repr(e)}
+                    line["kernel_path"] = {"error": repr(e)}
             al.close()
             al = None
-            if not args.no_legs:
+            if not args.no_legs and args.background == 0:
+                # the library's default ctx: the memo of groot_hip_open answers reads that equal an indexed WindowSize-mer
                 try:
-                    line["kernel_path"] = kernel_path(index, d_seq, d_off, R, args.leg_steps, local_rank, pw)
+                    alm = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
+                                         results_on_device=True, pipeline_depth=2)
+                    alm.set_profiling(True)
+                    v, ms, c = resident_rate(alm, d_seq.data_ptr(), d_off.data_ptr(), R, READ_LEN, args.leg_steps, 3)
+                    line["memo_tier"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "full_sketch_reads": c["full_sketch_reads"], "walked_reads": c["walked_reads"],
+                                         "mapped": c["mapped"], "alignments": c["alignments"], "open": alm.open_stats(),
+                                         "what": "configs[2] on the default ctx: error-free window-sized reads are the memo's keys -- a table look-up, not the kernels"}
+                    rf["memo_mreads"] = v
+                    line["robustness"] = robustness(alm, index, d_seq, d_off, R, args.leg_steps)
+                    rf["sub1_mreads"] = line["robustness"]["substitutions_1pct"]["value"]
+                    rf["sub1_align_ms"] = line["robustness"]["substitutions_1pct"]["stage_ms"].get("align")
+                    rf["background99_mreads"] = line["robustness"]["background_99pct"]["value"]
+                    alm.close()
                 except Exception as e:
-                    line["kernel_path"] = {"error": repr(e)}
+                    line["memo_tier"] = {"error": repr(e)}
+            if not args.no_legs:
                 try:
                     line["thresholds"] = threshold_sweep(index, d_seq, d_off, R, args.leg_steps, local_rank)
                 except Exception as e:
                     line["thresholds"] = {"error": repr(e)}
                 try:
                     line["mixed"] = mixed_leg(local_rank, args.mixed_reads, args.leg_steps, args.mixed_cli_reads, args.cli_bam_level)
+                    mk = line["mixed"]["kernels"]
+                    rf["mixed99_mreads"] = mk["t=0.99"]["value"]
+                    rf["mixed90_mreads"] = mk["t=0.90"]["value"]
+                    rf["mixed99_list_pass_ms"] = mk["t=0.99"]["stage_ms"].get("list_pass")
+                    rf["mixed99_align_ms"] = mk["t=0.99"]["stage_ms"].get("align")
+                    if "t=0.99, batches of 2 M reads" in mk:
+                        rf["mixed99_2m_mreads"] = mk["t=0.99, batches of 2 M reads"]["value"]
+                    if "value" in line["mixed"].get("cli_gzip", {}):
+                        rf["cli_gzip_mreads"] = line["mixed"]["cli_gzip"]["value"]
                 except Exception as e:
                     line["mixed"] = {"error": repr(e)}
             if not args.no_host_fed:
                 try:
-                    hf_steps = args.host_fed_steps or max(40, int(args.host_fed_seconds / (step_ms * 4e-3)))   # (a host-fed batch takes ~4x a resident step: PCIe)
+                    hf_steps = args.host_fed_steps or max(40, int(args.host_fed_seconds / 5e-3))   # (a host-fed batch of 10 M reads takes ~5 ms: PCIe)
                     hf, _ = host_fed(index, d_seq, R, hf_steps)
                     hf["frac_of_resident"] = hf["value"] / value
                     line["host_fed"] = hf
+                    rf["host_fed_mreads"] = hf["value"]
                 except Exception as e:   # the headline must still print
                     line["host_fed"] = {"error": repr(e)}
             if not args.no_cli:
                 try:
                     line["cli_e2e"] = cli_e2e(index, d_seq, min(args.cli_reads, R), args.cli_bam_level)
+                    rf["cli_e2e_mreads"] = line["cli_e2e"].get("value")
+                    rf["cli_stream_mreads"] = line["cli_e2e"].get("stream_value")
                 except Exception as e:
                     line["cli_e2e"] = {"error": repr(e)}
             if not args.no_cpu:

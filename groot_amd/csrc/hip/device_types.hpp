@@ -136,14 +136,23 @@ __host__ __device__ constexpr uint32_t text_exc_dwords(uint32_t tw)
 // exact-match table entry: windows whose whole sketch equals the query's
 struct ExactEntry { uint32_t tag; uint32_t id; };
 
-// signature-table entry (sketch_sig_kernel): one per window, keyed by the top 27 bits of every sketch slot
-struct alignas(16) SigEntry {
-    uint32_t tag;          // high half of the signature hash
-    uint32_t id;           // window; kEmpty = free slot
+// signature index (sketch_sig_kernel): the windows grouped by the signature of their sketch (kSigG of its slots, kernels_common.hpp).
+// DeviceIndex::sig_dir: open addressing over the DISTINCT signatures, buckets of two {tag, first entry} pairs (one 16-byte load; first = kEmpty: free);
+// DeviceIndex::sig: one entry per window, the windows of a signature back to back, sorted by (sketch class, window id) -- the windows of
+// one class (identical 64-bit sketches: a read's seed set) are neighbours, in ascending id as the exact table returns them.
+struct alignas(32) SigEntry {
+    uint32_t id;           // window
     uint32_t cls;          // windows with identical 64-bit sketches share a class
     uint32_t text_len;     // bits 0..9: bases of the window's text that were verified at open (0: the window cannot confirm a read);
-                           // bits 10..19 / 20..29: first position of the smallest canonical k-mer hash in the forward / reverse-complement row
+                           // bits 10..19 / 20..29: first position of the smallest canonical k-mer hash in the forward / reverse-complement row;
+                           // bit 30 (kSigInline): `verdict` below holds what DeviceIndex::sig_info says for offsets 0..7 of both rows
+    uint32_t group;        // bits 0..23: entries of this signature's group from this one on (the first entry holds the group's size);
+                           // bits 24..31: min(255, contained nodes of the window) (DeviceIndex::win_nodes: the span class of the scheduling key)
+    uint8_t verdict[2][8]; // the verdict byte of the strings at offsets 0..7 of the forward / reverse-complement row (most windows merge fewer than
+                           // eight WindowSize-mers): one 32-byte entry answers what took three more trips (sig_info, win_nodes) for most reads
 };
+static_assert(sizeof(SigEntry) == 32, "signature entry is two 16-byte words");
+constexpr uint32_t kSigInline = 1u << 30;
 constexpr uint32_t kTextMax = 256;       // bases kept per window text (window + merged neighbours), per orientation
 // SigEntry::text_len fields
 __host__ __device__ inline uint32_t sig_text_pack(uint32_t len, uint32_t argmin_fwd, uint32_t argmin_rc) { return len | (argmin_fwd << 10) | (argmin_rc << 20); }
@@ -197,6 +206,7 @@ struct DeviceIndex {
     // the bases it was sketched from -- WindowSize + MergeSpan of them along its first Ref path, 2 bits per base
     // ((byte >> 1) & 3, base j at bits 2*(j%4) of byte j/4): forward row at byte w*2*kTextMax/4, reverse complement kTextMax/4 later; null = not available
     const SigEntry *sig;
+    const uint4 *sig_dir;           // [sig_mask + 1] buckets {tag0, first0, tag1, first1}
     uint32_t sig_mask;
     const uint8_t *win_text;
     // what the seed stage's epilogue works out for a read that IS bases [o, o + WindowSize) of a text row (every such read is

@@ -181,7 +181,8 @@ struct groot_ctx {
     DevBuf<unsigned char> node_rec;
     DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
-    DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature table + window texts (absent: that kernel is not used)
+    DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature index + window texts (absent: that kernel is not used)
+    DevBuf<uint4> sig_dir;
     DevBuf<uint8_t> win_text, win_nodes;
     DevBuf<uint32_t> sig_info;             // per window-text string: verdict byte, or where its tabulated outcome is (DeviceIndex::sig_info)
     DevBuf<uint4> out_tab;                 // AlignRead outcomes of the window-text strings (DeviceIndex::out_tab)
@@ -544,8 +545,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;     // the LIST pass copies each read into its lane's LDS slice
         a.list_stride_dw = list_lds_stride(stride_dw);
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
-        const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;   // (+: the kernel reads whole register rows past a read)
-        launch_sig(c->s, a, s->max_len, grid, lds, c->stream);
+        launch_sig(c->s, a, s->max_len, false, c->stream);
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
         launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
@@ -1613,6 +1613,8 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
     HIP_TRY(c, hipMemcpy(c->out_tab.p, tab.data(), (c->out_entries * sq + 4) * sizeof(uint4), hipMemcpyHostToDevice));
     c->h_out_tab = std::move(tab);
     HIP_TRY(c, hipMemcpy(c->sig_info.p, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sig_inline_off_kernel, dim3((unsigned)((c->sig.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sig.p, (uint32_t)c->sig.n);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (WorkSet &w : c->ws) HIP_TRY(c, w.tab_idx.alloc(c->prm.max_batch_reads));
     HIP_TRY(c, c->tab_hist.alloc(c->n_windows));
     HIP_TRY(c, hipMemset(c->tab_hist.p, 0, (size_t)c->n_windows * sizeof(uint32_t)));
@@ -1656,7 +1658,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
 static int build_signature_index(groot_ctx *c, const groot_index_view *v, const std::vector<uint32_t> &sketch_class)
 {
     const uint32_t n = v->n_windows, s = v->sketch_size, w = v->window_size, k = v->kmer_size;
-    if (c->kn.no_sig || !sig_supported(s, v->max_k, k) || w > kTextMax || w < k || !n) return GROOT_OK;
+    if (c->kn.no_sig || !sig_supported(s, v->max_k, k) || w > kTextMax || w < k || !n || n >= (1u << 24)) return GROOT_OK;   // (SigEntry::group: 24 bits)
     const bool open_stats = c->kn.open_stats;
     auto t_lap = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1773,19 +1775,52 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     for (uint32_t i = 0; i < n; i++) nodes[i] = (uint8_t)std::min<uint32_t>(255, v->win_cn_off[i + 1] - v->win_cn_off[i]);
     lap("argmin + packing");
     if (c->bg_cancel) return GROOT_OK;   // (background build abandoned: nothing of it is installed)
-    // 4. signature table: windows in ascending id (like the exact table: equal sketches keep their relative order along a probe chain)
-    uint32_t cap = 16;
-    while (cap < 2 * (uint64_t)n) cap <<= 1;
-    std::vector<SigEntry> tab(cap, SigEntry{0, kEmpty, 0, 0});
+    // 4. signature index: the windows grouped by the hash of their signature (kSigG slots of the sketch: kernels_common.hpp sig_step -- the slots the
+    //    kernel computes), a group's windows sorted by (sketch class, id); a directory over the distinct signatures says where each group starts
+    const uint32_t m5 = (uint32_t)(((uint64_t)k * GROOT_MULTI_SEED) & 31u);
+    std::vector<uint64_t> key(n);
     for (uint32_t i = 0; i < n; i++) {
         uint64_t x = GROOT_SIG_HASH_INIT;
-        for (uint32_t j = 0; j < s; j++) x = sig_hash_step(x, (uint32_t)(v->win_sketch[(size_t)i * s + j] >> 37));
-        x = sig_hash_fin(x);
-        uint32_t slot = (uint32_t)x & (cap - 1);
-        while (tab[slot].id != kEmpty) slot = (slot + 1) & (cap - 1);
-        tab[slot] = SigEntry{(uint32_t)(x >> 32), i, sketch_class[i], sig_text_pack(tlen[i], argmin[2 * i], argmin[2 * i + 1])};
+        x = sig_hash_step(x, sig_part(0, v->win_sketch[(size_t)i * s]));
+        for (int j = 1; j < kSigG; j++) x = sig_hash_step(x, sig_part(j, v->win_sketch[(size_t)i * s + (uint32_t)(sig_step(j, (int)s, (int)m5) ^ (int)m5)]));
+        key[i] = sig_hash_fin(x);
     }
-    HIP_TRY(c, upload(c->sig, tab.data(), tab.size()));
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (key[a] != key[b]) return key[a] < key[b];
+        if (sketch_class[a] != sketch_class[b]) return sketch_class[a] < sketch_class[b];
+        return a < b;
+    });
+    std::vector<SigEntry> ent((size_t)n + 8, SigEntry{kEmpty, kEmpty, 0, 0, {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}});
+    uint32_t n_keys = 0;
+    for (uint32_t i = 0; i < n;) {
+        uint32_t j = i;
+        while (j < n && key[order[j]] == key[order[i]]) j++;
+        for (uint32_t x = i; x < j; x++) {
+            const uint32_t w_ = order[x];
+            SigEntry e{w_, sketch_class[w_], sig_text_pack(tlen[w_], argmin[2 * w_], argmin[2 * w_ + 1]) | kSigInline, (j - x) | ((uint32_t)nodes[w_] << 24), {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}};
+            for (uint32_t row = 0; row < 2; row++)
+                for (uint32_t o = 0; o < 8 && o < vstride; o++) e.verdict[row][o] = (uint8_t)verdict[((size_t)w_ * 2 + row) * vstride + o];
+            ent[x] = e;
+        }
+        n_keys++;
+        i = j;
+    }
+    uint32_t cap = 16;                                       // buckets of two: load <= 1/4
+    while ((uint64_t)cap * 2 < 4 * (uint64_t)n_keys) cap <<= 1;
+    std::vector<uint32_t> dir((size_t)cap * 4);
+    for (size_t i = 0; i < (size_t)cap; i++) { dir[4 * i] = 0; dir[4 * i + 1] = kEmpty; dir[4 * i + 2] = 0; dir[4 * i + 3] = kEmpty; }
+    for (uint32_t i = 0; i < n; i += ent[i].group & 0xFFFFFFu) {
+        const uint64_t x = key[order[i]];
+        for (uint32_t b = (uint32_t)x & (cap - 1);; b = (b + 1) & (cap - 1)) {
+            uint32_t *q = &dir[(size_t)b * 4];
+            if (q[1] == kEmpty) { q[0] = (uint32_t)(x >> 32); q[1] = i; break; }
+            if (q[3] == kEmpty) { q[2] = (uint32_t)(x >> 32); q[3] = i; break; }
+        }
+    }
+    HIP_TRY(c, upload(c->sig, ent.data(), ent.size()));
+    HIP_TRY(c, upload(c->sig_dir, reinterpret_cast<const uint4 *>(dir.data()), (size_t)cap));
     HIP_TRY(c, upload(c->win_text, packed.data(), packed.size()));
     HIP_TRY(c, upload(c->sig_info, verdict.data(), verdict.size()));
     HIP_TRY(c, upload(c->win_nodes, nodes.data(), nodes.size(), 4));
@@ -1794,6 +1829,7 @@ static int build_signature_index(groot_ctx *c, const groot_index_view *v, const 
     c->build_dix->win_nodes = c->win_nodes.p;
     lap("tables + uploads");
     c->build_dix->sig = c->sig.p;
+    c->build_dix->sig_dir = c->sig_dir.p;
     c->build_dix->sig_mask = cap - 1;
     c->build_dix->win_text = c->win_text.p;
     // 5. outcome table: the align stage itself, once, on every string that confirms reads
@@ -1863,7 +1899,7 @@ static int install_background(groot_ctx *c, bool wait)
     if (st == 4) return GROOT_OK;         // abandoned: the ctx goes on with the full-width kernels (same results)
     const DeviceIndex &b = c->bg_dix;
     c->dix.win_prefix = b.win_prefix;
-    c->dix.sig = b.sig; c->dix.sig_mask = b.sig_mask; c->dix.win_text = b.win_text;
+    c->dix.sig = b.sig; c->dix.sig_dir = b.sig_dir; c->dix.sig_mask = b.sig_mask; c->dix.win_text = b.win_text;
     c->dix.sig_info = b.sig_info; c->dix.sig_verdict_stride = b.sig_verdict_stride; c->dix.win_nodes = b.win_nodes;
     return GROOT_OK;
 }

@@ -373,7 +373,33 @@ __device__ __forceinline__ void seed_epilogue_tab(const SeedArgs &a, const uint3
 
 // ---- helpers the host side shares with the kernels (table hashes, LDS layouts) ----
 #define GROOT_SIG_HASH_INIT 0x2545F4914F6CDD1DULL
-__host__ __device__ __forceinline__ uint64_t sig_hash_step(uint64_t x, uint32_t top27) { return ((x << 13) | (x >> 51)) ^ top27; }
+__host__ __device__ __forceinline__ uint64_t sig_hash_step(uint64_t x, uint32_t top27)
+{
+    x = (x ^ top27) * 0x9E3779B97F4A7C15ULL;
+    return x ^ (x >> 29);
+}
+// sketch_sig_kernel's signature covers kSigG of the S sketch slots (round 5): slot 0 -- the smallest canonical ntHash itself, no multiply -- and
+// the kSigG - 1 slots whose MultiHash multipliers i ^ (k * multiSeed) come first in the kernel's running sum h * C0, h * C0 + h, ...
+// (slot i sits at step d = i ^ M5, M5 = (k * multiSeed) & 31).  A window whose sketch equals a read's has the same value in THOSE
+// slots: no table entry -> no seed, as rigorously as with all S slots; an entry is confirmed by text as before, and a read whose
+// entry cannot be confirmed takes the full-width kernel.  The other S - kSigG slots are never computed for reads this kernel decides.
+#ifndef GROOT_SIG_G
+#define GROOT_SIG_G 13
+#endif
+constexpr int kSigG = GROOT_SIG_G;
+// step d of the j-th signature slot (j = 1..): the j-th smallest d for which slot d ^ m5 exists; -1 if the sketch has too few slots
+__host__ __device__ constexpr int sig_step(int j, int s, int m5)
+{
+    int cnt = 0;
+    for (int d = 0; d < 32; d++) {
+        const int i = d ^ m5;
+        if (i >= 1 && i < s && ++cnt == j) return d;
+    }
+    return -1;
+}
+// what the signature keeps of a 64-bit sketch value: the top 24 bits of slot 0 (the kernel tracks the position of the read's smallest
+// k-mer in the low byte of that slot's running minimum), the top 27 of the others (MultiHash's t ^= t >> 27 leaves them alone)
+__host__ __device__ constexpr uint32_t sig_part(int j, uint64_t v) { return j == 0 ? (uint32_t)(v >> 40) : (uint32_t)(v >> 37); }
 __host__ __device__ __forceinline__ uint64_t sig_hash_fin(uint64_t x)
 {
     x *= 0xff51afd7ed558ccdULL;

@@ -155,6 +155,13 @@ __global__ __launch_bounds__(kBlock) void lsh_heavy_kernel(SeedArgs a)
     }
 }
 
+// the memo has turned DeviceIndex::sig_info into pointers to tabulated outcomes: the verdict bytes inlined in the signature entries no longer say it all
+__global__ __launch_bounds__(kBlock) void sig_inline_off_kernel(SigEntry *ent, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) ent[i].text_len &= ~kSigInline;
+}
+
 // fills the text table at open: string j (tw dwords at 2 bits per base, then its bytes other than ACGT: device_types.hpp
 // text_exc_dwords) with a non-zero sig_info word claims the first free slot of its probe sequence (compare-and-swap on the entry's
 // info word) and writes tag, bases and exceptions; hashed over the bases, twk dwords of them, as the lookup does

@@ -57,16 +57,28 @@ __device__ __forceinline__ void todo_push(const SeedArgs &a, uint32_t r)
 #ifndef GROOT_SIG_MIN_LANES
 #define GROOT_SIG_MIN_LANES 16
 #endif
+#ifndef GROOT_SIG_WALK_MAX
+#define GROOT_SIG_WALK_MAX 16
+#endif
+// windows of a signature's group a read looks at before it gives up and takes the full-width kernel (a wavefront waits for its longest walk; on
+// arg-annot.90 one group in a hundred is larger)
+constexpr uint32_t kSigWalkMax = GROOT_SIG_WALK_MAX;
 constexpr uint32_t kSigMinLanes = GROOT_SIG_MIN_LANES;   // (break-even: ~4 300 wave-instructions of hashing against ~180 per read in the list pass)
 // TW: dwords of a packed read the text comparison handles (reads of up to 16 * TW bases; longer ones take the full-width kernel)
-template <int S, int M5, int TW>
+// BS: threads per workgroup.  64: every wavefront is a workgroup of its own and retires -- frees its registers and LDS for the next one -- as soon as ITS
+// reads are done (the walk through a signature's group of windows is a chain of trips to memory whose length differs from read to read; in a workgroup
+// of four wavefronts three wait for the slowest).  256: one global atomic per 256 reads for the list of reads left to the full-width kernel, which is
+// what counts in a batch where every wavefront has such reads (mixed read lengths).
+template <int S, int M5, int TW, int BS = kBlock, int G = kSigG>
 #ifndef GROOT_SIG_WAVES_LONG
-#define GROOT_SIG_WAVES_LONG 5    // the instance for reads of up to 256 bases compares 16 dwords of text per orientation: at 6 waves (80 VGPRs) it spilled 34-60 of them
+#define GROOT_SIG_WAVES_LONG 4    // the instance for reads of up to 256 bases compares 16 dwords of text per orientation: 4 waves = 128 VGPRs, no spills (at 5 it spilled 28, at 6 34-60)
 #endif
-__global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVES) void sketch_sig_kernel(SeedArgs a)
+__global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVES) * (kBlock / BS)) void sketch_sig_kernel(SeedArgs a)
 {
+    static_assert(BS == 64 || BS == kBlock, "one wavefront or four per workgroup");
     static_assert(S >= 1 && S <= 32 && M5 >= 0 && M5 < 32, "slots i < 32 with a compile-time (k * multiSeed) & 31 only");
     static_assert(TW >= 1 && 16 * TW <= (int)kTextMax, "a read cannot be longer than a window text");
+    static_assert(G >= 1 && (G == 1 || sig_step(G - 1, S, M5) >= 0), "the sketch has fewer slots than the signature wants");
     constexpr int kTextWords = TW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ __attribute__((aligned(512))) unsigned char tab[512];
@@ -75,25 +87,26 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
     const DeviceIndex &ix = a.ix;
     const unsigned tid = threadIdx.x;
     const uint32_t k = ix.k;
-    // table entries: leaving base c -> {rol(seed[c], k), ror(seed[comp c], 1)}, entering base c -> {seed[c], rol(seed[comp c], k-1)}
-    // (ntHash's forward / reverse-strand updates).  Two copies: entries 16 bytes apart for a code sitting at bits 4..5 of a
-    // register, 64 bytes apart for one at bits 6..7 -- the address is then ONE v_and of the shifted code word.
-    if (tid < 4) {
-        const uint64_t f = seed_of_code(tid), fc = seed_of_code(tid ^ 2u);
-        const uint64_t of = rol64(f, k), orv = ror1(fc), iv = f, ir = rol64(fc, k - 1);
-        const uint4 eo = make_uint4((uint32_t)of, (uint32_t)(of >> 32), (uint32_t)orv, (uint32_t)(orv >> 32));
-        const uint4 ei = make_uint4((uint32_t)iv, (uint32_t)(iv >> 32), (uint32_t)ir, (uint32_t)(ir >> 32));
-        *reinterpret_cast<uint4 *>(tab + 16 * tid) = eo;
-        *reinterpret_cast<uint4 *>(tab + 64 + 16 * tid) = ei;
-        *reinterpret_cast<uint4 *>(tab + 256 + 64 * tid) = eo;
-        *reinterpret_cast<uint4 *>(tab + 256 + 16 + 64 * tid) = ei;
+    // ntHash's rolling update XORs two table values into each strand's hash: one for the base that leaves the k-mer, one for the base that enters
+    // (forward: rol(seed[out], k) ^ seed[in]; reverse strand: ror(seed[comp out], 1) ^ rol(seed[comp in], k - 1)).  The table is keyed by the PAIR
+    // (out | in << 2) and holds both strands' values already XORed together: one 16-byte LDS read and four XORs per k-mer.  16 entries at byte
+    // offset 16 * pair (the address is ONE v_and of the shifted code word); behind them the four entries of a base that only enters (first k-mer).
+    if (tid < 16) {
+        const unsigned o = tid & 3u, i = tid >> 2;
+        const uint64_t fo = seed_of_code(o), fco = seed_of_code(o ^ 2u), fi = seed_of_code(i), fci = seed_of_code(i ^ 2u);
+        const uint64_t f = rol64(fo, k) ^ fi, rv = ror1(fco) ^ rol64(fci, k - 1);
+        *reinterpret_cast<uint4 *>(tab + 16 * tid) = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)rv, (uint32_t)(rv >> 32));
+        if (tid < 4) {
+            const uint64_t iv = seed_of_code(tid), ir = rol64(seed_of_code(tid ^ 2u), k - 1);
+            *reinterpret_cast<uint4 *>(tab + 256 + 16 * tid) = make_uint4((uint32_t)iv, (uint32_t)(iv >> 32), (uint32_t)ir, (uint32_t)(ir >> 32));
+        }
     }
-    if (tid < 128) badbits[tid] = 0;
+    for (uint32_t i = tid; i < 128; i += BS) badbits[i] = 0;
     __shared__ uint32_t list_cnt, list_base;               // the reads this workgroup leaves to the list pass
     if (tid == 0) list_cnt = 0;
     // ---- stage this block's reads as 2-bit codes: one contiguous span, 16 bases per lane per load ----
-    const uint32_t r0 = blockIdx.x * kBlock;
-    const uint32_t r_end = min(r0 + (uint32_t)kBlock, a.n_reads);
+    const uint32_t r0 = blockIdx.x * BS;
+    const uint32_t r_end = min(r0 + (uint32_t)BS, a.n_reads);
     const uint64_t span0 = a.seq_off[r0], span1 = a.seq_off[r_end];
     const uint64_t base16 = span0 & ~15ULL;
     const uint64_t span_bytes = span1 - base16;
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
     if (in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
         const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
-        for (uint32_t i = tid; i < n16; i += kBlock) {
+        for (uint32_t i = tid; i < n16; i += BS) {
             const uint4 v = src[i];
             uint32_t bad = 0;
             const uint32_t c = codes_of4(v.x, bad) | (codes_of4(v.y, bad) << 8) | (codes_of4(v.z, bad) << 16) | (codes_of4(v.w, bad) << 24);
@@ -162,34 +175,39 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
         }
     }
 
-    // ---- top 32 bits of the running minima (khf.go:35-55) ----
-    uint32_t m[S];
+    // ---- the signature slots' running minima, top 32 bits (khf.go:35-55) ----
+    // m[0] = min over the k-mers of (top 24 bits of the canonical hash | k-mer index): slot 0 of the sketch IS the smallest canonical hash, and the
+    // index of the k-mer that holds it says where the read lies inside a window text.  m[j], j >= 1: slot sig_step(j) ^ M5.
+    uint32_t m[G];
 #pragma unroll
-    for (int i = 0; i < S; i++) m[i] = ~0u;
+    for (int i = 0; i < G; i++) m[i] = ~0u;
     const uint64_t C0 = ((uint64_t)k * GROOT_MULTI_SEED) & ~31ULL;
     uint64_t fh = 0, rh = 0;
-    uint32_t key0 = ~0u, kj = 0;     // smallest (top 24 bits of h | k-mer index): where the read's smallest k-mer is (ties: see the text compare)
+    uint32_t kj = 0;
     auto ent = [&](uint32_t byte_off) { return *reinterpret_cast<const uint4 *>(tab + byte_off); };
-    auto roll = [&](const uint4 eo, const uint4 ei) {
+    auto roll = [&](const uint4 e) {
         const uint32_t fl = (uint32_t)fh, fu = (uint32_t)(fh >> 32), rl = (uint32_t)rh, ru = (uint32_t)(rh >> 32);
-        const uint32_t nfl = __builtin_amdgcn_alignbit(fl, fu, 31) ^ eo.x ^ ei.x, nfu = __builtin_amdgcn_alignbit(fu, fl, 31) ^ eo.y ^ ei.y;   // rol 1
-        const uint32_t nrl = __builtin_amdgcn_alignbit(ru, rl, 1) ^ eo.z ^ ei.z, nru = __builtin_amdgcn_alignbit(rl, ru, 1) ^ eo.w ^ ei.w;     // ror 1
+        const uint32_t nfl = __builtin_amdgcn_alignbit(fl, fu, 31) ^ e.x, nfu = __builtin_amdgcn_alignbit(fu, fl, 31) ^ e.y;   // rol 1
+        const uint32_t nrl = __builtin_amdgcn_alignbit(ru, rl, 1) ^ e.z, nru = __builtin_amdgcn_alignbit(rl, ru, 1) ^ e.w;     // ror 1
         fh = (uint64_t)nfl | ((uint64_t)nfu << 32);
         rh = (uint64_t)nrl | ((uint64_t)nru << 32);
     };
     auto slots = [&]() {
         const uint64_t h = fh < rh ? fh : rh;              // canonical
-        m[0] = min(m[0], (uint32_t)(h >> 32));
-        key0 = min(key0, ((uint32_t)(h >> 32) & ~255u) | kj);
-        kj++;
         const uint32_t hl = (uint32_t)h, hu = (uint32_t)(h >> 32);
-        uint64_t acc = (uint64_t)hl * (uint32_t)C0;        // h * C0 = h * c_i for the slot with (i ^ M5) == 0
-        acc += (uint64_t)(hl * (uint32_t)(C0 >> 32) + hu * (uint32_t)C0) << 32;
+        m[0] = min(m[0], (hu & ~255u) | kj);
+        kj++;
+        if constexpr (G > 1) {
+            uint64_t acc = (uint64_t)hl * (uint32_t)C0;    // h * C0 = h * c_i for the slot with (i ^ M5) == 0
+            acc += (uint64_t)(hl * (uint32_t)(C0 >> 32) + hu * (uint32_t)C0) << 32;
+            int at = 0;
 #pragma unroll
-        for (int d = 0; d < 32; d++) {
-            const int i = d ^ M5;
-            if (i >= 1 && i < S) m[i] = min(m[i], (uint32_t)(acc >> 32));
-            acc += h;
+            for (int j = 1; j < G; j++) {
+                const int d = sig_step(j, S, M5);
+                acc += (uint64_t)(d - at) * h;             // (d - at: a compile-time 0, 1 or small step over slots the sketch does not have)
+                at = d;
+                m[j] = min(m[j], (uint32_t)(acc >> 32));
+            }
         }
     };
     const uint32_t P = 2u * (uint32_t)(o0 - base16);       // bit position of base 0 in `codes`
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
             lo = nx;
             const uint32_t cnt = min(16u, k - i);
             for (uint32_t j = 0; j < cnt; j++) {
-                roll(make_uint4(0, 0, 0, 0), ent(64 + ((uint32_t)t & 0x30u)));
+                roll(ent(256 + ((uint32_t)t & 0x30u)));
                 t >>= 2;
             }
         }
@@ -214,16 +232,18 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
         uint32_t li = codes[di], ln = codes[dn];
         while (left >= 16) {
             const uint32_t ni = codes[++di], nn = codes[++dn];
-            const uint32_t wi = __builtin_amdgcn_alignbit(ni, li, si), wo = __builtin_amdgcn_alignbit(nn, ln, sn);
+            const uint32_t wi = __builtin_amdgcn_alignbit(ni, li, si), wo = __builtin_amdgcn_alignbit(nn, ln, sn);   // 16 entering / 16 leaving codes
             li = ni; ln = nn;
-            uint64_t ti = (uint64_t)wi << 4, to = (uint64_t)wo << 4;     // code of the pair's first base at bits 4..5, second at 6..7
+            // pairs (out | in << 2) of the even k-mers 0, 2, .. 14 in the nibbles of pe, of the odd ones in po; both pre-shifted to bits 4..7
+            uint64_t pe = (uint64_t)((wo & 0x33333333u) | ((wi << 2) & 0xCCCCCCCCu)) << 4;
+            uint64_t po = (uint64_t)(((wo >> 2) & 0x33333333u) | (wi & 0xCCCCCCCCu)) << 4;
 #pragma unroll 1
             for (int p = 0; p < 8; p++) {
-                const uint32_t a0 = (uint32_t)to & 0x30u, b0 = (uint32_t)ti & 0x30u, a1 = (uint32_t)to & 0xC0u, b1 = (uint32_t)ti & 0xC0u;
-                ti >>= 4; to >>= 4;
-                roll(ent(a0), ent(64 + b0));
+                const uint32_t a0 = (uint32_t)pe & 0xF0u, a1 = (uint32_t)po & 0xF0u;
+                pe >>= 4; po >>= 4;
+                roll(ent(a0));
                 slots();
-                roll(ent(256 + a1), ent(256 + 16 + b1));
+                roll(ent(a1));
                 slots();
             }
             left -= 16;
@@ -231,7 +251,7 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
         if (left) {
             const uint32_t wi = __builtin_amdgcn_alignbit(codes[di + 1], li, si), wo = __builtin_amdgcn_alignbit(codes[dn + 1], ln, sn);
             for (uint32_t j = 0; j < left; j++) {
-                roll(ent(((wo >> (2 * j)) & 3u) << 4), ent(64 + (((wi >> (2 * j)) & 3u) << 4)));
+                roll(ent((((wo >> (2 * j)) & 3u) | (((wi >> (2 * j)) & 3u) << 2)) << 4));
                 slots();
             }
         }
@@ -239,8 +259,9 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
 
     // ---- ContainmentIndex.Query (lshe.go:153-175), every slot must be equal ----
     uint64_t x = GROOT_SIG_HASH_INIT;
+    x = sig_hash_step(x, m[0] >> 8);
 #pragma unroll
-    for (int i = 0; i < S; i++) x = sig_hash_step(x, m[i] >> 5);
+    for (int i = 1; i < G; i++) x = sig_hash_step(x, m[i] >> 5);
     x = sig_hash_fin(x);
     const uint32_t tag = (uint32_t)(x >> 32);
     // the read as packed codes in registers, and a comparison with len bases of a packed text row starting at base o
@@ -270,46 +291,18 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
     }
     SeedAhead ahead;
     const bool use_table = ix.sig_info && len == ix.w && a.sort_key;   // the epilogue's answers for window-sized text reads exist already
-    uint32_t vbyte = 0, nodes_ahead = 0, first_id = kEmpty;
+    uint32_t vbyte = 0, nodes_ahead = 0, conf_id = kEmpty;
     bool have_vbyte = false;
-    const uint32_t j0 = key0 & 255u;
-    uint32_t n_tagged = 0, only_id = kEmpty, cls = kEmpty;
-    const uint4 *sig = reinterpret_cast<const uint4 *>(ix.sig);
-    for (uint32_t slot = (uint32_t)x & ix.sig_mask;; slot = (slot + 1) & ix.sig_mask) {
-        const uint4 e = sig[slot];                         // {tag, id, cls, sig_text_pack(text_len, argmin fwd, argmin rc)}
-        if (e.y == kEmpty) break;
-        if (e.x != tag) continue;
-        n_tagged++;
-        only_id = e.y;
-        if (n_tagged == 1) first_id = e.y;
-        if (n_tagged == 1 && use_table) nodes_ahead = ix.win_nodes[e.y];
-        else if (n_tagged == 1 && len >= 12 && a.sort_key) {    // most likely the read's only seed: what the verdicts will need, in flight now
-            ahead.win = e.y;
-            load32(ix.win_rec + e.y, ahead.wa, ahead.wb);
-            const uint32_t *tab = ix.win_prefix + (size_t)e.y * kPrefixWords;
-            ahead.tf_a = tab[(code_f & 0xFFFu) >> 5]; ahead.tf_b = tab[128 + (code_f >> 17)];
-            ahead.tr_a = tab[(code_r & 0xFFFu) >> 5]; ahead.tr_b = tab[128 + (code_r >> 17)];
-        }
-        const uint32_t tl = sig_text_len(e.w);
-        if (cls != kEmpty || tl < len) continue;
-        // the text's smallest k-mer (first occurrence) must be the read's: that fixes the offset, per orientation
-        const uint8_t *rows = ix.win_text + (size_t)e.y * (2 * kTextMax / 4);
-        const uint32_t of = sig_text_argmin(e.w, 0) - j0, orc = sig_text_argmin(e.w, 1) - j0;
-        const bool okf = of <= tl - len, okr = orc <= tl - len;
-        uint32_t vf = 0, vr = 0;
-        if (use_table) {
-            const uint32_t *vt = ix.sig_info + (size_t)e.y * 2 * ix.sig_verdict_stride;
-            if (okf) vf = vt[of];
-            if (okr) vr = vt[ix.sig_verdict_stride + orc];
-        }
-        const uint32_t df = okf ? row_differs(rows, of) : 1u, dr = okr ? row_differs(rows + kTextMax / 4, orc) : 1u;
-        if (!df || !dr) {
-            cls = e.z;
-            have_vbyte = use_table;
-            vbyte = !df ? vf : vr;
-        }
+    const uint32_t j0 = m[0] & 255u;
+    // directory: the group of windows with this signature, if any (buckets of two; a free place ends the search)
+    uint32_t first = kEmpty;
+    for (uint32_t b = (uint32_t)x & ix.sig_mask;; b = (b + 1) & ix.sig_mask) {
+        const uint4 d = ix.sig_dir[b];
+        if (d.y != kEmpty && d.x == tag) { first = d.y; break; }
+        if (d.y == kEmpty) break;
+        if (d.w != kEmpty && d.z == tag) { first = d.w; break; }
+        if (d.w == kEmpty) break;
     }
-    if (n_tagged && cls == kEmpty) { todo_push(a, r); return; }
     uint32_t n_hits = 0, min_win = kEmpty;
     uint32_t s0 = kEmpty, s1 = kEmpty, s2 = kEmpty, s3 = kEmpty;
     bool asc = true;
@@ -317,21 +310,75 @@ __global__ __launch_bounds__(kBlock, TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_W
     auto hit = [&](uint32_t id) {
         if (n_hits < a.seed_slots) a.seed_win[(size_t)n_hits * a.n_reads + r] = id;
         if (n_hits == 0) s0 = id; else if (n_hits == 1) s1 = id; else if (n_hits == 2) s2 = id; else if (n_hits == 3) s3 = id;
-        asc &= n_hits == 0 || id > prev_id;                // (the exact / signature tables return windows in ascending id)
+        asc &= n_hits == 0 || id > prev_id;                // (a class's windows follow each other in ascending id)
         prev_id = id;
         n_hits++;
         min_win = min(min_win, id);
         max_win = max(max_win, id);
     };
-    if (n_tagged == 1) hit(only_id);
-    else if (n_tagged)
-        for (uint32_t slot = (uint32_t)x & ix.sig_mask;; slot = (slot + 1) & ix.sig_mask) {
-            const uint4 e = sig[slot];
-            if (e.y == kEmpty) break;
-            if (e.x == tag && e.z == cls) hit(e.y);
+    if (first != kEmpty) {
+        // The group: windows that share the kSigG signature slots -- neighbouring windows of a sequence and its alleles, half a dozen on
+        // arg-annot.90 --, sorted by (sketch class, id).  The first window whose text holds the read confirms it; the read's seeds are then ALL
+        // windows of that window's class (identical 64-bit sketches), which sit around it.
+        const uint4 *grp = reinterpret_cast<const uint4 *>(ix.sig) + 2 * (size_t)first;
+        uint32_t n_grp = 1, cls = kEmpty, run0 = 0, run_cls = kEmpty, i = 0;
+        // Two nested loops, so that a wavefront pays for a text comparison only when a lane HAS a candidate: the inner one is a few instructions per
+        // entry -- the text's smallest k-mer (first occurrence) must be the read's, which fixes where the read would lie in the text, per orientation;
+        // most windows of a group (the same sequence a few bases on) fail that --, the outer one compares.  (One loop that did both ran the comparison's
+        // instructions for every entry any lane looked at: 1 600 of the kernel's 4 400 instructions per wavefront.)
+        while (cls == kEmpty) {
+            uint4 e = make_uint4(0, 0, 0, 0);               // {id, class, sig_text_pack(text_len, argmin fwd, argmin rc) | kSigInline, entries left | nodes << 24}
+            uint32_t of = 0, orc = 0, tl = 0;
+            bool okf = false, okr = false;
+            for (; i < n_grp && i < kSigWalkMax; i++) {
+                e = grp[2 * i];
+                if (i == 0) n_grp = e.w & 0xFFFFFFu;
+                if (e.y != run_cls) { run_cls = e.y; run0 = i; }
+                tl = sig_text_len(e.z);
+                of = sig_text_argmin(e.z, 0) - j0; orc = sig_text_argmin(e.z, 1) - j0;
+                okf = tl >= len && of <= tl - len; okr = tl >= len && orc <= tl - len;
+                if (okf || okr) break;
+            }
+            if (!(okf || okr)) break;                        // the group holds no (further) window whose text could be the read
+            // the candidate: verdict bytes (second half of the entry, or the table for offsets beyond 7) and the text row(s), in flight together
+            const uint4 ev = grp[2 * i + 1];
+            const uint8_t *rows = ix.win_text + (size_t)e.x * (2 * kTextMax / 4);
+            uint32_t vf = 0, vr = 0;
+            if (use_table) {
+                const bool inl = (e.z & kSigInline) != 0;
+                const uint32_t *vt = ix.sig_info + (size_t)e.x * 2 * ix.sig_verdict_stride;
+                if (okf) vf = inl && of < 8u ? ((of < 4u ? ev.x : ev.y) >> (8u * (of & 3u))) & 0xFFu : vt[of];
+                if (okr) vr = inl && orc < 8u ? ((orc < 4u ? ev.z : ev.w) >> (8u * (orc & 3u))) & 0xFFu : vt[ix.sig_verdict_stride + orc];
+                nodes_ahead = e.w >> 24;
+            } else if (len >= 12 && a.sort_key) {          // what the verdicts will need if this is the read's first seed
+                ahead.win = e.x;
+                load32(ix.win_rec + e.x, ahead.wa, ahead.wb);
+                const uint32_t *tabp = ix.win_prefix + (size_t)e.x * kPrefixWords;
+                ahead.tf_a = tabp[(code_f & 0xFFFu) >> 5]; ahead.tf_b = tabp[128 + (code_f >> 17)];
+                ahead.tr_a = tabp[(code_r & 0xFFFu) >> 5]; ahead.tr_b = tabp[128 + (code_r >> 17)];
+            }
+            // one comparison for the orientation that fits (both fit for one text in a thousand: then a second one)
+            const bool first_f = okf;
+            uint32_t d0 = row_differs(first_f ? rows : rows + kTextMax / 4, first_f ? of : orc);
+            bool hit_f = first_f && !d0, hit_r = !first_f && !d0;
+            if (d0 && okf && okr) hit_r = row_differs(rows + kTextMax / 4, orc) == 0;
+            if (hit_f || hit_r) {
+                cls = e.y;
+                conf_id = e.x;
+                have_vbyte = use_table;
+                vbyte = hit_f ? vf : vr;
+            }
+            i++;
         }
+        if (cls == kEmpty) { todo_push(a, r); return; }      // a window with this signature, none whose text is the read: the full-width kernel decides
+        for (uint32_t i = run0; i < n_grp; i++) {
+            const uint4 e = grp[2 * i];
+            if (e.y != cls) break;
+            hit(e.x);
+        }
+    }
     if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte, s0, s1, s2, s3);
-    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == first_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc, max_win);
+    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == conf_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc, max_win);
     else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead, asc, max_win);   // all bytes are ACGT
 }
 

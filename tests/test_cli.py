@@ -234,6 +234,9 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["per_step_counts"]["received"] == 300000 and "cpu_baseline" not in line
+    # every rank's own step time and its all-reduce time are on the line, so that a scaling run can be read rank by rank
+    assert len(line["per_rank"]["ms_per_step"]) == 2 and len(line["per_rank"]["allreduce_ms"]) == 2 and min(line["per_rank"]["ms_per_step"]) > 0
+    assert line["roofline"]["allreduce_ms_max"] >= 0 and line["roofline"]["rank_ms_per_step_max"] >= line["roofline"]["rank_ms_per_step_min"]
     one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "300000", "--no-cpu",
                           "--leg-steps", "2", "--mixed-reads", "30000", "--mixed-cli-reads", "5000", "--host-fed-seconds", "0.3"],
                          cwd=REPO, capture_output=True, timeout=900)
@@ -247,6 +250,16 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     assert set(single["thresholds"]) == {"t=0.97", "t=0.95", "t=0.90"} and all(v["value"] > 0 for v in single["thresholds"].values())
     assert set(single["mixed"]["kernels"]) == {"t=0.99", "t=0.97", "t=0.95", "t=0.90"} and single["mixed"]["cli_gzip"].get("value", 0) > 0, single["mixed"]
     assert single["roofline"]["frac"] > 0 and single["cpu_baseline"] if "cpu_baseline" in single else True
+    # `value` is the rate through the hashing and graph-walk kernels (memo off): every read was walked, none answered from a table; the flat
+    # scalars the driver keeps say how fast those kernels are and what the legs reached
+    c = single["config"]
+    assert c["walked_reads"] == c["mapped"] > 0.9 * 300000 and "memo OFF" in c["workload"], c
+    rf = single["roofline"]
+    assert rf["kernel"] in ("sketch_sig_kernel", "align_kernel", "sketch_seed_kernel<LIST>") and rf["kernel_path_mreads"] == single["value"]
+    for k in ("sig_kernel_ms", "align_kernel_ms", "order_ms", "whole_step_frac", "memo_mreads", "sub1_mreads", "sub1_nomemo_mreads", "mixed99_mreads",
+              "mixed90_mreads", "host_fed_mreads", "cli_e2e_mreads"):
+        assert isinstance(rf.get(k), float) and rf[k] > 0, (k, rf.get(k))
+    assert single["memo_tier"]["walked_reads"] < 0.05 * 300000 and single["kernel_path"]["substitutions_1pct"]["value"] > 0
     assert single["cli_e2e"].get("value", 0) > 0 and single["cli_e2e"]["reads"] == 300000, single["cli_e2e"]
 
 
