@@ -655,24 +655,21 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             if (g == done_graph) continue;                    // graphminion.go:96-98: stop after the first alignment
             }
             if (a.update_weights && !(cls & kClsHelper)) {     // :67 IncrementSubPath
-                // neighbouring lanes mostly hold reads of the same window (processing order): one atomic per distinct cell
-                // among the lanes that are here together instead of one per lane (0.44 of 3.15 ms per 10 M reads)
+                // neighbouring lanes mostly hold reads of the same window (processing order): one atomic per RUN of equal cells among the lanes
+                // that are here together -- a lane whose cell differs from that of the lane before it adds the length of its run (round 4 looped over
+                // the distinct cells)
                 const uint64_t cell = (uint64_t)qrow * ix.n_windows + w;
-                // (... when they do: if the first lane's cell is shared by fewer than a quarter of the lanes here, the reads are unrelated --
-                // mixed lengths, reads with errors -- and a lane each is cheaper than a trip round this loop per distinct cell)
-                const uint64_t cell0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cell) |
-                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cell >> 32)) << 32);
-                const bool together = 4 * __popcll(__ballot(cell == cell0)) >= __popcll(__ballot(1));
-                if (!together) atomicAdd(&a.attempts[cell], 1u);
-                for (bool pending = together; pending;) {
-                    const uint64_t first = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cell) |
-                                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cell >> 32)) << 32);
-                    const unsigned long long same = __ballot(cell == first);
-                    if (cell == first) {
-                        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u)) == 0)
-                            atomicAdd(&a.attempts[first], (uint32_t)__popcll(same));
-                        pending = false;
-                    }
+                const unsigned long long here = __ballot(1);
+                const unsigned lane_ = threadIdx.x & 63u;
+                const unsigned long long below = here & ((1ull << lane_) - 1ull);
+                const int prev = below ? 63 - __builtin_clzll(below) : -1;                 // the lane before this one among those here
+                const uint32_t plo = __shfl((uint32_t)cell, prev < 0 ? (int)lane_ : prev), phi = __shfl((uint32_t)(cell >> 32), prev < 0 ? (int)lane_ : prev);
+                const bool head = prev < 0 || plo != (uint32_t)cell || phi != (uint32_t)(cell >> 32);
+                const unsigned long long heads = __ballot(head);
+                if (head) {
+                    const unsigned long long after = lane_ == 63u ? 0ull : heads & ~((2ull << lane_) - 1ull);   // the next run's head
+                    const unsigned long long run = here & ~((1ull << lane_) - 1ull) & (after ? ((1ull << (__ffsll(after) - 1)) - 1ull) : ~0ull);
+                    atomicAdd(&a.attempts[cell], (uint32_t)__popcll(run));
                 }
             }
             GROOT_SUBT(3);

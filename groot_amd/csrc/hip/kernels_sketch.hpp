@@ -33,7 +33,8 @@ namespace groot {
 #ifndef GROOT_LIST_ROWS_AHEAD
 #define GROOT_LIST_ROWS_AHEAD 2
 #endif
-constexpr int seed_waves(int S, bool list = false) { return S == 0 ? 1 : (S <= 30 ? (list ? (S <= 24 ? GROOT_LIST_WAVES : 3) : GROOT_SEED_WAVES) : (S <= 48 ? 3 : 2)); }
+// (round 5: sketch sizes 22..30 at 4 waves -- they spilled 31..95 VGPRs at 5 --, 45 and more at 2 -- 48 spilled 293 at 3; tools/kernel_meta.sh)
+constexpr int seed_waves(int S, bool list = false) { return S == 0 ? 1 : (S <= 30 ? (list ? (S <= 24 ? GROOT_LIST_WAVES : 3) : (S <= 21 ? GROOT_SEED_WAVES : 4)) : (S <= 44 ? 3 : 2)); }
 template <int S, int MAXK, bool DUMP, int M5, bool LIST = false>
 __global__ __launch_bounds__(kBlock, seed_waves(S, LIST)) void sketch_seed_kernel(SeedArgs a)
 {
