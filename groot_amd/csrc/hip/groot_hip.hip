@@ -74,13 +74,14 @@ template <class T> struct PinBuf {
 // compare the tiers with each other and with the CPU checker); TEST_SMALL_BUFFERS starts every growable buffer and list too small, so that
 // a test batch walks the grow-and-redo and the fall-back paths; OPEN_STATS prints where groot_hip_open spent its time.
 struct Knobs {
-    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false;
+    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false, poison = false;
     static Knobs read()
     {
         Knobs k;
         k.no_outcome_table = getenv("GROOT_NO_OUTCOME_TABLE") != nullptr; k.no_text_table = getenv("GROOT_NO_TEXT_TABLE") != nullptr;
         k.no_sig = getenv("GROOT_NO_SIG") != nullptr;                     k.force_rccl = getenv("GROOT_FORCE_RCCL") != nullptr;
         k.small_buffers = getenv("GROOT_TEST_SMALL_BUFFERS") != nullptr;  k.open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
+        k.poison = getenv("GROOT_TEST_POISON") != nullptr;
         return k;
     }
 };
@@ -727,6 +728,18 @@ static int run_batch_async(groot_ctx *c, Slot *s, bool update_weights)
     // compute stream: the seed stage, once the batch that used this work set last is through its order stage
     if (w->used) HIP_TRY(c, hipStreamWaitEvent(c->stream, w->ev_free, 0));
     HIP_TRY(c, hipMemsetAsync(s->d_ctr.p, 0, sizeof(DeviceCounters), c->stream));
+    if (c->kn.poison) {
+        // GROOT_TEST_POISON: what the seed stage writes per read is wiped first.  A work set keeps the values of the batch that used it last, and a
+        // stream of equal batches hides a read that no kernel of the seed stage handled -- round 4's one-in-a-million signature kernel dropped a
+        // dozen reads per 10 M from the list of the full-width pass, visible only in the first batch through each work set (tools/first_use_check.py)
+        const size_t n = s->n_reads;
+        HIP_TRY(c, hipMemsetAsync(w->seed_count.p, 0, n * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(w->read_rec.p, 0, n * sizeof(ReadRec), c->stream));
+        HIP_TRY(c, hipMemsetAsync(w->trav_cnt.p, 0, n * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->sort_key.p, 0xFF, n * sizeof(uint32_t), c->stream));
+        if (w->tab_idx.p) HIP_TRY(c, hipMemsetAsync(w->tab_idx.p, 0xFF, n * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->todo_list.p, 0, n * sizeof(uint32_t), c->stream));
+    }
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[1], c->stream));
     if (int rc = launch_seed_stage(c, s, update_weights)) return rc;
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[3], c->stream));

@@ -146,3 +146,44 @@ def test_every_compiled_instance_and_long_windows(msa_dir, monkeypatch, k, s, w)
     else:
         assert counts["full_sketch_reads"] < counts["received"]
     al.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("memo", ["off", "on"])
+def test_no_read_is_left_out_by_the_seed_stage(argannot_index, monkeypatch, memo):
+    """Every read of every batch is handled by exactly one kernel of the seed stage -- text lookup, signature kernel, list pass, heavy LSH-Forest
+    reads --: with GROOT_TEST_POISON the per-read outputs of the seed stage are wiped before each batch, so a read that fell between the kernels
+    (round 4: a signature kernel whose workgroup-level list bookkeeping dropped a dozen reads per 10 M from the full-width pass's list) shows as a
+    read without seeds.  Without the wipe a stream of equal batches hides it: the work set still holds the right values from its last use, and only
+    the FIRST batch through each of the two work sets is wrong (tools/first_use_check.py).  3 M reads per batch, six batches, all alike."""
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("GROOT_TEST_POISON", "1")
+    index = argannot_index
+    cat, o, lens = synth.reference_sequences(index)
+    R = 3_000_000
+    seq, off, _ = synth.reads_np(cat, o, lens, R, 100, first=12345)
+    al = device.Aligner(index, max_batch_reads=R, max_read_len=128, max_batch_bases=R * 100 + 64, memo_budget_mb=device.MEMO_OFF if memo == "off" else 0)
+    ref = None
+    for b in range(6):
+        al.submit(seq, off)
+        c = al.wait()
+        t, m = al.travs()
+        cnt = np.bincount(t["read_id"], minlength=R)
+        if ref is None:
+            ref, c0, t0, m0 = cnt, c, t, m
+        else:
+            bad = np.flatnonzero(cnt != ref)
+            assert len(bad) == 0 and c == c0, "batch %d: %d reads differ from batch 0, first: %s" % (b, len(bad), bad[:8])
+    al.close()
+    # ... and batch 0 itself is right: the oracle on a sample
+    pick = np.sort(np.random.default_rng(9).choice(R, 20_000, replace=False))
+    rows = seq[: R * 100].reshape(R, 100)[pick].reshape(-1).copy()
+    orc = O.Run(index, 0.99)
+    orc.batch(rows, np.arange(20_001, dtype=np.uint64) * 100)
+    oal = orc.alns()
+    sel = np.isin(t0["read_id"], pick)
+    got = device.expand_alns(index, t0[sel], m0[sel])
+    assert len(got) == len(oal) and np.array_equal(np.searchsorted(pick, got["read_id"]), oal["read_id"])
+    for f in ("graph_id", "path_id", "ref_id", "pos", "start_clip", "end_clip", "rc", "secondary"):
+        assert np.array_equal(got[f], oal[f]), f
