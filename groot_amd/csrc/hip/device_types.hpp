@@ -237,7 +237,8 @@ struct SeedArgs {
     uint32_t *seed_win;          // [H][n_reads] slot-major
     uint64_t *sketch_out;        // [n_reads*s] or null
     uint32_t *sort_key;          // [n_reads] (node span class, first seed window, orientation class), kEmpty without seeds; or null
-    uint32_t sort_span_bits;     // top bits of sort_key that hold min(contained nodes of the window, 2^bits-1); 0 = none
+    uint32_t sort_span_bits;     // bits of sort_key that hold the span class 2^bits-1 - min(contained nodes of the window, 2^bits-1); 0 = none
+    uint32_t sort_span_shift;    // ... and where they sit: right above window << 2 | class, so that the sort runs over as few bits as the index needs
     ReadRec *read_rec;           // [n_reads]
     uint32_t *q_seen;            // [max_q + 1] set for every kmerCount of a seeded read that has no row yet; or null
     uint32_t *trav_cnt;          // [n_reads] traversal counts of the align stage: zeroed here for reads without seeds (it skips them); or null

@@ -494,11 +494,16 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     }
     // processing order of the align stage: reads sorted by (node span of the first seed window, that window, likely
     // orientation).  key = span << (32-span_bits) | window << 2 | class; reads without seeds carry 0xFFFFFFFF and sort last
-    unsigned win_bits = 3;                                  // 2 class bits + one bit above the largest window id
-    for (uint32_t v = c->n_windows; v; v >>= 1) win_bits++;
-    win_bits = std::min(32u, win_bits);
+    unsigned win_bits = 2;                                  // 2 class bits + the bits of the largest window id
+    for (uint32_t v = c->n_windows ? c->n_windows - 1 : 0; v; v >>= 1) win_bits++;
+    win_bits = std::min(32u, std::max(3u, win_bits));
+    // (round 5: the span class sits right above the window bits, five bits when that makes the sorted range 24 bits -- three passes of the radix sort
+    // instead of four; the two class bits below the window are not sorted on: reads of one window are neighbours either way)
     a.sort_span_bits = std::min((unsigned)GROOT_SPAN_BITS, 32u - win_bits);
-    const unsigned end_bit = a.sort_span_bits ? 32u : win_bits;
+    if (win_bits - 2u + a.sort_span_bits > 24u && win_bits - 2u + 4u <= 24u) a.sort_span_bits = 24u - (win_bits - 2u);
+    // (reads without seeds carry 0xFFFFFFFF: all ones in the span field, which no window has -- every window contains a node -- so they sort last)
+    a.sort_span_shift = win_bits;
+    const unsigned begin_bit = 2u, end_bit = win_bits + a.sort_span_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
     const uint32_t list_blocks = 1280u;   // workgroups of the list pass (grid-stride; 5 per CU)
     // a batch of one read length that is not on the exact-table branch (lower thresholds, reads shorter than the windows) would
@@ -598,14 +603,14 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     size_t tmp_bytes = 0;
     // keys are (window << 2 | class) below 2^end_bit, or 0xFFFFFFFF for reads without seeds: sorting the low
     // end_bit bits keeps those last as long as bit end_bit-1.. are all ones for them, which they are
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, w->perm.p, s->n_reads, 0,
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, w->perm.p, s->n_reads, begin_bit,
                                          end_bit, c->stream));
     if (tmp_bytes > c->sort_tmp.n) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, c->sort_tmp.alloc(tmp_bytes + tmp_bytes / 4));
     }
     HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->sort_key.p, c->sort_key_out.p, c->perm_in.p, w->perm.p,
-                                         s->n_reads, 0, end_bit, c->stream));
+                                         s->n_reads, begin_bit, end_bit, c->stream));
     return GROOT_OK;
 }
 

@@ -286,7 +286,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
                 // windows spanning a similar number of nodes need similar numbers of DFS steps: keep them together, and
                 const uint32_t nn = min(wr.cn_end - wr.cn_off, (1u << a.sort_span_bits) - 1u);
                 // longest walks first: the slow chunks are handed out early and the short ones fill the tail of the launch
-                key |= (((1u << a.sort_span_bits) - 1u) - nn) << (32u - a.sort_span_bits);
+                key |= (((1u << a.sort_span_bits) - 1u) - nn) << a.sort_span_shift;
             }
         }
         a.sort_key[r] = key;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
     a.seed_count[r] = n_hits;
     if (a.sort_key) {
         uint32_t key = (min_win << 2) | (vbyte >> 6);
-        if (a.sort_span_bits) key |= (((1u << a.sort_span_bits) - 1u) - min(nodes, (1u << a.sort_span_bits) - 1u)) << (32u - a.sort_span_bits);
+        if (a.sort_span_bits) key |= (((1u << a.sort_span_bits) - 1u) - min(nodes, (1u << a.sort_span_bits) - 1u)) << a.sort_span_shift;
         a.sort_key[r] = key;
     }
     if (a.read_rec) {
