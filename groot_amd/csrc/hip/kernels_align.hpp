@@ -786,31 +786,30 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
             // is a trip to L2 whatever it computes, and the general step hides some of it.)
             bool fast_done = false;
             {
-                // (every test evaluated, ONE branch instead of a chain of && -- a saved exec mask and a jump per condition in the ISA; measured in round 5: the same 2.88 ms either way)
-                const uint32_t slen = rec.seq_len(), ef = eff();
-                const uint32_t take = min(slen, ef - dist);
+                const uint32_t take = min(rec.seq_len(), eff() - dist);
                 const uint32_t rdeg = rec.deg();
-                const bool shape = (coff == 0) & (take - 1u < 8u) & (take == slen) & (dist + take < ef) & !rec.wild() & (rdeg - 1u < 4u);
-                const bool eqp = prefix_eq(rec.first8(), cur8, shape ? take : 1u);
-                uint64_t nm[PW];
-                bool any = false;
+                if (coff == 0 && take >= 1 && take <= 8 && take == rec.seq_len() && dist + take < eff() && !rec.wild() && rdeg >= 1 && rdeg <= 4 &&
+                    prefix_eq(rec.first8(), cur8, take)) {
+                    uint64_t nm[PW];
+                    bool any = false;
 #pragma unroll
-                for (int i = 0; i < PW; i++) { nm[i] = mask[i] & rec.mask(i); any |= nm[i] != 0; }
-                const uint64_t c8 = dfs_chunk(shape ? dist + take : dist);
-                const unsigned nextb = (unsigned)c8 & 0xFF;
-                uint32_t hits = 0, pick = 0;
+                    for (int i = 0; i < PW; i++) { nm[i] = mask[i] & rec.mask(i); any |= nm[i] != 0; }
+                    const uint64_t c8 = dfs_chunk(dist + take);
+                    const unsigned nextb = (unsigned)c8 & 0xFF;
+                    uint32_t hits = 0, pick = 0;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const unsigned cf1 = rec.child_first(e);
-                    const bool m = ((uint32_t)e < rdeg) & ((cf1 == 'N') | (cf1 == nextb));
-                    hits += m;
-                    pick = m ? rec.edge(e) : pick;
-                }
-                fast_done = shape & eqp & any & (hits == 1);
-                if (fast_done) {
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned cf1 = rec.child_first(e);
+                        const bool m = (uint32_t)e < rdeg && (cf1 == 'N' || cf1 == nextb);
+                        hits += m;
+                        if (m) pick = rec.edge(e);
+                    }
+                    if (any && hits == 1) {
 #pragma unroll
-                    for (int i = 0; i < PW; i++) mask[i] = nm[i];
-                    dist += take; cur8 = c8; cur = pick; coff = 0;
+                        for (int i = 0; i < PW; i++) mask[i] = nm[i];
+                        dist += take; cur8 = c8; cur = pick; coff = 0;
+                        fast_done = true;
+                    }
                 }
             }
             if (!fast_done) {
