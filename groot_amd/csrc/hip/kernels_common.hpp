@@ -1,15 +1,16 @@
-// kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the `groot align` hot path.
+// kernels_common.hpp -- what the gfx950 (CDNA4, wave64) kernels of the `groot align` hot path share: ntHash / MultiHash constants, the table hashes
+// the host builds its tables with, 8-bases-at-a-time byte comparison, and the epilogue every seed kernel ends a read with.
 //
-//   sketch_seed_kernel   K1+K2: per read ntHash -> KHF MinHash sketch (registers) -> LSH-Ensemble
-//                        containment lookup -> per-read seed slots.          thread per read
-//   align_kernel         K3: per read the graphMinion loop: IncrementSubPath call counts and the
-//                        hierarchical exact-match DFS alignment.               thread per read
-//   order_*_kernel       compact traversal records into canonical (read, ord) order (scan + scatter)
+//   kernels_sig.hpp      sketch_sig_kernel  K1+K2 for reads of at least the window size on the every-slot-equal branch of Query: a few slots of the
+//                                           sketch (kSigG), signature index, confirmation by text.  text_lookup_kernel: reads the memo knows.
+//   kernels_sketch.hpp   sketch_seed_kernel K1+K2 full width: all S slots at 64 bits, exact table / LSH Forest; LIST instances take the reads the
+//                                           kernels above leave.                                                thread per read
+//   kernels_align.hpp    align_kernel       K3: the graphMinion loop -- IncrementSubPath call counts, hierarchical exact-match DFS; persistent,
+//                                           per-lane state machine with wave-coherent phase scheduling
+//   kernels_misc.hpp     heavy LSH-Forest reads, seed-list sort / split, call-count rows, ordering of the traversal records, table builders of open
 //
-// Integer/byte work throughout: no MFMA.  The sketch is VALU bound (64-bit multiply-mix-min per
-// (k-mer, slot)); reads are staged through LDS with coalesced 16-byte loads; the index (graphs,
-// window sketches, lookup tables: ~100 MB for arg-annot.90) is re-used by every read and stays in
-// L2 / Infinity Cache.
+// Integer / byte work throughout: no MFMA.  Hashing is bound by VALU issue, the graph walk by dependent trips to L2; reads are staged through LDS with
+// coalesced 16-byte loads; the index is reused by every read and stays in L2 / Infinity Cache.  
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -7,26 +7,32 @@ namespace groot {
 // ---------------------------------------------------------------------------------------------
 // K1+K2, fast path: sketch_sig_kernel
 // ---------------------------------------------------------------------------------------------
-// For reads whose Containment > t needs every sketch slot equal (the exact-table branch of sketch_seed_kernel) the seed
-// set is decided without ever forming the 64-bit minima:
+// For reads whose Containment > t needs every sketch slot equal (the exact-table branch of sketch_seed_kernel) the seed set is decided
+// without ever forming the sketch:
 //  * MultiHash mixes with t ^= t >> 27, which leaves the top 27 bits of t alone, and truncation is monotone, so
-//    top27(min_j mix(t_j)) = min_j top27(t_j) = (min_j hi32(h_j * c_i)) >> 5: a running 32-bit minimum of the raw product's
-//    high word gives the top 27 bits of every slot EXACTLY -- a 64-bit add and half a v_min3_u32 per (k-mer, slot) (the
-//    compiler pairs two k-mers) instead of seven instructions (add, shift, 2 xor, 64-bit compare, 2 selects);
-//  * a window can only equal the read's sketch if its signature (those 27 bits of all S slots) does: the signature table
-//    holds every window; no entry -> no seed, rigorously;
-//  * an entry is confirmed by TEXT: the window's sketch is the sketch of every WindowSize-mer of the bases it was merged
-//    from (graph.go:293-333; re-sketched and compared with Key.Sketch when the ctx is opened), so a read that equals one
-//    of them, or its reverse complement (canonical k-mer hashes), has exactly that sketch.  Where in the text to compare is
-//    known from the read's smallest k-mer (its position in each text row is in the table entry).  Its seeds are then all
-//    windows of the same sketch class, in table order = ascending window id, as the exact table would have returned them;
-//  * for a confirmed window-sized read the epilogue's verdicts come from DeviceIndex::sig_verdict -- the full-width seed
-//    stage was run on every WindowSize-mer of every text at open;
-//  * everything else -- a signature found but no text equal (reads with errors that keep all minimisers, windows merged
-//    from another path), bytes other than ACGT (their 2-bit codes say nothing), other lengths / thresholds (LSH-Forest
-//    branch), spans too long for the LDS -- goes onto a list and through sketch_seed_kernel<..., LIST> unchanged.
-// Reads are staged as 2-bit codes (6.4 KB per 256 x 100 bp instead of 25.6 KB), the rolling hash takes both strands'
-// table entries of the entering and the leaving base with one 16-byte LDS read each.
+//    top27(min_j mix(t_j)) = min_j top27(t_j) = (min_j hi32(h_j * c_i)) >> 5: a running 32-bit minimum of the raw product's high word gives the
+//    top 27 bits of a slot EXACTLY -- one 64-bit add (v_lshl_add_u64) and half a v_min3_u32 per (k-mer, slot) instead of seven instructions;
+//  * round 5, LAZY: only kSigG of the S slots are computed (slot 0 = the smallest canonical hash itself, no multiply; then the slots that come first
+//    in the running sum h * C0 + d * h).  A window whose sketch equals the read's agrees in THOSE slots too: no window with this partial signature ->
+//    no seed, as rigorously as with all S; the other slots are never needed, because
+//  * an entry is confirmed by TEXT: the window's sketch is the sketch of every WindowSize-mer of the bases it was merged from (graph.go:293-333;
+//    re-sketched and compared with Key.Sketch when the ctx is opened), so a read that equals one of them, or its reverse complement (canonical
+//    k-mer hashes), has exactly that sketch.  Where in the text to compare is known from the read's smallest k-mer (its position in each text
+//    row is in the entry).  Its seeds are then all windows of the same sketch class, in ascending window id as the exact table returns them;
+//  * the signature index has two levels (device_types.hpp SigEntry): a directory over the distinct signatures, and the windows of a signature back
+//    to back, sorted by (class, id), 32 bytes each with the verdict bytes of their first eight offsets inline.  A read first runs through its
+//    group with a few instructions per entry (does the text's smallest k-mer sit where the read's does?) and only compares text for a candidate;
+//  * ntHash's rolling update takes ONE 16-byte LDS read and four XORs per k-mer: the table is keyed by the (leaving, entering) pair of bases and
+//    holds both strands' values already XORed together;
+//  * for a confirmed window-sized read the epilogue's verdicts come from the table made at open (the full-width seed stage was run on every
+//    WindowSize-mer of every text);
+//  * everything else -- a signature found but no text equal (reads with errors that keep those minimisers, windows merged from another path), bytes
+//    other than ACGT, other lengths / thresholds (LSH-Forest branch), spans too long for the LDS -- goes onto a list and through
+//    sketch_seed_kernel<..., LIST> unchanged.
+// Measured (10 M x 100 bp, alone on the chip): 1.65 ms with all 21 slots (round 4) -> 1.25 ms with 13; hashing alone is 0.86 ms (G = 9) .. 1.26 ms
+// (G = 20), the rest is the directory / group / text trips.  Fewer slots hash faster and confirm slower (neighbouring windows of a sequence share
+// most minimisers: a signature over G slots has ~21 / G windows of a path in its group): G = 5 / 7 / 9 / 13 / 20 -> 2.0 / 1.7 / 1.3 / 1.25 / 1.5 ms.
+// Reads are staged as 2-bit codes (6.4 KB per 256 x 100 bp instead of 25.6 KB).
 #ifndef GROOT_SIG_WAVES
 #define GROOT_SIG_WAVES 6
 #endif

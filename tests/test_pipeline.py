@@ -214,6 +214,36 @@ def test_results_on_device_and_legacy_reads(small_index):
     al.close()
 
 
+def test_stream_join_orders_a_caller_stream_behind_the_results(small_index):
+    """groot_hip_set_stream puts only the seed stage on the caller's stream; the align and order stages run on a stream of the ctx.  A caller that
+    consumes results_on_device records from its own stream orders it with groot_hip_stream_join: the copy below is enqueued on the caller's stream
+    right after the submit, without any host wait, and must see the finished records."""
+    import torch
+
+    batches = make_batches(small_index, 1, 3000)
+    _, per = oracle_of(small_index, batches)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    seq, off = batches[0]
+    d_seq = torch.zeros(len(seq) + 64, dtype=torch.uint8, device=dev)
+    d_seq[: len(seq)] = torch.from_numpy(np.ascontiguousarray(seq)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(off).astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    al = device.Aligner(small_index, max_batch_reads=4096, results_on_device=True)
+    al.set_stream(st.cuda_stream)
+    al.stream_join()                                   # (nothing submitted yet: a no-op)
+    al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), len(off) - 1, first_read_id=0, max_len=int(np.diff(off).max()))
+    al.stream_join()                                   # the caller's stream now waits for the batch's order stage
+    with torch.cuda.stream(st):
+        marker = torch.ones(1, device=dev)             # work of the caller behind the join
+    st.synchronize()                                   # ... so when ITS stream has drained, the batch is through the device
+    assert float(marker.item()) == 1.0
+    c = al.wait()
+    recs = al.alns()
+    assert len(recs) == len(per[0]) and all(np.array_equal(recs[f], per[0][f]) for f in per[0].dtype.names) and c["received"] == len(off) - 1
+    al.close()
+
+
 def test_corrupt_view_is_refused(small_index):
     """groot_hip_open runs the consistency pass before uploading anything"""
     import ctypes as C
