@@ -189,10 +189,10 @@ struct DeviceIndex {
     // band_keys with that prefix -- [(b * max_k + K-1) << band_hash_bits | slot], reusing ExactEntry {tag, id = row}
     const ExactEntry *band_hash;
     uint32_t band_hash_bits;
-    // per band row: one byte per sketch slot (the first 32 slots), sig8() of the slot's 64-bit value.  Rows of equal prefix
-    // are neighbours, so a candidate is first judged on this 32-byte neighbourhood read: only windows whose signature
-    // agrees in enough slots have their 8*S-byte sketch fetched
-    const uint8_t *band_sig;        // [l_max][n_windows][32]
+    // per band row: five bits per sketch slot (the first 24 slots, six to a dword), sig5() of the slot's 64-bit value.  Rows of equal prefix
+    // are neighbours, so a candidate is first judged on this 16-byte neighbourhood read (32 bytes of one byte per slot until round 5: half the
+    // lines and round trips of the walk): only windows whose signature agrees in enough slots have their 8*S-byte sketch fetched
+    const uint8_t *band_sig;        // [l_max][n_windows][16]
     const uint32_t *band_run;       // [l_max][max_k][n_windows]: rows sharing the K-prefix of row e, counted from e (valid at first rows)
     uint32_t max_k, l_max;
     // per kmerCount q (0..max_q): LSH params and the smallest #equal slots with Containment > t

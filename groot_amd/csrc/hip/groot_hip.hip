@@ -503,6 +503,8 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     if (win_bits - 2u + a.sort_span_bits > 24u && win_bits - 2u + 4u <= 24u) a.sort_span_bits = 24u - (win_bits - 2u);
     // (reads without seeds carry 0xFFFFFFFF: all ones in the span field, which no window has -- every window contains a node -- so they sort last)
     a.sort_span_shift = win_bits;
+    // (the low window bits matter: sorted without the lowest 4 / 8 of them -- two radix passes instead of three -- configs[2] through the kernels ran at
+    // 1 832 / 1 406 instead of 2 035 Mreads/s, the align kernel 3.6 / 5.4 ms instead of 3.1: neighbouring windows walk the same nodes)
     const unsigned begin_bit = 2u, end_bit = win_bits + a.sort_span_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
     const uint32_t list_blocks = 1280u;   // workgroups of the list pass (grid-stride; 5 per CU)
@@ -2153,9 +2155,9 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         c->band_hash_bits = bits;
         const uint32_t cap = 1u << bits;
         lsh.tab.assign((size_t)lmax * mk * cap, ExactEntry{0, kEmpty});
-        lsh.sig.assign((size_t)lmax * n * 32, 0);
+        lsh.sig.assign((size_t)lmax * n * kRowBytes, 0);
         lsh.run.assign((size_t)lmax * mk * n, 0);
-        const uint32_t sl = std::min<uint32_t>(s, 32);
+        const uint32_t sl = std::min<uint32_t>(s, kRowSlots);
         lsh.job = std::thread([&lsh, v, n, s, mk, lmax, bits, cap, sl]() {
         auto &keys = lsh.keys; auto &ids = lsh.ids; auto &tab = lsh.tab; auto &sig = lsh.sig; auto &run = lsh.run;
         auto band = [&](uint32_t b) {                            // the bands are independent: one thread each
@@ -2188,8 +2190,9 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
             }
             for (uint32_t e = 0; e < n; e++) {
                 const uint64_t *ws = v->win_sketch + (size_t)ids[(size_t)b * n + e] * s;
-                uint8_t *row = &sig[((size_t)b * n + e) * 32];
-                for (uint32_t i = 0; i < sl; i++) row[i] = (uint8_t)sig8(ws[i]);
+                uint32_t row[4] = {0, 0, 0, 0};                 // 5 bits per slot, six slots to a dword (kernels_common.hpp row_same6)
+                for (uint32_t i = 0; i < sl; i++) row[i / 6] |= sig5(ws[i]) << (5 * (i % 6));
+                memcpy(&sig[((size_t)b * n + e) * kRowBytes], row, kRowBytes);
             }
             for (uint32_t K = 1; K <= mk; K++) {
                 uint32_t *rn = run.data() + ((size_t)b * mk + (K - 1)) * n;
@@ -2304,7 +2307,10 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     // candidate rows to lsh_heavy_kernel (a wavefront per read).  Two alternatives were built, measured slower on every workload
     // and removed in round 4 ("Removed"): a kernel dealing the rows of 64 reads over a wavefront, and a query launch of its own.
     if (c->l_max <= kLshMaxBands) {
-        c->lsh_defer_rows = 64u;
+#ifndef GROOT_LSH_DEFER_ROWS
+#define GROOT_LSH_DEFER_ROWS 64    // (round 5, mixed 75..150-base reads, 8 M per batch, t = 0.99 / 0.90: 8 -> 813 / 404, 16 -> 980 / 512, 32 -> 1 120 / 618, 64 -> 1 203 / 656 Mreads/s)
+#endif
+        c->lsh_defer_rows = GROOT_LSH_DEFER_ROWS;
         c->lsh_cap = c->kn.small_buffers ? 4u : std::max<uint32_t>(4096, R / 4);   // (small: most heavy reads find the list full and walk their own rows)
         HIP_TRY(c, c->lsh_list.alloc(c->lsh_cap));
         HIP_TRY(c, c->lsh_count.alloc(4));

@@ -58,7 +58,16 @@ __host__ __device__ __forceinline__ uint64_t sketch_hash_step(uint64_t h, uint64
 }
 #define GROOT_SKETCH_HASH_INIT 0x9E3779B97F4A7C15ULL
 // one byte of a sketch slot for DeviceIndex::band_sig
-__host__ __device__ __forceinline__ uint32_t sig8(uint64_t v) { return (uint32_t)((v * 0xD6E8FEB86659FD93ULL) >> 56); }
+// LSH-Forest rows (DeviceIndex::band_sig): 5 bits per sketch slot, six slots to a dword (bits 30, 31 zero), four dwords = the first 24 slots
+__host__ __device__ __forceinline__ uint32_t sig5(uint64_t v) { return (uint32_t)((v * 0xD6E8FEB86659FD93ULL) >> 59); }
+constexpr uint32_t kRowSlots = 24, kRowBytes = 16;
+// slots whose 5-bit fields agree in one dword of a row and of the read (an UPPER bound: the borrow of the zero-field test may also flag a field
+// of value 1 right above an equal one; fields neither side uses are zero on both and are taken off by the caller)
+__device__ __forceinline__ uint32_t row_same6(uint32_t w, uint32_t r)
+{
+    const uint32_t x = w ^ r;
+    return (uint32_t)__builtin_popcount((x - 0x02108421u) & ~x & 0x21084210u);
+}
 
 // 2-bit code of an upper-case base ((b>>1)&3: A=0 C=1 T=2 G=3); 12-bit code of the first 6 bases of r8,
 // or -1 if one of them is not ACGT (such a base can still meet the graph's 'N' wildcard)

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void lsh_heavy_kernel(SeedArgs a)
     __shared__ uint32_t aux_lds[(kBlock / 64) * (2 * kLshMaxBands + 16)];
     const DeviceIndex &ix = a.ix;
     const uint32_t S = ix.s, maxk = ix.max_k, LB = ix.l_max, n = ix.n_windows;
-    const uint32_t sl = S < 32 ? S : 32, nd = (sl + 3) >> 2;
+    const uint32_t sl = S < kRowSlots ? S : kRowSlots, nd = (sl + 5) / 6;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t *m = sk_lds + wave * kLshHeavyMaxS;
     uint32_t *blo = aux_lds + wave * (2 * kLshMaxBands + 16);   // [LB] first row per band
@@ -103,30 +103,28 @@ __global__ __launch_bounds__(kBlock) void lsh_heavy_kernel(SeedArgs a)
         if (lane == 0) for (uint32_t b = 0; b < LB; b++) bcum[b + 1] += bcum[b];
         wave_sync();
         const uint32_t T = bcum[LB];
-        uint32_t rs[8];
+        uint32_t rs[4];
 #pragma unroll
-        for (uint32_t wd = 0; wd < 8; wd++) {
+        for (uint32_t wd = 0; wd < 4; wd++) {
             uint32_t v = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++)
-                if (4 * wd + i < sl) v |= sig8(m[4 * wd + i]) << (8 * i);
+            for (uint32_t i = 0; i < 6; i++)
+                if (6 * wd + i < sl) v |= sig5(m[6 * wd + i]) << (5 * i);
             rs[wd] = v;
         }
         for (uint32_t t = lane; t < T; t += 64) {
             uint32_t b = 0;
             while (b + 1 < LB && bcum[b + 1] <= t) b++;
             const uint32_t e = blo[b] + (t - bcum[b]);
-            const uint4 *sg = reinterpret_cast<const uint4 *>(ix.band_sig + ((size_t)b * n + e) * 32);
-            const uint4 sa = sg[0], sb = sg[1];
-            const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            const uint4 sa = *reinterpret_cast<const uint4 *>(ix.band_sig + ((size_t)b * n + e) * kRowBytes);
+            const uint32_t ws4[4] = {sa.x, sa.y, sa.z, sa.w};
             uint32_t same = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 8; i++) {
+            for (uint32_t i = 0; i < 4; i++) {
                 if (i >= nd) break;
-                const uint32_t x = ws8[i] ^ rs[i];
-                same += __popc((x - 0x01010101u) & ~x & 0x80808080u);
+                same += row_same6(ws4[i], rs[i]);
             }
-            if (same - (4u * nd - sl) + (S - sl) < min_eq) continue;
+            if (same - (6u * nd - sl) + (S - sl) < min_eq) continue;
             const uint32_t id = ix.band_ids[(size_t)b * n + e];
             const uint64_t *ws = ix.win_sketch + (size_t)id * S;
             uint32_t eq = 0;

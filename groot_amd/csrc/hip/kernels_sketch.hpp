@@ -25,13 +25,13 @@ namespace groot {
 // (the S running minima are 2 S registers: at GROOT_SEED_WAVES waves per SIMD (~100 VGPRs) sketch sizes above 30 spilled them --
 // 20 ms per 2 M reads at S = 64.  Larger sketches get fewer, larger waves: 3 per SIMD up to S = 48, 2 beyond)
 #ifndef GROOT_LIST_WAVES
-#define GROOT_LIST_WAVES 4      // the list instance: 4 waves = 128 VGPRs, 0 spilled with two rows of the LSH-Forest walk fetched together (126 used; four rows: 7 spilled).
+#define GROOT_LIST_WAVES 4      // the list instance: 4 waves = 128 VGPRs (6 spilled with four 16-byte rows of the LSH-Forest walk and their window ids fetched together).
                                 // History: 5 waves spilled 25-50 VGPRs; 3 waves with four rows ahead took the list pass of a mixed-length batch from 4.0 to 3.6 ms; 4 waves x 2 rows,
                                 // measured once the signature kernel left its sparse wavefronts' reads to this pass: mixed t = 0.99 1 093 -> 1 176, t = 0.90 606 -> 653 Mreads/s
                                 // (4 x 4: 1 174 / 649, 4 x 1: 1 154 / 647, 3 x 8: 1 109 / 607, 5 x 2: 1 073 / 611)
 #endif
 #ifndef GROOT_LIST_ROWS_AHEAD
-#define GROOT_LIST_ROWS_AHEAD 2
+#define GROOT_LIST_ROWS_AHEAD 4
 #endif
 // (round 5: sketch sizes 22..30 at 4 waves -- they spilled 31..95 VGPRs at 5 --, 45 and more at 2 -- 48 spilled 293 at 3; tools/kernel_meta.sh)
 constexpr int seed_waves(int S, bool list = false) { return S == 0 ? 1 : (S <= 30 ? (list ? (S <= 24 ? GROOT_LIST_WAVES : 3) : (S <= 21 ? GROOT_SEED_WAVES : 4)) : (S <= 44 ? 3 : 2)); }
@@ -214,50 +214,97 @@ __global__ __launch_bounds__(kBlock, seed_waves(S, LIST)) void sketch_seed_kerne
         const int lmax_ = s_ / maxk_;
         const uint32_t K = ix.q_k[q], L = ix.q_l[q];
         const uint32_t n = ix.n_windows;
-        const int sl_ = s_ < 32 ? s_ : 32;                  // slots covered by the row signatures
-        uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int sl_ = s_ < (int)kRowSlots ? s_ : (int)kRowSlots;   // slots covered by the row signatures
+        uint32_t rs[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < sl_; i++) rs[i >> 2] |= sig8(m[i]) << (8 * (i & 3));
+        for (int i = 0; i < sl_; i++) rs[i / 6] |= sig5(m[i]) << (5 * (i % 6));
         // the rows of equal prefix in every band first: a read with many of them (a sequence that dozens of graphs share) would keep
         // its lane walking while the other 63 wait -- it goes to lsh_heavy_kernel, a wavefront per read
         // (the run-time-sized instance has room for kGenericMaxBands = kGenericMaxS bands)
         constexpr int LB_ = (S && MAXK) ? (S / MAXK > 0 ? S / MAXK : 1) : kGenericMaxBands;
         uint32_t b_lo[LB_], b_end[LB_];
         uint32_t rows = 0;
-#pragma unroll
-        for (int b = 0; b < lmax_; b++) {
-            if (b >= LB_) break;
-            b_lo[b] = n; b_end[b] = n;
-            if ((uint32_t)b >= L) continue;
+        // first row of the (sorted) band table with a band's prefix: hash table over the distinct prefixes, open addressing from `slot` on
+        auto probe = [&](int b, uint32_t slot, uint32_t tag) -> uint32_t {
             const uint32_t *keys = ix.band_keys + (size_t)b * n * maxk_;
-            auto cmp = [&](uint32_t e) {      // -1 / 0 / +1 : table entry e vs query prefix
-                const uint32_t *ke = keys + (size_t)e * maxk_;
-#pragma unroll
-                for (int j = 0; j < maxk_; j++) {
-                    if ((uint32_t)j >= K) break;
-                    const uint32_t qv = (uint32_t)m[b * maxk_ + j], kv = ke[j];
-                    if (kv != qv) return kv < qv ? -1 : 1;
-                }
-                return 0;
-            };
-            // first row of the (sorted) band table with this prefix: hash table over the distinct prefixes
-            uint32_t lo = n;
-            if (K >= 1) {
-                uint64_t hk = GROOT_SKETCH_HASH_INIT;
+            const ExactEntry *tab = ix.band_hash + (((size_t)b * maxk_ + (K - 1)) << ix.band_hash_bits);
+            const uint32_t hmask = (1u << ix.band_hash_bits) - 1u;
+            for (slot &= hmask;; slot = (slot + 1) & hmask) {
+                const ExactEntry e = tab[slot];
+                if (e.id == kEmpty) return n;
+                if (e.tag != tag) continue;
+                const uint32_t *ke = keys + (size_t)e.id * maxk_;
+                bool eqk = true;
 #pragma unroll
                 for (int j = 0; j < maxk_; j++)
-                    if ((uint32_t)j < K) hk = sketch_hash_step(hk, (uint32_t)m[b * maxk_ + j]);
-                const ExactEntry *tab = ix.band_hash + (((size_t)b * maxk_ + (K - 1)) << ix.band_hash_bits);
-                const uint32_t hmask = (1u << ix.band_hash_bits) - 1u, tag = (uint32_t)(hk >> 32);
-                for (uint32_t slot = (uint32_t)hk & hmask;; slot = (slot + 1) & hmask) {
-                    const ExactEntry e = tab[slot];
-                    if (e.id == kEmpty) break;
-                    if (e.tag == tag && cmp(e.id) == 0) { lo = e.id; break; }
-                }
+                    if ((uint32_t)j < K) eqk &= ke[j] == (uint32_t)m[b * maxk_ + j];
+                if (eqk) return e.id;
             }
-            b_lo[b] = lo;
-            b_end[b] = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
-            rows += b_end[b] - lo;
+        };
+        auto band_hash_of = [&](int b) {
+            uint64_t hk = GROOT_SKETCH_HASH_INIT;
+#pragma unroll
+            for (int j = 0; j < maxk_; j++)
+                if ((uint32_t)j < K) hk = sketch_hash_step(hk, (uint32_t)m[b * maxk_ + j]);
+            return hk;
+        };
+        if constexpr (S && MAXK && LIST) {
+            // (round 5) the bands' look-ups side by side: the first table entry of every band in one round of loads, then the keys and the run length
+            // of the rows they name in a second -- two trips to memory for all bands instead of three per band, one after the other (hash entry ->
+            // keys of its row -> length of the run).  A band whose first entry is somebody else's (open addressing) goes on alone.
+            const uint32_t hmask = (1u << ix.band_hash_bits) - 1u;
+            const uint32_t Kc = K ? K : 1u;
+            uint32_t slot0[LB_], tag0[LB_];
+            ExactEntry e0[LB_];
+#pragma unroll
+            for (int b = 0; b < LB_; b++) {
+                const uint64_t hk = band_hash_of(b);
+                slot0[b] = (uint32_t)hk & hmask; tag0[b] = (uint32_t)(hk >> 32);
+                e0[b] = ix.band_hash[((((size_t)b * MAXK + (Kc - 1)) << ix.band_hash_bits)) + slot0[b]];
+            }
+            uint32_t kv[LB_][MAXK], run0[LB_];
+#pragma unroll
+            for (int b = 0; b < LB_; b++) {
+                const bool cand = (uint32_t)b < L && K >= 1 && e0[b].id != kEmpty && e0[b].tag == tag0[b];
+                const uint32_t idc = cand ? e0[b].id : 0u;
+                const uint32_t *ke = ix.band_keys + ((size_t)b * n + idc) * MAXK;
+#pragma unroll
+                for (int j = 0; j < MAXK; j++) kv[b][j] = ke[j];
+                run0[b] = ix.band_run[((size_t)b * MAXK + (Kc - 1)) * n + idc];
+            }
+#pragma unroll
+            for (int b = 0; b < LB_; b++) {
+                b_lo[b] = n; b_end[b] = n;
+                if ((uint32_t)b >= L || K < 1) continue;
+                if (e0[b].id == kEmpty) continue;
+                bool eqk = e0[b].tag == tag0[b];
+#pragma unroll
+                for (int j = 0; j < MAXK; j++)
+                    if ((uint32_t)j < K) eqk &= kv[b][j] == (uint32_t)m[b * MAXK + j];
+                uint32_t lo = e0[b].id, len_run = run0[b];
+                if (!eqk) {
+                    lo = probe(b, slot0[b] + 1, tag0[b]);
+                    len_run = lo < n ? ix.band_run[((size_t)b * MAXK + (K - 1)) * n + lo] : 0;
+                }
+                b_lo[b] = lo;
+                b_end[b] = lo < n ? lo + len_run : n;
+                rows += b_end[b] - lo;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < lmax_; b++) {
+                if (b >= LB_) break;
+                b_lo[b] = n; b_end[b] = n;
+                if ((uint32_t)b >= L) continue;
+                uint32_t lo = n;
+                if (K >= 1) {
+                    const uint64_t hk = band_hash_of(b);
+                    lo = probe(b, (uint32_t)hk, (uint32_t)(hk >> 32));
+                }
+                b_lo[b] = lo;
+                b_end[b] = lo < n ? lo + ix.band_run[((size_t)b * maxk_ + (K - 1)) * n + lo] : n;   // rows with this prefix
+                rows += b_end[b] - lo;
+            }
         }
         if (a.lsh_list && rows > a.lsh_defer_rows && (uint32_t)s_ <= kLshHeavyMaxS) {
             // (one atomic for the lanes that are here together: the counter is a single address)
@@ -279,37 +326,37 @@ __global__ __launch_bounds__(kBlock, seed_waves(S, LIST)) void sketch_seed_kerne
         for (int b = 0; b < lmax_; b++) {
             if ((uint32_t)b >= L || b >= LB_) break;
             const uint32_t *ids = ix.band_ids + (size_t)b * n;
-            const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * 32);
+            const uint4 *sigs = reinterpret_cast<const uint4 *>(ix.band_sig + (size_t)b * n * kRowBytes);
             const uint32_t lo = b_lo[b], e_end = b_end[b];
-            // (rows are 32 consecutive bytes each: kRowsAhead of them are fetched together -- the walk is a chain of round trips, 790
-            // load instructions per wavefront and read on mixed-length batches, two thirds of the kernel's time spent waiting)
+            // (rows are 16 consecutive bytes each: kRowsAhead of them are fetched together -- the walk is a chain of round trips, two thirds of
+            // the kernel's time on mixed-length batches spent waiting)
             constexpr uint32_t kRowsAhead = LIST ? GROOT_LIST_ROWS_AHEAD : GROOT_LSH_ROWS_AHEAD;
             for (uint32_t e4 = lo; e4 < e_end; e4 += kRowsAhead) {
-            uint4 rowa[kRowsAhead], rowb[kRowsAhead];
+            uint4 rowa[kRowsAhead];
 #pragma unroll
-            for (uint32_t i = 0; i < kRowsAhead; i++) {
-                const size_t ee = min(e4 + i, e_end - 1u);
-                rowa[i] = sigs[2 * ee]; rowb[i] = sigs[2 * ee + 1];
-            }
+            for (uint32_t i = 0; i < kRowsAhead; i++) rowa[i] = sigs[min(e4 + i, e_end - 1u)];
+            // (the rows' window ids come along in the same round trip: on mixed-length reads of resfinder.90 four rows in ten pass the filter, and nine
+            // in ten of those are seeds -- id, then sketch, was two trips per seed in the lane that holds up its wavefront)
+            uint32_t rid[kRowsAhead];
+#pragma unroll
+            for (uint32_t i = 0; i < kRowsAhead; i++) rid[i] = ids[min(e4 + i, e_end - 1u)];
 #pragma unroll
             for (uint32_t i = 0; i < kRowsAhead; i++) {
                 const uint32_t e = e4 + i;
                 if (e >= e_end) break;
-                // slots whose signature bytes agree (pad bytes are zero on both sides): an upper bound of the equal slots
-                // (this filter is most of the branch's time -- runs of ~40 rows per band: only the dwords that hold slots, and the
-                // cheap zero-byte test, which may also flag a byte of value 1 above an equal one: an upper bound still)
-                const uint4 sa = rowa[i], sb = rowb[i];
-                const uint32_t ws8[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-                const int nd = (sl_ + 3) >> 2;
+                // slots whose signature fields agree: an upper bound of the equal slots (this filter is most of the branch's time -- runs of
+                // ~40 rows per read: only the dwords that hold slots)
+                const uint4 sa = rowa[i];
+                const uint32_t ws4[4] = {sa.x, sa.y, sa.z, sa.w};
+                const int nd = (sl_ + 5) / 6;
                 uint32_t same = 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 4; i++) {
                     if (i >= nd) break;
-                    const uint32_t x = ws8[i] ^ rs[i];
-                    same += __popc((x - 0x01010101u) & ~x & 0x80808080u);
+                    same += row_same6(ws4[i], rs[i]);
                 }
-                if (same - (4u * (uint32_t)nd - (uint32_t)sl_) + (uint32_t)(s_ - sl_) < min_eq) continue;
-                const uint32_t id = ids[e];
+                if (same - (6u * (uint32_t)nd - (uint32_t)sl_) + (uint32_t)(s_ - sl_) < min_eq) continue;
+                const uint32_t id = rid[i];
                 const uint64_t *ws = ix.win_sketch + (size_t)id * s_;
                 uint32_t eq = 0;
                 bool earlier = false;
