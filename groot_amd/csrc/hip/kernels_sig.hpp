@@ -32,7 +32,7 @@ namespace groot {
 // Measured (10 M x 100 bp, alone on the chip): 1.65 ms with all 21 slots (round 4) -> 1.25 ms with 13; hashing alone is 0.86 ms (G = 9) .. 1.26 ms
 // (G = 20), the rest is the directory / group / text trips.  Fewer slots hash faster and confirm slower (neighbouring windows of a sequence share
 // most minimisers: a signature over G slots has ~21 / G windows of a path in its group): G = 5 / 7 / 9 / 13 / 20 -> 2.0 / 1.7 / 1.3 / 1.25 / 1.5 ms.
-// Reads are staged as 2-bit codes (6.4 KB per 256 x 100 bp instead of 25.6 KB).
+// Reads are staged as 2-bit codes (6.4 KB per 256 x 100 bp instead of 25.6 KB) -- by the workgroups that will hash any: the reads are classified by length first.
 #ifndef GROOT_SIG_WAVES
 #define GROOT_SIG_WAVES 6
 #endif
@@ -117,8 +117,23 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
     const uint64_t base16 = span0 & ~15ULL;
     const uint64_t span_bytes = span1 - base16;
     const bool in_lds = span_bytes <= a.lds_read_bytes;
-    __syncthreads();
-    if (in_lds) {
+    const uint32_t r = r0 + tid;
+    // (no thread leaves before the barriers below: threads without a read, or with one that is answered at once, are predicated off instead)
+    const bool valid = r < a.n_reads;
+    const uint64_t o0 = valid ? a.seq_off[r] : 0;
+    const uint32_t len = valid ? (uint32_t)(a.seq_off[r + 1] - o0) : 0;
+    const uint32_t q = len - k + 1;                        // kmerCount, boss.go:169
+    // (len >= WindowSize: only then does the read cover whole WindowSize-mers of a text, whose sketches are proven; a shorter
+    // read is a substring with FEWER k-mers -- its minima may differ below the 27 signature bits -- and takes the full-width kernel)
+    bool fast = valid && in_lds && len >= k && len >= ix.w && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
+    const uint32_t qme = (valid && len >= k && q <= ix.max_q) ? ix.q_min_eq[q] : 0u;
+    if (fast) fast = qme == (uint32_t)S;                   // else: out of reach (answered below) or the LSH-Forest branch
+    // A wavefront hashes at the price of 64 reads however few of its lanes take part (below), and a workgroup stages its 256 reads as 2-bit codes
+    // whether anybody hashes them or not: 100+ bytes per read from HBM, and on a batch of mixed read lengths -- 2-3 % window-sized reads, one or two
+    // to a wavefront -- nobody does.  The reads are therefore classified by LENGTH first, and a workgroup none of whose wavefronts will hash
+    // stages nothing (round 5; the barrier that follows the table set-up carries the vote).
+    const bool stage = __syncthreads_or((uint32_t)__popcll(__ballot(fast)) >= kSigMinLanes) != 0;
+    if (stage && in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
         const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
         for (uint32_t i = tid; i < n16; i += BS) {
@@ -130,23 +145,13 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
         }
     }
     __syncthreads();
-    const uint32_t r = r0 + tid;
-    // (no thread leaves before the two barriers of the list bookkeeping below: threads without a read, or with one that is answered
-    // at once, are predicated off instead)
-    const bool valid = r < a.n_reads;
-    const uint64_t o0 = valid ? a.seq_off[r] : 0;
-    const uint32_t len = valid ? (uint32_t)(a.seq_off[r + 1] - o0) : 0;
-    const uint32_t q = len - k + 1;                        // kmerCount, boss.go:169
     bool answered = !valid;
-    if (valid && len >= k && len <= a.max_read_len && (q > ix.max_q || ix.q_min_eq[q] > (uint32_t)S)) {
+    if (valid && len >= k && len <= a.max_read_len && (q > ix.max_q || qme > (uint32_t)S)) {
         // Containment > t is out of reach for this many k-mers: no seed, and nothing to hash
         seed_epilogue(a, r, o0, len, q, 0, kEmpty, kEmpty, kEmpty, kEmpty, kEmpty, false);
         answered = true;
     }
-    // (len >= WindowSize: only then does the read cover whole WindowSize-mers of a text, whose sketches are proven; a shorter
-    // read is a substring with FEWER k-mers -- its minima may differ below the 27 signature bits -- and takes the full-width kernel)
-    bool fast = !answered && in_lds && len >= k && len >= ix.w && len <= a.max_read_len && len <= 16u * TW && q <= ix.max_q;
-    if (fast) fast = ix.q_min_eq[q] == (uint32_t)S;        // else: LSH-Forest branch
+    fast = fast && stage;
     if (fast) {
         const uint32_t c0 = (uint32_t)(o0 - base16) >> 4, c1 = (uint32_t)(o0 - base16 + len - 1) >> 4;
         for (uint32_t w = c0 >> 5; w <= c1 >> 5; w++) {
