@@ -667,7 +667,17 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         HIP_TRY(c, hipMemsetAsync(c->incr_cnt.p, 0, (size_t)s->n_reads * sizeof(uint32_t), c->astream));
     }
     a.head_lanes = s->mixed_len ? 16u : 0u;              // (8: best at 2 M reads before the items of split reads took the head; 16: 2.9 / 5.2 ms at 2 M / 8 M reads, 8 gave 3.05 / 5.6)
-    a.refill = s->mixed_len ? 32u : 64u;                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
+    // (round 5: 48 when fewer than six reads in ten are walked -- reads with errors: some align at once, some fail through the hierarchy, and lanes that
+    // have finished take new reads before the whole round has: configs[2] with 1 % substitutions, memo off, 2 625 -> 2 740 Mreads/s; on error-free reads,
+    // which march in step, 64 stays: 1 966 against 1 892 / 1 895 / 1 908 at 32 / 48 / 56)
+#ifndef GROOT_REFILL_ERR
+#define GROOT_REFILL_ERR 48       // (2 / 16 / 32 / 48: 2 674 / 2 712 / 2 736 / 2 755 Mreads/s on configs[2] with 1 % substitutions, memo off)
+#endif
+#ifndef GROOT_REFILL_MIXED
+#define GROOT_REFILL_MIXED 2      // mixed read lengths: a lane that has finished takes its next read at once -- no rounds (2 / 8 / 16 / 32 / 48: 1 258 / 1 253 / 1 249 / 1 208 /
+                                  // 1 172 Mreads/s at t = 0.99 on 8 M reads of 75..150 bases, 694 / 678 / 680 / 676 / 653 at t = 0.90; batches of 2 M: 850-890 -> 912)
+#endif
+    a.refill = s->mixed_len ? (uint32_t)GROOT_REFILL_MIXED : (c->dfs_frac >= kSparseBelow && c->dfs_frac < 0.6 ? (uint32_t)GROOT_REFILL_ERR : 64u);                   // reads of many lengths finish their walks far apart (tools/mixed_probe.py)
 #ifdef GROOT_WORK_COUNTERS
     if (const char *e = getenv("GROOT_DEV_ROUND")) a.round_lanes = (uint32_t)atoi(e);   // instrumented builds only (tools/slow_reads_probe.py: one read per round)
 #endif
