@@ -224,6 +224,7 @@ struct groot_ctx {
     std::deque<Slot *> inflight;           // submission order: IN_FLIGHT / D2H_ISSUED
     uint64_t next_ticket = 1;
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
+    double todo_frac = 1.0;                // share of the latest finished batch's reads that the first seed kernel left to the list pass
     double dfs_frac = 1.0;                 // share of the latest finished batch's reads that needed the align stage's graph walk (the rest: no seeds / tabulated outcomes)
     double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
     double bytes_per_trav = 0;             // compact path-set bytes per traversal, likewise (0 = not seen yet: 8 * path_words)
@@ -507,7 +508,16 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
     // 1 832 / 1 406 instead of 2 035 Mreads/s, the align kernel 3.6 / 5.4 ms instead of 3.1: neighbouring windows walk the same nodes)
     const unsigned begin_bit = 2u, end_bit = win_bits + a.sort_span_bits;
     const dim3 grid((s->n_reads + kBlock - 1) / kBlock);
-    const uint32_t list_blocks = 1280u;   // workgroups of the list pass (grid-stride; 5 per CU)
+    // workgroups of the list pass (grid-stride over the list).  Round 5: as many as the list is expected to need at a read per thread -- the latest
+    // finished batch says how long it was --, not the 1 280 (five per CU) that are resident at once: reads of the LSH-Forest branch cost between a
+    // few and a few hundred row visits, a workgroup that walks eight or nine sets of 256 of them in a fixed order ends when its slowest sets add up,
+    // and workgroups dealt out as CUs become free level that (8 M reads of 75..150 bases, 2.84 M on the list, t = 0.99 / 0.90: 1 024 -> 1 229 / 665,
+    // 1 280 -> 1 255 / 699, 2 560 -> 1 294 / 710, 5 120 -> 1 340 / 726, 20 480 -> 1 346 / 730 Mreads/s).  At least 1 280, so that a batch that
+    // differs from the one before is not left with a handful.
+#ifndef GROOT_LIST_BLOCKS_MIN
+#define GROOT_LIST_BLOCKS_MIN 1280
+#endif
+    const uint32_t list_blocks = std::max<uint32_t>(GROOT_LIST_BLOCKS_MIN, (uint32_t)std::min<double>(4.0e6, c->todo_frac * 1.25 * (double)s->n_reads / kBlock + 1.0));
     // a batch of one read length that is not on the exact-table branch (lower thresholds, reads shorter than the windows) would
     // send every read through the list: the full-width kernel alone is 25-30 % faster then (tools/threshold_probe.py)
     bool sig_useful = true;
@@ -1113,6 +1123,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
     // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
     if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
     if (s->n_reads && !c->tab_capture) c->dfs_frac = (double)h.seeded_reads / (double)s->n_reads;
+    if (s->n_reads && (s->sig_used || s->text_used)) c->todo_frac = (double)h.todo_reads / (double)s->n_reads;
     if (s->n_reads && !c->tab_capture && c->dix.text_tab) {
         c->text_hit_frac = s->text_used ? 1.0 - (double)h.todo_reads / (double)s->n_reads : (double)h.tab_reads / (double)s->n_reads;
         // (a batch that tried the lookup in vain sent all its reads through the list pass: on a stream the memo cannot answer --
@@ -1612,7 +1623,7 @@ static int build_outcome_table(groot_ctx *c, const groot_index_view *v, const st
         HIP_TRY(c, hipMemset(c->q_nrows.p, 0, 4));
         if (c->att_cap) HIP_TRY(c, hipMemset(c->attempts_ptr, 0, (size_t)c->att_cap * c->n_windows * sizeof(uint32_t)));
         for (WorkSet &w : c->ws) w.owner = nullptr;
-        c->trav_per_read = 1.25; c->bytes_per_trav = 0; c->dfs_frac = 1.0;
+        c->trav_per_read = 1.25; c->bytes_per_trav = 0; c->dfs_frac = 1.0; c->todo_frac = 1.0;
     }
     if (rc_all) return rc_all;
     lap("pipeline on the strings");
