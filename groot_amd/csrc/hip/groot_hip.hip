@@ -467,6 +467,15 @@ static uint32_t list_lds_stride(uint32_t stride_dw)
 {
     return kLdsReads + (uint64_t)kBlock * stride_dw * 4 <= 32 * 1024 ? stride_dw : 0;
 }
+// workgroups of the two wavefront-per-read kernels of the seed stage's tail (grid-stride over their lists): many small shares level out reads that
+// cost between a few and a few thousand rows (round 5, 8 M reads of 75..150 bases, t = 0.99 / 0.90: heavy reads 512 / 2 048 / 8 192 / 32 768 workgroups
+// -> 1 306 / 1 330 / 1 347 / 1 356 and 667 / 728 / 750 / 748 Mreads/s; seed-list sort 512 / 2 048 / 8 192 -> 1 283 / 1 330 / 1 360 and 680 / 728 / 748)
+#ifndef GROOT_HEAVY_BLOCKS
+#define GROOT_HEAVY_BLOCKS 16384u
+#endif
+#ifndef GROOT_SORTLIST_BLOCKS
+#define GROOT_SORTLIST_BLOCKS 16384
+#endif
 static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     WorkSet *w = &c->ws[s->set];
@@ -574,7 +583,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
     }
     // the reads of the LSH-Forest branch with many candidate rows: a wavefront each
-    if (a.lsh_list) hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, 2048u)), dim3(kBlock), 0, c->stream, a);
+    if (a.lsh_list) hipLaunchKernelGGL(lsh_heavy_kernel, dim3(std::min<uint32_t>(grid.x, GROOT_HEAVY_BLOCKS)), dim3(kBlock), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[12], c->stream));   // (the list pass behind the first kernel + the heavy LSH-Forest reads)
     // seed lists of more than four windows that are not ascending (LSH-Forest hits come in band order): sorted, a wavefront per read
@@ -586,7 +595,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         sa.split = c->vcap && !c->tab_capture && !c->prm.no_exact_align;
         sa.vitem = w->vitem.p; sa.vcount = w->vcount.p; sa.vcap = c->vcap; sa.split_list = w->split_list.p;
         sa.ctr = s->d_ctr.p; sa.update_weights = update_weights ? 1 : 0;
-        hipLaunchKernelGGL(sort_seed_lists_kernel, dim3(2048), dim3(kBlock), 0, c->stream, sa);
+        hipLaunchKernelGGL(sort_seed_lists_kernel, dim3(GROOT_SORTLIST_BLOCKS), dim3(kBlock), 0, c->stream, sa);
     }
     if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[2], c->stream));
     hipLaunchKernelGGL(assign_q_rows_kernel, dim3(1), dim3(64), 0, c->stream, c->q_seen.p, c->q_row.p, c->q_of_row.p, c->q_nrows.p, c->att_cap,
