@@ -63,7 +63,17 @@ def main():
     time.sleep(0.2)
     print("[probe] loop starts", time.time_ns(), file=sys.stderr, flush=True)
     t_loop = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
-    v, ms, c = bench.resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), R, max_len, steps, 2, mixed=mixed)
+    if os.environ.get("PROBE_SERIAL") == "1":               # one batch at a time: the stages run one after the other, nothing overlaps
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), R, first_read_id=0, max_len=max_len, mixed=mixed)
+            c = al.wait()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        v, ms = R * steps / dt / 1e6, al.stage_ms()
+    else:
+        v, ms, c = bench.resident_rate(al, d_seq.data_ptr(), d_off.data_ptr(), R, max_len, steps, 2, mixed=mixed)
     al.close()
     print(json.dumps({"workload": wl, "reads": R, "steps": steps, "value": v, "stage_ms": ms, "counts": c, "loop_start_monotonic_ns": t_loop}), flush=True)
 
