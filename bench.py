@@ -49,7 +49,7 @@ sys.path.insert(0, REPO)
 
 READ_LEN = 100
 HBM_PEAK_GBS = 8000.0  # spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
-PMC_FILE = next((f for f in (os.path.join(REPO, "profiles", n) for n in ("r05_pmc.json", "r04_pmc.json")) if os.path.exists(f)), "")   # {workload: {kernel: per-launch counters}}, tools/profile_r05.sh
+PMC_FILE = next((f for f in (os.path.join(REPO, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json")) if os.path.exists(f)), "")   # {workload: {kernel: per-launch counters}}, tools/profile_r05.sh
 
 
 def usable_cpus():
@@ -127,8 +127,8 @@ def cpu_baseline(index_path, seconds):
     allv, wall = run(cores, per, 1_000_000)
     return {"value": allv, "unit": "Mreads/s", "cores": cores, "kind": "port", "hardware_threads": os.cpu_count(),
             "cores_note": "cores = CPUs this container may use (min of affinity mask and cgroup CPU quota); the box shows more hardware threads than it grants",
-            "sample": f"{cores} oracle processes x {per} reads of the same synthetic stream, started together, {wall:.1f} s wall "
-                      f"(records dropped per 25k-read chunk as the reference streams them to the BAM)",
+            "sample": f"{cores} oracle processes x {per} reads of the synthetic stream, together, {wall:.1f} s wall",
+            "sample_note": "records dropped per 25k-read chunk as the reference streams them to the BAM",
             "single_core": {"value": one, "sample": f"{one_n} reads, one process, {one_wall:.1f} s"},
             "scaling_efficiency": allv / (one * cores),
             "note": "oracle/groot_oracle.c = CPU restatement of the reference path; the Go binary itself cannot be built in this image"}
@@ -142,6 +142,17 @@ def pmc_of(workload, kernel):
         return json.load(open(PMC_FILE)).get(workload, {}).get(kernel, {})
     except Exception:
         return {}
+
+
+def pmc_commit():
+    """the commit the PMC passes of PMC_FILE were taken on: the file's own "_meta" entry, else the known ones"""
+    try:
+        m = json.load(open(PMC_FILE)).get("_meta", {})
+        if m.get("commit"):
+            return m["commit"]
+    except Exception:
+        pass
+    return {"r05_pmc.json": "6cad506", "r04_pmc.json": "fb627ca"}.get(os.path.basename(PMC_FILE))
 
 
 def kernel_blocks(workload, ms, counts, R, mean_len, pw):
@@ -487,6 +498,87 @@ def cli_e2e(index, d_seq, n_reads, bam_level):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 8000     # the driver keeps an 8 KB tail of stdout and parses the last line; round 5's 20 KB line did not parse
+
+
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the compact line's bytes go to names, not to digits)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _flat(d):
+    """keep a dict's scalars (rounded); strings cut at 110 characters (the driver cuts at ~120)"""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, (dict, list, tuple)):
+            continue
+        out[k] = v[:110] if isinstance(v, str) else _r(v)
+    return out
+
+
+def compact_line(full):
+    """The ONE stdout line the driver parses: bench-contract scalars, `config`, `roofline`, `cpu_baseline` -- every value below the three
+    objects is a scalar (depth 2), under COMPACT_LIMIT bytes.  Everything else (per-kernel blocks, per-leg stage times, counters) goes to
+    bench_full.json and stderr.  tests/test_bench_line.py holds it to that."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(full.get(k), 6) for k in top}
+    cfg = full.get("config", {})
+    line["config"] = _flat({k: cfg.get(k) for k in ("workload", "reads_per_gpu_per_step", "read_len", "parallelism", "memo", "walked_reads",
+                                                     "full_sketch_reads", "mapped", "alignments", "travs", "seeds", "background_fraction") if cfg.get(k) is not None})
+    rf = _flat(full.get("roofline", {}))
+    rf.pop("note", None)
+    line["roofline"] = rf
+    pr = full.get("per_rank")
+    if pr:
+        # N > 1: every rank's own ms per step and all-reduce ms, flat (rank_ms_per_step_min/max and allreduce_ms_max are already in rf)
+        for i, (a, b) in enumerate(zip(pr.get("ms_per_step", []), pr.get("allreduce_ms", []))):
+            if i < 16:
+                rf["rank%d_ms_per_step" % i] = _r(a)
+                rf["rank%d_allreduce_ms" % i] = _r(b)
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _flat(cb)
+        c.pop("note", None)
+        c.pop("cores_note", None)
+        if isinstance(cb.get("single_core"), dict):
+            c["single_core"] = _r(cb["single_core"].get("value"))
+        line["cpu_baseline"] = c
+    for k in ("host_fed", "cli_e2e", "mixed", "memo_tier", "thresholds", "kernel_path"):
+        if isinstance(full.get(k), dict) and "error" in full[k]:
+            line.setdefault("leg_errors", {})[k] = str(full[k]["error"])[:110]
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= COMPACT_LIMIT:      # never expected; drop the least important scalars rather than lose the record again
+        for k in sorted(rf, key=lambda k_: (k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"), -len(k_))):
+            if len(s) < COMPACT_LIMIT:
+                break
+            if k not in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+                rf.pop(k)
+                s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
+def emit(full):
+    """full object -> bench_full.json (repo root, and gpurun_out/ when there is one) + stderr; compact line -> stdout, last"""
+    txt = json.dumps(full)
+    for d in (REPO, os.path.join(REPO, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(txt + "\n")
+        except OSError:
+            pass
+    print("[bench] full object:", txt, file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -668,15 +760,16 @@ def main():
             "metric": "Mreads/s aligned", "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[2], memo OFF: 10M x 100bp error-free reads of arg-annot.90 (k31 s21 w100 t0.99), every read hashed, looked up, walked",
+            "config": {"workload": "configs[2] memo off: 10M x 100bp reads, arg-annot.90 k31 s21 w100 t0.99; every read hashed, looked up, walked",
                        "reads_per_gpu_per_step": R, "read_len": READ_LEN, **({"background_fraction": args.background} if args.background > 0 else {}), "parallelism": f"reads sharded x{world}, index replicated",
                        "residency": "inputs and records resident in HBM, two batches in flight (host_fed_mreads / cli_e2e_mreads: PCIe- and host-inclusive)",
-                       "memo": "off for `value` (groot_params.memo_budget_mb = GROOT_MEMO_OFF); the default ctx's memo tier is roofline.memo_mreads",
+                       "memo": "off for value (memo_budget_mb = GROOT_MEMO_OFF); the memo tier is roofline.memo_mreads",
                        "full_sketch_reads": counts["full_sketch_reads"], "walked_reads": counts["walked_reads"], "mapped": counts["mapped"],
                        "alignments": counts["alignments"], "travs": counts["travs"], "seeds": counts["seeds"],
                        "per_step_counts": counts, "stage_ms": stage, "open": open_stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": b.get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": b.get("frac"), "traffic": b.get("traffic"), "traffic_source": b.get("traffic_source"),
+                         "frac": b.get("frac"), "traffic": b.get("traffic"), "traffic_source": b.get("traffic_source"), "pmc_commit": pmc_commit(),
+                         "kernel_selected_by": "longest avg duration in the committed trace (kernel_trace_ms); kernel_ms is live",
                          "bytes_per_launch": b["bytes_per_launch"], "kernel_ms": b["kernel_ms"], "kernel_trace_ms": b.get("pmc_kernel_ms"),
                          "sig_kernel_trace_ms": blocks["sketch_sig_kernel"].get("pmc_kernel_ms"),
                          "valu_issue_frac": b.get("valu_issue"), "wait_frac": b.get("wait_frac"),
@@ -774,7 +867,7 @@ def main():
                     line["cpu_baseline"] = cpu_baseline(index_path, args.cpu_seconds)
                 except Exception as e:
                     line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if al is not None:
         al.close()
     if dist is not None:
