@@ -231,7 +231,12 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
            "--master-port", "29517", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300000"]
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    last = r.stdout.decode().strip().splitlines()[-1]
+    compact = json.loads(last)                       # what the driver parses: the LAST stdout line, under its 8 KB tail
+    assert len(last) < 8000 and compact["n_gpus"] == 2 and compact["value"] > 0 and "rank1_ms_per_step" in compact["roofline"]
+    assert all(not isinstance(v2, (dict, list)) for v in compact.values() if isinstance(v, dict) for v2 in v.values())
+    line = json.load(open(os.path.join(REPO, "bench_full.json")))          # the full object of the same run
+    assert line["value"] == pytest.approx(compact["value"], rel=1e-4)
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["per_step_counts"]["received"] == 300000 and "cpu_baseline" not in line
     # every rank's own step time and its all-reduce time are on the line, so that a scaling run can be read rank by rank
@@ -241,7 +246,12 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
                           "--leg-steps", "2", "--mixed-reads", "30000", "--mixed-cli-reads", "5000", "--host-fed-seconds", "0.3"],
                          cwd=REPO, capture_output=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
-    single = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    last = one.stdout.decode().strip().splitlines()[-1]
+    compact = json.loads(last)
+    assert len(last) < 8000 and compact["n_gpus"] == 1 and compact["roofline"]["frac"] > 0 and compact["roofline"]["host_fed_mreads"] > 0
+    assert all(not isinstance(v2, (dict, list)) for v in compact.values() if isinstance(v, dict) for v2 in v.values())
+    single = json.load(open(os.path.join(REPO, "bench_full.json")))
+    assert single["value"] == pytest.approx(compact["value"], rel=1e-4)
     assert single["n_gpus"] == 1 and single["config"]["per_step_counts"]["received"] == 300000
     # the PCIe- and host-inclusive legs ride on the same line
     assert single["host_fed"].get("value", 0) > 0 and single["host_fed"]["d2h_bytes_per_read"] > 10, single["host_fed"]
@@ -253,7 +263,7 @@ def test_bench_multi_rank_code_path(argannot_index, tmp_path):
     # `value` is the rate through the hashing and graph-walk kernels (memo off): every read was walked, none answered from a table; the flat
     # scalars the driver keeps say how fast those kernels are and what the legs reached
     c = single["config"]
-    assert c["walked_reads"] == c["mapped"] > 0.9 * 300000 and "memo OFF" in c["workload"], c
+    assert c["walked_reads"] == c["mapped"] > 0.9 * 300000 and "memo off" in c["workload"], c
     rf = single["roofline"]
     assert rf["kernel"] in ("sketch_sig_kernel", "align_kernel", "sketch_seed_kernel<LIST>") and rf["kernel_path_mreads"] == single["value"]
     for k in ("sig_kernel_ms", "align_kernel_ms", "order_ms", "whole_step_frac", "memo_mreads", "sub1_mreads", "sub1_nomemo_mreads", "mixed99_mreads",
