@@ -42,7 +42,7 @@ const (
 
 // Counts mirrors groot_counts (the boss counters, boss.go:24-27)
 type Counts struct {
-	Received, Mapped, Multimapped, Alignments, Seeds, Travs, RevcompPanics, ShortReads, FullSketchReads, WalkedReads uint64
+	Received, Mapped, Multimapped, Alignments, Seeds, Travs, RevcompPanics, ShortReads, FullSketchReads, WalkedReads, LeanReads uint64
 }
 
 // Index owns a flat index (groot_index) loaded from the files `groot index` wrote
@@ -329,7 +329,7 @@ func (c *Ctx) Collect() (*Result, error) {
 	n := int(r.n_travs)
 	res := &Result{Ticket: uint64(r.ticket), NumReads: int(r.n_reads), PathWords: int(r.path_words)}
 	res.Counts = Counts{uint64(r.counts.received), uint64(r.counts.mapped), uint64(r.counts.multimapped), uint64(r.counts.alignments),
-		uint64(r.counts.seeds), uint64(r.counts.travs), uint64(r.counts.revcomp_panics), uint64(r.counts.short_reads), uint64(r.counts.full_sketch_reads), uint64(r.counts.walked_reads)}
+		uint64(r.counts.seeds), uint64(r.counts.travs), uint64(r.counts.revcomp_panics), uint64(r.counts.short_reads), uint64(r.counts.full_sketch_reads), uint64(r.counts.walked_reads), uint64(r.counts.lean_reads)}
 	if n > 0 {
 		res.Travs = (*[1 << 28]Trav)(unsafe.Pointer(r.travs))[:n:n]
 		// the path sets travel compact (as many bytes as the traversal's graph has paths / 8); widen them once per batch

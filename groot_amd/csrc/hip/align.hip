@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels_align.hpp"
+#include "kernels_lean.hpp"
 #include "launch.hpp"
 
 namespace groot {
@@ -17,6 +18,13 @@ void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st)
         if (lds) hipLaunchKernelGGL((align_kernel<11, true>), grid, dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((align_kernel<11, false>), grid, dim3(kBlock), 0, st, a);
     }
+}
+
+void launch_align_lean(uint32_t pw, const LeanArgs &a, dim3 grid, hipStream_t st)
+{
+    if (pw != 3) return;
+    const size_t lds = (size_t)kBlock * a.lds_stride_dw * 4;
+    hipLaunchKernelGGL((align_lean_kernel<3>), grid, dim3(kBlock), lds, st, a);
 }
 
 } // namespace groot

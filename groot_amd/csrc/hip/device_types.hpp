@@ -38,6 +38,7 @@ struct DeviceCounters {
     unsigned int todo_reads;    // reads sketch_sig_kernel handed to the full-width kernel (0 when that kernel ran alone)
     unsigned int seeded_reads;  // reads with at least one seed whose alignment is not tabulated: the align stage's share of the processing order (they sort first)
     unsigned int tab_reads;     // reads the signature kernel answered from the outcome table
+    unsigned int lean_reads;    // reads align_lean_kernel finished
     unsigned long long dbg[192]; // work counters (only with -DGROOT_WORK_COUNTERS): [e] wave iterations with event e, [32+e] lanes with it,
                                  // [64+b] lanes finishing their read b*2 iterations into the round, [128+b] rounds of that length
 };
@@ -298,8 +299,49 @@ struct AlignArgs {
     const uint4 *vitem;
     const uint32_t *vcount;
     uint32_t vcap;
+    const uint32_t *n_perm;      // entries of perm when it is the list the first pass left (align_lean_kernel + stream compaction); null: DeviceCounters::seeded_reads
     uint32_t refill;             // waiting lanes that make a wavefront take new reads: 64 (all of them) for batches of one read length, 32 for mixed ones
     DeviceCounters *ctr;
 };
+
+// ---- K3, first pass (kernels_lean.hpp) ----
+// a graph node for the lean walk: 64 bytes, four 16-byte loads in flight together
+struct alignas(16) LeanNode {
+    uint32_t seq_off;      // index of the node's first base in DeviceIndex::bases / LeanArgs::bases2
+    uint32_t seq_len;
+    uint32_t deg_kids;     // bits 0..2 out-degree (<= 4); bit 31: not for this pass (an 'N' in the node, more than four OutEdges);
+                           // bits 8..23: four bits per OutEdge: 0..3 = code of the neighbour's first base, 4 = it is an 'N', 8 = the neighbour is empty
+    uint32_t pad;
+    uint32_t edges[4];     // OutEdges order (global node indices)
+    uint64_t first32;      // first min(32, seq_len) bases, 2 bits each
+    uint64_t mask[3];      // path ids through the node
+};
+static_assert(sizeof(LeanNode) == 64, "lean node record is one 64-byte line");
+constexpr uint32_t kLeanNo = 0x80000000u;
+
+struct LeanArgs {
+    const LeanNode *nodes;
+    const uint32_t *bases2;        // every graph base at 2 bits, 16 to a dword, in DeviceIndex::bases order (+ 4 dwords of slack)
+    const uint4 *cn_pre2;          // per ContainedNodes entry: {bases [0,16), bases [16,24) | min(len, 65535) << 16, node, 0}
+    const uint8_t *win_ok;         // [n_windows] 1: neither the window's node nor any contained node holds an 'N'
+    const WinRec *win_rec;
+    const uint64_t *node_l2b;      // DeviceIndex::node_l2b (null: none)
+    const uint32_t *q_row;
+    const uint8_t *seq;
+    const uint32_t *perm;          // processing order
+    const ReadRec *read_rec;
+    uint32_t n_reads, first_read_id, n_windows, k;
+    uint32_t update_weights;
+    uint32_t lds_stride_dw;        // dwords per lane: 2 zero dwords, the read at 16 bases per dword, 2 of slack; odd
+    uint32_t max_len;              // longest read the slices hold
+    uint32_t *attempts;
+    groot_trav *trav_first;
+    uint64_t *mask_first;
+    uint32_t *trav_cnt;
+    uint8_t *defer;                // [n_reads] by slot: 1 = left to align_kernel
+    DeviceCounters *ctr;
+};
+
+__host__ __device__ inline uint32_t lean_stride_dw(uint32_t max_len) { return (2u + ((max_len + 15u) >> 4) + 2u) | 1u; }
 
 } // namespace groot

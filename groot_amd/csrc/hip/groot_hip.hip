@@ -74,7 +74,7 @@ template <class T> struct PinBuf {
 // compare the tiers with each other and with the CPU checker); TEST_SMALL_BUFFERS starts every growable buffer and list too small, so that
 // a test batch walks the grow-and-redo and the fall-back paths; OPEN_STATS prints where groot_hip_open spent its time.
 struct Knobs {
-    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false, poison = false;
+    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false, poison = false, no_lean = false;
     static Knobs read()
     {
         Knobs k;
@@ -82,6 +82,7 @@ struct Knobs {
         k.no_sig = getenv("GROOT_NO_SIG") != nullptr;                     k.force_rccl = getenv("GROOT_FORCE_RCCL") != nullptr;
         k.small_buffers = getenv("GROOT_TEST_SMALL_BUFFERS") != nullptr;  k.open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
         k.poison = getenv("GROOT_TEST_POISON") != nullptr;
+        k.no_lean = getenv("GROOT_NO_LEAN") != nullptr;                   // the align stage without its first pass (tests compare the two)
         return k;
     }
 };
@@ -98,6 +99,7 @@ struct Slot {
     bool mixed_len = false;                // the reads are known to differ in length (the align stage then refills its wavefronts earlier)
     bool text_used = false;                // text_lookup_kernel ran first (the list behind it goes through the full-width kernel)
     bool sig_used = false;                 // the signature kernel ran in front of the full-width kernel for this batch
+    bool lean_used = false;                // align_lean_kernel ran in front of align_kernel for this batch
     bool one_len = false;                  // the reads are known to have max_len bases each, or the caller said so (submit_device with max_len)
     uint64_t n_bases = 0, n_exc = 0;
     enum Input { IN_ASCII, IN_PACKED, IN_PACKED16, IN_DEVICE } input = IN_ASCII;
@@ -132,7 +134,7 @@ struct Slot {
     bool host_results = false;             // the traversal records of this batch are in h_trav / h_mask
     hipEvent_t ev_seed = nullptr;          // behind the batch's seed stage on the compute stream: its align stage waits for it
     hipEvent_t ev_h2d0 = nullptr, ev_h2d = nullptr, ev_compute = nullptr, ev_ctr = nullptr, ev_d2h0 = nullptr, ev_d2h = nullptr;
-    hipEvent_t ev[13]{};                   // [7..8] around the first seed kernel, [9..10] around order_first_kernel, [11] start of the align stage (align stream), [12] behind the list pass
+    hipEvent_t ev[14]{};                   // [7..8] around the first seed kernel, [9..10] around order_first_kernel, [11] start of the align stage (align stream), [12] behind the list pass
                                            // [0..6] stage boundaries on the compute stream (profiling)
     groot_counts counts{};
     int status = GROOT_OK;
@@ -145,6 +147,8 @@ struct Slot {
 // One of the two sets of buffers a batch's seed stage fills for its align and order stages (groot_ctx::ws)
 struct WorkSet {
     DevBuf<uint32_t> seed_count, seed_win, perm, perm_count, trav_cnt, tab_idx;
+    DevBuf<uint32_t> perm2, perm2_count;                 // the slots align_lean_kernel left, in processing order, and how many
+    DevBuf<uint8_t> defer;                               // LeanArgs::defer
     DevBuf<ReadRec> read_rec;
     DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
     DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
@@ -180,6 +184,11 @@ struct groot_ctx {
     DevBuf<uint16_t> q_min_eq;
     DevBuf<uint64_t> win_sketch;
     DevBuf<unsigned char> node_rec;
+    DevBuf<LeanNode> lean_nodes;           // first pass of the align stage (kernels_lean.hpp): nodes, graph bases and ContainedNodes prefixes at 2 bits per base
+    DevBuf<uint32_t> bases2;
+    DevBuf<uint4> cn_pre2;
+    DevBuf<uint8_t> win_ok;
+    bool lean = false;
     DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
     DevBuf<SigEntry> sig;                  // sketch_sig_kernel: signature index + window texts (absent: that kernel is not used)
@@ -702,6 +711,34 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
 #endif
     a.ctr = s->d_ctr.p;
     HIP_TRY(c, hipMemsetAsync(c->ovf_cnt.p, 0, (kOvfShards + 2) * sizeof(uint32_t), c->astream));   // + the two chunk cursors
+    // First pass (kernels_lean.hpp): a thread per read in processing order finishes the reads of one seed window whose walks never branch;
+    // the slots it leaves are flagged, a stream compaction keeps them in processing order, and align_kernel takes that list.
+    const uint32_t lean_stride = lean_stride_dw(s->max_len);
+    s->lean_used = c->lean && !c->tab_capture && s->n_reads && (size_t)kBlock * lean_stride * 4 <= 40 * 1024;
+    if (s->lean_used) {
+        LeanArgs l{};
+        l.nodes = c->lean_nodes.p; l.bases2 = c->bases2.p; l.cn_pre2 = c->cn_pre2.p; l.win_ok = c->win_ok.p;
+        l.win_rec = c->dix.win_rec; l.node_l2b = c->dix.node_l2b; l.q_row = c->q_row.p;
+        l.seq = s->seq(); l.perm = w->perm.p; l.read_rec = w->read_rec.p;
+        l.n_reads = s->n_reads; l.first_read_id = s->first_read_id; l.n_windows = c->n_windows; l.k = c->k;
+        l.update_weights = update_weights ? 1 : 0;
+        l.lds_stride_dw = lean_stride; l.max_len = s->max_len;
+        l.attempts = c->attempts_ptr;
+        l.trav_first = w->trav_first.p; l.mask_first = w->mask_first.p; l.trav_cnt = w->trav_cnt.p;
+        l.defer = w->defer.p; l.ctr = s->d_ctr.p;
+        launch_align_lean(c->pw, l, dim3((s->n_reads + kBlock - 1) / kBlock), c->astream);
+        HIP_TRY(c, hipGetLastError());
+        size_t tb = 0;
+        HIP_TRY(c, rocprim::select(nullptr, tb, w->perm.p, w->defer.p, w->perm2.p, w->perm2_count.p, (size_t)s->n_reads, c->astream));
+        if (tb > c->scan_tmp.n) {
+            HIP_TRY(c, hipStreamSynchronize(c->astream));
+            HIP_TRY(c, c->scan_tmp.alloc(tb + tb / 4));
+        }
+        HIP_TRY(c, rocprim::select(c->scan_tmp.p, tb, w->perm.p, w->defer.p, w->perm2.p, w->perm2_count.p, (size_t)s->n_reads, c->astream));
+        a.perm = w->perm2.p;
+        a.n_perm = w->perm2_count.p;
+        if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[13], c->astream));
+    }
     launch_align(c->pw, a, dim3(blocks), c->astream);
     HIP_TRY(c, hipGetLastError());
     return GROOT_OK;
@@ -1066,7 +1103,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
             merged.flags = keep | again.flags;
             merged.q_rows = again.q_rows;
             merged.mask_words = again.mask_words;
-            merged.todo_reads = again.todo_reads; merged.tab_reads = again.tab_reads;
+            merged.todo_reads = again.todo_reads; merged.tab_reads = again.tab_reads; merged.lean_reads = again.lean_reads;
             h = merged;
         } else h = again;
     }
@@ -1077,6 +1114,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
     o.travs = s->n_trav; o.revcomp_panics = h.revcomp_panics; o.short_reads = h.short_reads;
     o.full_sketch_reads = (s->sig_used || s->text_used) ? h.todo_reads : s->n_reads;
     o.walked_reads = h.seeded_reads;
+    o.lean_reads = h.lean_reads;
     if (s->status == GROOT_OK) {
         char buf[256];
         if (h.flags & kFlagLongRead) { s->status = GROOT_E_NOSPACE; snprintf(buf, sizeof buf, "a read is longer than max_read_len=%u", c->prm.max_read_len); s->status_msg = buf; }
@@ -1197,6 +1235,8 @@ static int collect_impl(groot_ctx *c, Slot **out)
         (void)hipEventElapsedTime(&s->ms.first_seed_kernel, s->ev[7], s->ev[8]);
         (void)hipEventElapsedTime(&s->ms.order_kernel, s->ev[9], s->ev[10]);
         (void)hipEventElapsedTime(&s->ms.list_pass, s->ev[8], s->ev[12]);
+        s->ms.lean_pass = 0;
+        if (s->lean_used) (void)hipEventElapsedTime(&s->ms.lean_pass, s->ev[11], s->ev[13]);
         (void)hipEventElapsedTime(&s->ms.wall, s->ev[1], s->ev[5]);
         if (!c->prm.results_on_device) (void)hipEventElapsedTime(&s->ms.d2h, s->ev_d2h0, s->ev_d2h);
     }
@@ -2034,6 +2074,68 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         else build_node_records<11>(v, recs);
         HIP_TRY(c, upload(c->node_rec, recs.data(), recs.size()));
     }
+    // ---- first pass of the align stage (kernels_lean.hpp): everything at 2 bits per base ----
+    c->lean = c->pw == 3 && !c->kn.no_lean && !c->prm.no_exact_align;
+    if (c->lean) {
+        auto code_of = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'T' ? 2 : b == 'G' ? 3 : -1; };
+        std::vector<uint32_t> b2((size_t)(v->n_bases + 15) / 16 + 4, 0);
+        for (uint64_t i = 0; i < v->n_bases; i++) {
+            const int cd = code_of(v->bases[i]);
+            if (cd > 0) b2[i >> 4] |= (uint32_t)cd << (2 * (i & 15));
+        }
+        std::vector<LeanNode> ln(v->n_nodes);
+        std::vector<uint8_t> node_bad(v->n_nodes, 0);
+        for (uint32_t n = 0; n < v->n_nodes; n++) {
+            LeanNode &r = ln[n];
+            memset(&r, 0, sizeof r);
+            r.seq_off = v->node_seq_off[n];
+            r.seq_len = v->node_seq_off[n + 1] - v->node_seq_off[n];
+            const uint32_t e0 = v->node_edge_off[n], deg = v->node_edge_off[n + 1] - e0;
+            bool no = deg > 4;
+            for (uint32_t i = 0; i < r.seq_len; i++) {
+                const int cd = code_of(v->bases[r.seq_off + i]);
+                if (cd < 0) no = true;                             // the graph's 'N' (alignment.go:212-222): align_kernel's business
+                else if (i < 32) r.first32 |= (uint64_t)cd << (2 * i);
+            }
+            node_bad[n] = no;
+            r.deg_kids = std::min(deg, 7u) | (no ? kLeanNo : 0u);
+            for (uint32_t e = 0; e < std::min(deg, 4u); e++) {
+                const uint32_t ch = v->edges[e0 + e];
+                r.edges[e] = ch;
+                uint32_t kid = 8;                                   // an empty neighbour spells nothing: never entered
+                if (v->node_seq_off[ch] < v->node_seq_off[ch + 1]) {
+                    const int cd = code_of(v->bases[v->node_seq_off[ch]]);
+                    kid = cd < 0 ? 4u : (uint32_t)cd;
+                }
+                r.deg_kids |= kid << (8 + 4 * e);
+            }
+            for (uint32_t w = 0; w < v->path_words && w < 3; w++) r.mask[w] = v->node_mask[(size_t)n * v->path_words + w];
+        }
+        std::vector<uint32_t> pre2((size_t)v->n_cn * 4 + 4, 0);
+        for (uint64_t i = 0; i < v->n_cn; i++) {
+            const uint32_t nd = v->cn_node[i];
+            const uint32_t s0 = v->node_seq_off[nd], nlen = v->node_seq_off[nd + 1] - s0;
+            uint64_t bits = 0;
+            for (uint32_t j = 0; j < std::min(nlen, 24u); j++) {
+                const int cd = code_of(v->bases[s0 + j]);
+                if (cd > 0) bits |= (uint64_t)cd << (2 * j);
+            }
+            uint32_t *e = &pre2[(size_t)i * 4];
+            e[0] = (uint32_t)bits; e[1] = (uint32_t)(bits >> 32) | (std::min(nlen, 65535u) << 16); e[2] = nd; e[3] = 0;
+        }
+        std::vector<uint8_t> ok(v->n_windows, 1);
+        for (uint32_t w = 0; w < v->n_windows; w++) {
+            if (node_bad[v->win_node[w]]) ok[w] = 0;
+            for (uint32_t i = v->win_cn_off[w]; i < v->win_cn_off[w + 1]; i++) {
+                const uint32_t nd = v->cn_node[i];
+                if (node_bad[nd] || v->node_seq_off[nd + 1] - v->node_seq_off[nd] > 65535u) ok[w] = 0;
+            }
+        }
+        HIP_TRY(c, upload(c->bases2, b2.data(), b2.size()));
+        HIP_TRY(c, upload(c->lean_nodes, ln.data(), ln.size()));
+        HIP_TRY(c, upload(c->cn_pre2, reinterpret_cast<const uint4 *>(pre2.data()), pre2.size() / 4));
+        HIP_TRY(c, upload(c->win_ok, ok.data(), ok.size()));
+    }
     {   // level 2 of AlignRead: the first 24 bases, index and length of every ContainedNodes entry, in list order (DeviceIndex::cn_pre)
         std::vector<uint32_t> pre((size_t)v->n_cn * 8 + 8, 0);
         for (uint64_t i = 0; i < v->n_cn; i++) {
@@ -2311,6 +2413,11 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, w.read_rec.alloc(R));
         HIP_TRY(c, w.perm.alloc(R));
         HIP_TRY(c, w.perm_count.alloc(4));
+        if (c->lean) {
+            HIP_TRY(c, w.perm2.alloc(R));
+            HIP_TRY(c, w.perm2_count.alloc(4));
+            HIP_TRY(c, w.defer.alloc(R));
+        }
         if (c->prm.keep_sketches) HIP_TRY(c, w.sketches.alloc((size_t)R * s));
         HIP_TRY(c, w.trav_first.alloc((size_t)R + c->vcap));
         HIP_TRY(c, w.mask_first.alloc(((size_t)R + c->vcap) * c->pw));

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     // reads without seeds sort last and have nothing to do here (the seed stage zeroed their traversal counts)
     // (items of split reads come first: slot j < nv is AlignArgs::vitem[j], slot nv + i is position i of the processing order)
     const uint32_t nv = a.vitem ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)*a.vcount), a.vcap) : 0u;
-    const uint32_t n_todo = nv + (a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads)) : a.n_reads);   // (scalar: it bounds every refill)
+    const uint32_t n_todo = nv + (a.perm ? min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.n_perm ? *a.n_perm : a.ctr->seeded_reads))) : a.n_reads);   // (scalar: it bounds every refill)
     // Lanes per round.  A round lasts as long as its slowest read, so when there are fewer reads than 64 per resident wavefront
     // (most of the batch was answered from the outcome table: what is left are the hard reads) the rounds are made smaller
     // and spread over all wavefronts: the launch then ends with the slowest read instead of the slowest sum of rounds.

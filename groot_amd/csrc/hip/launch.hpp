@@ -20,5 +20,6 @@ void launch_text_lookup(uint32_t key_dwords, const SeedArgs &a, dim3 grid, size_
 
 // K3
 void launch_align(uint32_t pw, const AlignArgs &a, dim3 grid, hipStream_t st);
+void launch_align_lean(uint32_t pw, const LeanArgs &a, dim3 grid, hipStream_t st);   // first pass (pw == 3 only)
 
 } // namespace groot

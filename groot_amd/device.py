@@ -30,7 +30,7 @@ MEMO_OFF = 0xFFFFFFFF
 
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("received", "mapped", "multimapped", "alignments", "seeds", "travs",
-                                            "revcomp_panics", "short_reads", "full_sketch_reads", "walked_reads")]
+                                            "revcomp_panics", "short_reads", "full_sketch_reads", "walked_reads", "lean_reads")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -42,7 +42,7 @@ class OpenStats(C.Structure):
 
 
 class StageMs(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack", "first_seed_kernel", "order_kernel", "list_pass", "wall")]
+    _fields_ = [(n, C.c_float) for n in ("h2d", "sketch_seed", "align", "sort", "total", "schedule", "d2h", "unpack", "first_seed_kernel", "order_kernel", "list_pass", "wall", "lean_pass")]
 
 
 class BatchBuffers(C.Structure):

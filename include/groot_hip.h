@@ -83,6 +83,8 @@ typedef struct groot_counts {
                                  * lookup / the signature kernel runs in front of it -- those it could not decide (diagnostic) */
     uint64_t walked_reads;      /* reads that went through the align stage's graph walk (the others: no seed window, or their
                                  * whole outcome came from the memo of groot_hip_open) (diagnostic) */
+    uint64_t lean_reads;        /* ... of them, reads the align stage's first pass finished (one seed window, a walk that never
+                                 * has two neighbours to choose from); the others took the state-machine kernel (diagnostic) */
 } groot_counts;
 
 /* per-stage device time of a batch, HIP events (ms); 0 if profiling off.
@@ -100,6 +102,8 @@ typedef struct groot_stage_ms {
      * wall = first kernel of the batch .. last kernel of the batch on the wall clock of the device: the seed stage of the next
      * batch runs beside this batch's align stage, so wall < sketch_seed + schedule + align + sort of two neighbouring batches */
     float list_pass, wall;
+    /* lean_pass = the first pass of the align stage (align_lean_kernel + the stream compaction of what it leaves), inside align; 0 when it did not run */
+    float lean_pass;
 } groot_stage_ms;
 
 int groot_hip_device_count(int *n);
