@@ -24,7 +24,10 @@ void launch_align_lean(uint32_t pw, const LeanArgs &a, dim3 grid, hipStream_t st
 {
     if (pw != 3) return;
     const size_t lds = (size_t)kBlock * a.lds_stride_dw * 4;
-    hipLaunchKernelGGL((align_lean_kernel<3>), grid, dim3(kBlock), lds, st, a);
+    // (64-bit pieces per node comparison: reads of up to 128 / 160 / 256 bases)
+    if (a.max_len <= 128) hipLaunchKernelGGL((align_lean_kernel<3, 4>), grid, dim3(kBlock), lds, st, a);
+    else if (a.max_len <= 160) hipLaunchKernelGGL((align_lean_kernel<3, 5>), grid, dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((align_lean_kernel<3, 8>), grid, dim3(kBlock), lds, st, a);
 }
 
 } // namespace groot

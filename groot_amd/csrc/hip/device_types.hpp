@@ -71,7 +71,7 @@ static_assert(sizeof(WinRec) == 32, "window record is two 16-byte words");
 // what the align stage needs to start a read, written by the seed stage in one 32-byte record
 struct alignas(16) ReadRec {
     uint64_t seq_off;      // first base of the read in the batch buffer
-    uint32_t len;
+    uint32_t len;          // | kRecPacked
     uint32_t cnt_flags;    // seeds (bits 0..23) | kRec* verdicts of the seed stage on the FIRST seed window | byte > 'T' (bit 31)
     uint32_t seed[4];      // the first four seed windows (all of them for 99.9% of reads); more: seed_win slots
 };
@@ -81,6 +81,7 @@ static_assert(sizeof(ReadRec) == 32, "read record is two 16-byte words");
 // (F) / its reverse complement (R) in the read's first seed window, as established by the seed stage
 constexpr uint32_t kRecCountMask = 0x00FFFFFFu;
 constexpr uint32_t kRecNo12F = 1u << 24, kRecNo3F = 1u << 25, kRecNo4F = 1u << 26;   // R = F << 3
+constexpr uint32_t kRecPacked = 1u << 31;                   // ReadRec::len: the read is all ACGT and its 2-bit codes are in SeedArgs::packed (sketch_sig_kernel wrote them: the align stage's first pass stages it from there)
 constexpr uint32_t kRecAscending = 1u << 30;                // cnt_flags: the read's seed windows were written in ascending order
 constexpr uint32_t kLongListCap = 1u << 20, kSortSeedsMax = 512;   // sort_seed_lists_kernel: reads per batch, seed windows per read
 // A read with more than kSplitMin seed windows is handled by several lanes of the align stage: its ascending window list is cut at
@@ -253,6 +254,8 @@ struct SeedArgs {
     uint64_t *lsh_sketch;
     uint32_t *dfs_list, *dfs_count;   // reads with a scheduling key, appended by the seed epilogue (processing order of the align stage when few are left); or null
     uint32_t *long_list, *long_count; // reads with more than four seed windows that were not found in ascending order (sort_seed_lists_kernel); up to kLongListCap
+    uint4 *packed;               // [n_reads][packed_q] the reads sketch_sig_kernel decides, 16 bases per dword (for align_lean_kernel); null: not wanted
+    uint32_t packed_q;           // 16-byte words per read in `packed`
     uint32_t *todo_list;         // [n_reads] reads sketch_sig_kernel leaves to sketch_seed_kernel<..., LIST>
     uint32_t *todo_count;        // [1]
     uint32_t lsh_defer_rows, lsh_cap;
@@ -310,7 +313,8 @@ struct alignas(16) LeanNode {
     uint32_t seq_off;      // index of the node's first base in DeviceIndex::bases / LeanArgs::bases2
     uint32_t seq_len;
     uint32_t deg_kids;     // bits 0..2 out-degree (<= 4); bit 31: not for this pass (an 'N' in the node, more than four OutEdges);
-                           // bits 8..23: four bits per OutEdge: 0..3 = code of the neighbour's first base, 4 = it is an 'N', 8 = the neighbour is empty
+                           // bits 8..23: four bits per OutEdge: 0..3 = code of the neighbour's first base, 4 = it is an 'N', 8 = the neighbour is empty;
+                           // bits 24..27: OutEdge e leads to a node of more than 32 bases (its LeanExt is wanted with its record)
     uint32_t pad;
     uint32_t edges[4];     // OutEdges order (global node indices)
     uint64_t first32;      // first min(32, seq_len) bases, 2 bits each
@@ -318,21 +322,32 @@ struct alignas(16) LeanNode {
 };
 static_assert(sizeof(LeanNode) == 64, "lean node record is one 64-byte line");
 constexpr uint32_t kLeanNo = 0x80000000u;
+// bases [32, 256) of a node, 2 bits each: fetched together with the node's record when the node is known to be long, so that a walk
+// step is ONE trip to memory whatever the node's length
+struct alignas(16) LeanExt {
+    uint64_t b[7];
+    uint64_t pad;
+};
+static_assert(sizeof(LeanExt) == 64, "lean node extension is one 64-byte line");
+constexpr uint32_t kLeanMaxLen = 256;   // longest read the first pass takes
 
 struct LeanArgs {
     const LeanNode *nodes;
-    const uint32_t *bases2;        // every graph base at 2 bits, 16 to a dword, in DeviceIndex::bases order (+ 4 dwords of slack)
-    const uint4 *cn_pre2;          // per ContainedNodes entry: {bases [0,16), bases [16,24) | min(len, 65535) << 16, node, 0}
+    const LeanExt *ext;
+    const uint32_t *bases2;        // every graph base at 2 bits, 16 to a dword, in DeviceIndex::bases order (+ slack for 17 dwords from any base)
+    const uint4 *cn_pre2;          // per ContainedNodes entry: {bases [0,16), bases [16,24) | min(len, 65535) << 16, node, index of its first base}
+    const uint64_t *node_l2b;      // DeviceIndex::node_l2b (null: none)
     const uint8_t *win_ok;         // [n_windows] 1: neither the window's node nor any contained node holds an 'N'
     const WinRec *win_rec;
-    const uint64_t *node_l2b;      // DeviceIndex::node_l2b (null: none)
     const uint32_t *q_row;
     const uint8_t *seq;
+    const uint4 *packed;           // SeedArgs::packed of the batch (reads whose record says kRecPacked); null: none
+    uint32_t packed_q;
     const uint32_t *perm;          // processing order
     const ReadRec *read_rec;
     uint32_t n_reads, first_read_id, n_windows, k;
     uint32_t update_weights;
-    uint32_t lds_stride_dw;        // dwords per lane: 2 zero dwords, the read at 16 bases per dword, 2 of slack; odd
+    uint32_t lds_stride_dw;        // lean_stride_dw(max_len)
     uint32_t max_len;              // longest read the slices hold
     uint32_t *attempts;
     groot_trav *trav_first;
@@ -342,6 +357,7 @@ struct LeanArgs {
     DeviceCounters *ctr;
 };
 
-__host__ __device__ inline uint32_t lean_stride_dw(uint32_t max_len) { return (2u + ((max_len + 15u) >> 4) + 2u) | 1u; }
+// LDS dwords per lane: 2 zero dwords, the read at 16 bases per dword (one strand at a time), 2 zero dwords, 7 dwords of the seed window's record; odd
+__host__ __device__ inline uint32_t lean_stride_dw(uint32_t max_len) { return (((max_len + 15u) >> 4) + 11u) | 1u; }
 
 } // namespace groot

@@ -99,6 +99,7 @@ struct Slot {
     bool mixed_len = false;                // the reads are known to differ in length (the align stage then refills its wavefronts earlier)
     bool text_used = false;                // text_lookup_kernel ran first (the list behind it goes through the full-width kernel)
     bool sig_used = false;                 // the signature kernel ran in front of the full-width kernel for this batch
+    uint32_t packed_q = 0;                 // SeedArgs::packed_q of the batch's signature kernel (0: it left no codes)
     bool lean_used = false;                // align_lean_kernel ran in front of align_kernel for this batch
     bool one_len = false;                  // the reads are known to have max_len bases each, or the caller said so (submit_device with max_len)
     uint64_t n_bases = 0, n_exc = 0;
@@ -149,6 +150,7 @@ struct WorkSet {
     DevBuf<uint32_t> seed_count, seed_win, perm, perm_count, trav_cnt, tab_idx;
     DevBuf<uint32_t> perm2, perm2_count;                 // the slots align_lean_kernel left, in processing order, and how many
     DevBuf<uint8_t> defer;                               // LeanArgs::defer
+    DevBuf<uint4> packed;                                // SeedArgs::packed
     DevBuf<ReadRec> read_rec;
     DevBuf<uint4> vitem, split_list;                     // AlignArgs::vitem, sort_seed_lists_kernel
     DevBuf<uint32_t> vcount;                             // [0] items, [1] split reads of the batch
@@ -184,6 +186,7 @@ struct groot_ctx {
     DevBuf<uint16_t> q_min_eq;
     DevBuf<uint64_t> win_sketch;
     DevBuf<unsigned char> node_rec;
+    DevBuf<LeanExt> lean_ext;
     DevBuf<LeanNode> lean_nodes;           // first pass of the align stage (kernels_lean.hpp): nodes, graph bases and ContainedNodes prefixes at 2 bits per base
     DevBuf<uint32_t> bases2;
     DevBuf<uint4> cn_pre2;
@@ -489,6 +492,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
     WorkSet *w = &c->ws[s->set];
     SeedArgs a{};
+    s->packed_q = 0;
     a.ix = c->dix;
     a.seq = s->seq();
     a.seq_off = s->off();
@@ -581,6 +585,9 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         const uint32_t stride_dw = ((s->max_len + 3) / 4 + 1) | 1u;     // the LIST pass copies each read into its lane's LDS slice
         a.list_stride_dw = list_lds_stride(stride_dw);
         HIP_TRY(c, hipMemsetAsync(c->todo_count.p, 0, sizeof(uint32_t), c->stream));
+        // (the reads it decides it also leaves as 2-bit codes for the first pass of the align stage)
+        if (c->lean && !c->tab_capture && w->packed.p) { a.packed = w->packed.p; a.packed_q = s->max_len <= 128 ? 2u : 4u; }
+        s->packed_q = a.packed ? a.packed_q : 0;
         launch_sig(c->s, a, s->max_len, false, c->stream);
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
@@ -714,12 +721,12 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     // First pass (kernels_lean.hpp): a thread per read in processing order finishes the reads of one seed window whose walks never branch;
     // the slots it leaves are flagged, a stream compaction keeps them in processing order, and align_kernel takes that list.
     const uint32_t lean_stride = lean_stride_dw(s->max_len);
-    s->lean_used = c->lean && !c->tab_capture && s->n_reads && (size_t)kBlock * lean_stride * 4 <= 40 * 1024;
+    s->lean_used = c->lean && !c->tab_capture && s->n_reads && s->max_len <= kLeanMaxLen;
     if (s->lean_used) {
         LeanArgs l{};
-        l.nodes = c->lean_nodes.p; l.bases2 = c->bases2.p; l.cn_pre2 = c->cn_pre2.p; l.win_ok = c->win_ok.p;
+        l.nodes = c->lean_nodes.p; l.ext = c->lean_ext.p; l.bases2 = c->bases2.p; l.cn_pre2 = c->cn_pre2.p; l.win_ok = c->win_ok.p;
         l.win_rec = c->dix.win_rec; l.node_l2b = c->dix.node_l2b; l.q_row = c->q_row.p;
-        l.seq = s->seq(); l.perm = w->perm.p; l.read_rec = w->read_rec.p;
+        l.seq = s->seq(); l.packed = s->packed_q ? w->packed.p : nullptr; l.packed_q = s->packed_q; l.perm = w->perm.p; l.read_rec = w->read_rec.p;
         l.n_reads = s->n_reads; l.first_read_id = s->first_read_id; l.n_windows = c->n_windows; l.k = c->k;
         l.update_weights = update_weights ? 1 : 0;
         l.lds_stride_dw = lean_stride; l.max_len = s->max_len;
@@ -1145,6 +1152,13 @@ static int finish_counters(groot_ctx *c, Slot *s)
             for (int b = 0; b < 64; b++) fprintf(stderr, " %llu", h.dbg[64 + 64 * hh + b]);
             fprintf(stderr, "\n");
         }
+    }
+#elif defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 4
+    if (h.dbg[151]) {
+        const double nw = (double)h.dbg[151];
+        fprintf(stderr, "[groot lean] wavefronts %llu; per wavefront: %.1f iterations (with a level-1 / level-2 / level-3-4 / walk lane: %.1f / %.1f / %.1f / %.1f); lane-steps per wavefront: %.0f / %.0f / %.0f / %.0f; staging %.2f us, loop %.2f us\n",
+                h.dbg[151], (double)h.dbg[148] / nw, (double)h.dbg[140] / nw, (double)h.dbg[141] / nw, (double)h.dbg[142] / nw, (double)h.dbg[143] / nw,
+                (double)h.dbg[144] / nw, (double)h.dbg[145] / nw, (double)h.dbg[146] / nw, (double)h.dbg[147] / nw, (double)h.dbg[149] / nw / 100.0, (double)h.dbg[150] / nw / 100.0);
     }
 #elif defined(GROOT_WORK_COUNTERS)
     for (int e = 0; e < 32; e++)
@@ -2078,16 +2092,18 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     c->lean = c->pw == 3 && !c->kn.no_lean && !c->prm.no_exact_align;
     if (c->lean) {
         auto code_of = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'T' ? 2 : b == 'G' ? 3 : -1; };
-        std::vector<uint32_t> b2((size_t)(v->n_bases + 15) / 16 + 4, 0);
+        std::vector<uint32_t> b2((size_t)(v->n_bases + 15) / 16 + 20, 0);
         for (uint64_t i = 0; i < v->n_bases; i++) {
             const int cd = code_of(v->bases[i]);
             if (cd > 0) b2[i >> 4] |= (uint32_t)cd << (2 * (i & 15));
         }
         std::vector<LeanNode> ln(v->n_nodes);
+        std::vector<LeanExt> lx(v->n_nodes);
         std::vector<uint8_t> node_bad(v->n_nodes, 0);
         for (uint32_t n = 0; n < v->n_nodes; n++) {
             LeanNode &r = ln[n];
             memset(&r, 0, sizeof r);
+            memset(&lx[n], 0, sizeof(LeanExt));
             r.seq_off = v->node_seq_off[n];
             r.seq_len = v->node_seq_off[n + 1] - v->node_seq_off[n];
             const uint32_t e0 = v->node_edge_off[n], deg = v->node_edge_off[n + 1] - e0;
@@ -2096,6 +2112,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                 const int cd = code_of(v->bases[r.seq_off + i]);
                 if (cd < 0) no = true;                             // the graph's 'N' (alignment.go:212-222): align_kernel's business
                 else if (i < 32) r.first32 |= (uint64_t)cd << (2 * i);
+                else if (i < 256) lx[n].b[(i >> 5) - 1] |= (uint64_t)cd << (2 * (i & 31));
             }
             node_bad[n] = no;
             r.deg_kids = std::min(deg, 7u) | (no ? kLeanNo : 0u);
@@ -2108,6 +2125,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                     kid = cd < 0 ? 4u : (uint32_t)cd;
                 }
                 r.deg_kids |= kid << (8 + 4 * e);
+                if (v->node_seq_off[ch + 1] - v->node_seq_off[ch] > 32u) r.deg_kids |= 1u << (24 + e);
             }
             for (uint32_t w = 0; w < v->path_words && w < 3; w++) r.mask[w] = v->node_mask[(size_t)n * v->path_words + w];
         }
@@ -2121,7 +2139,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
                 if (cd > 0) bits |= (uint64_t)cd << (2 * j);
             }
             uint32_t *e = &pre2[(size_t)i * 4];
-            e[0] = (uint32_t)bits; e[1] = (uint32_t)(bits >> 32) | (std::min(nlen, 65535u) << 16); e[2] = nd; e[3] = 0;
+            e[0] = (uint32_t)bits; e[1] = (uint32_t)(bits >> 32) | (std::min(nlen, 65535u) << 16); e[2] = nd; e[3] = s0;
         }
         std::vector<uint8_t> ok(v->n_windows, 1);
         for (uint32_t w = 0; w < v->n_windows; w++) {
@@ -2133,6 +2151,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         }
         HIP_TRY(c, upload(c->bases2, b2.data(), b2.size()));
         HIP_TRY(c, upload(c->lean_nodes, ln.data(), ln.size()));
+        HIP_TRY(c, upload(c->lean_ext, lx.data(), lx.size()));
         HIP_TRY(c, upload(c->cn_pre2, reinterpret_cast<const uint4 *>(pre2.data()), pre2.size() / 4));
         HIP_TRY(c, upload(c->win_ok, ok.data(), ok.size()));
     }
@@ -2417,6 +2436,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
             HIP_TRY(c, w.perm2.alloc(R));
             HIP_TRY(c, w.perm2_count.alloc(4));
             HIP_TRY(c, w.defer.alloc(R));
+            HIP_TRY(c, w.packed.alloc((size_t)R * (c->prm.max_read_len <= 128 ? 2 : 4)));
         }
         if (c->prm.keep_sketches) HIP_TRY(c, w.sketches.alloc((size_t)R * s));
         HIP_TRY(c, w.trav_first.alloc((size_t)R + c->vcap));

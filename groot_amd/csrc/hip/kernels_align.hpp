@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
                 if (virt) { cnt = min(vhi, a.seed_slots); cls = 0x80u | 0x100u | 0x200u | 0x400u; }
                 if (cnt == 0) { a.trav_cnt[r] = 0; phase = PH_WAIT; continue; }
                 high_byte = sc >> 31;
-                len = ra.z;
+                len = ra.z & ~kRecPacked;
                 p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
                 sd0 = rb.x; sd1 = rb.y; sd2 = rb.z; sd3 = rb.w;
                 if (cls & 0x200u) sd0 = vlo;                   // (ascending list: sd0 is the position in it; else sd0 / sd1 = smallest / largest window)

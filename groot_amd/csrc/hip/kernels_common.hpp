@@ -248,7 +248,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
                                               const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
                                               const uint32_t s2, const uint32_t s3, const bool high, const bool have_codes = false,
                                               const uint32_t code_f = 0, const uint32_t code_r = 0, const SeedAhead *ahead = nullptr, const bool asc = false,
-                                              const uint32_t max_win = 0)
+                                              const uint32_t max_win = 0, const uint32_t len_flags = 0)
 {
     // have_codes: the read is all ACGT and at least 12 bases long; code_f / code_r = 2-bit codes of oriented bases [0,12) of
     // the forward read / its reverse complement (base i at bits 2i)
@@ -321,7 +321,7 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
             if (at < kLongListCap) a.long_list[at] = r;
         }
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecSplit - 1u) | verdicts | (asc ? kRecAscending : 0u) | (high ? 0x80000000u : 0u));
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len | len_flags, min(n_hits, kRecSplit - 1u) | verdicts | (asc ? kRecAscending : 0u) | (high ? 0x80000000u : 0u));
         // (more than four seeds: the smallest and the largest window instead of the first two -- the align stage starts at the
         // smallest and knows when nothing is left without looking through the list)
         rq[1] = n_hits > 4 ? make_uint4(min_win, max_win, s2, s3) : make_uint4(s0, s1, s2, s3);
@@ -332,7 +332,8 @@ __device__ __forceinline__ void seed_epilogue(const SeedArgs &a, const uint32_t 
 // the same for a read known to be bases [o, o + WindowSize) of a window text row: its verdicts come from the table made at open
 __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uint32_t r, const uint64_t o0, const uint32_t len, const uint32_t q,
                                                     const uint32_t n_hits, const uint32_t min_win, const uint32_t s0, const uint32_t s1,
-                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes, const bool asc, const uint32_t max_win)
+                                                    const uint32_t s2, const uint32_t s3, const uint32_t vbyte, const uint32_t nodes, const bool asc, const uint32_t max_win,
+                                                    const uint32_t len_flags = 0)
 {
     a.seed_count[r] = n_hits;
     if (a.sort_key) {
@@ -342,7 +343,7 @@ __device__ __forceinline__ void seed_epilogue_known(const SeedArgs &a, const uin
     }
     if (a.read_rec) {
         uint4 *rq = reinterpret_cast<uint4 *>(a.read_rec + r);
-        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len, min(n_hits, kRecSplit - 1u) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u) | (asc ? kRecAscending : 0u));
+        rq[0] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), len | len_flags, min(n_hits, kRecSplit - 1u) | (a.sort_key ? (vbyte & 0x3Fu) << 24 : 0u) | (asc ? kRecAscending : 0u));
         rq[1] = n_hits > 4 ? make_uint4(min_win, max_win, s2, s3) : make_uint4(s0, s1, s2, s3);
     }
     seed_counters(a, r, q, n_hits);

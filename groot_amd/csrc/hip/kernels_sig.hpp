@@ -279,6 +279,16 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
     uint32_t rdw[kTextWords];
 #pragma unroll
     for (int j = 0; j < kTextWords; j++) rdw[j] = __builtin_amdgcn_alignbit(codes[(P >> 5) + j + 1], codes[(P >> 5) + j], P & 31);
+    // ... and for the first pass of the align stage, which then stages the read from two 16-byte loads instead of len unaligned bytes
+    uint32_t len_flags = 0;
+    if (a.packed) {
+        static_assert(kTextWords % 4 == 0, "whole 16-byte words");
+        uint4 *pk = a.packed + (size_t)r * a.packed_q;
+#pragma unroll
+        for (int j = 0; j < kTextWords / 4; j++)
+            if ((uint32_t)j < a.packed_q) pk[j] = make_uint4(rdw[4 * j], rdw[4 * j + 1], rdw[4 * j + 2], rdw[4 * j + 3]);
+        len_flags = kRecPacked;
+    }
     const uint32_t n_full = len >> 4, tail_mask = (1u << (2 * (len & 15))) - 1u;
     auto row_differs = [&](const uint8_t *row, uint32_t o) {
         uint32_t t[kTextWords + 1];
@@ -389,8 +399,8 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
         }
     }
     if (have_vbyte && (vbyte & kOutTab) && a.tab_idx) seed_epilogue_tab(a, r, q, n_hits, vbyte, s0, s1, s2, s3);
-    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == conf_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc, max_win);
-    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead, asc, max_win);   // all bytes are ACGT
+    else if (have_vbyte) seed_epilogue_known(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, vbyte, min_win == conf_id ? nodes_ahead : (uint32_t)ix.win_nodes[min_win], asc, max_win, len_flags);
+    else seed_epilogue(a, r, o0, len, q, n_hits, min_win, s0, s1, s2, s3, false, len >= 12, code_f, code_r, &ahead, asc, max_win, len_flags);   // all bytes are ACGT
 }
 
 // ---------------------------------------------------------------------------------------------
