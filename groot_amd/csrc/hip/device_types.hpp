@@ -354,10 +354,16 @@ struct LeanArgs {
     uint64_t *mask_first;
     uint32_t *trav_cnt;
     uint8_t *defer;                // [n_reads] by slot: 1 = left to align_kernel
+    uint4 *stk;                    // [n_reads][2][2] by slot: pending neighbours of the walk {node | long << 31, dist, path set}
+    groot_trav *ovf_trav;          // AlignArgs::ovf_* (traversals with ord >= 1)
+    uint64_t *ovf_mask;
+    uint32_t *ovf_cnt;
+    uint32_t ovf_cap;
     DeviceCounters *ctr;
 };
 
-// LDS dwords per lane: 2 zero dwords, the read at 16 bases per dword (one strand at a time), 2 zero dwords, 7 dwords of the seed window's record; odd
-__host__ __device__ inline uint32_t lean_stride_dw(uint32_t max_len) { return (((max_len + 15u) >> 4) + 11u) | 1u; }
+// LDS dwords per lane: 2 zero dwords, the read at 16 bases per dword (one strand at a time), 2 zero dwords, 7 dwords of the current window's record,
+// the read's (up to four) seed windows; odd
+__host__ __device__ inline uint32_t lean_stride_dw(uint32_t max_len) { return (((max_len + 15u) >> 4) + 15u) | 1u; }
 
 } // namespace groot

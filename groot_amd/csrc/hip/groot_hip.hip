@@ -191,6 +191,7 @@ struct groot_ctx {
     DevBuf<uint32_t> bases2;
     DevBuf<uint4> cn_pre2;
     DevBuf<uint8_t> win_ok;
+    DevBuf<uint4> lean_stk;                // LeanArgs::stk (align stream)
     bool lean = false;
     DevBuf<WinRec> win_rec;
     DevBuf<ExactEntry> exact;
@@ -733,6 +734,7 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         l.attempts = c->attempts_ptr;
         l.trav_first = w->trav_first.p; l.mask_first = w->mask_first.p; l.trav_cnt = w->trav_cnt.p;
         l.defer = w->defer.p; l.ctr = s->d_ctr.p;
+        l.stk = c->lean_stk.p; l.ovf_trav = c->ovf_trav.p; l.ovf_mask = c->ovf_mask.p; l.ovf_cnt = c->ovf_cnt.p; l.ovf_cap = c->ovf_cap;
         launch_align_lean(c->pw, l, dim3((s->n_reads + kBlock - 1) / kBlock), c->astream);
         HIP_TRY(c, hipGetLastError());
         size_t tb = 0;
@@ -1159,6 +1161,8 @@ static int finish_counters(groot_ctx *c, Slot *s)
         fprintf(stderr, "[groot lean] wavefronts %llu; per wavefront: %.1f iterations (with a level-1 / level-2 / level-3-4 / walk lane: %.1f / %.1f / %.1f / %.1f); lane-steps per wavefront: %.0f / %.0f / %.0f / %.0f; staging %.2f us, loop %.2f us\n",
                 h.dbg[151], (double)h.dbg[148] / nw, (double)h.dbg[140] / nw, (double)h.dbg[141] / nw, (double)h.dbg[142] / nw, (double)h.dbg[143] / nw,
                 (double)h.dbg[144] / nw, (double)h.dbg[145] / nw, (double)h.dbg[146] / nw, (double)h.dbg[147] / nw, (double)h.dbg[149] / nw / 100.0, (double)h.dbg[150] / nw / 100.0);
+        fprintf(stderr, "[groot lean] finished without an alignment %llu; left to align_kernel: seeds > 4: %llu, 2..4 (or none): %llu, byte > T / length: %llu, byte other than ACGT: %llu, window with an N: %llu, node with an N: %llu, N ahead: %llu, two neighbours: %llu\n",
+                h.dbg[160], h.dbg[161], h.dbg[162], h.dbg[163], h.dbg[164], h.dbg[165], h.dbg[166], h.dbg[167], h.dbg[168]);
     }
 #elif defined(GROOT_WORK_COUNTERS)
     for (int e = 0; e < 32; e++)
@@ -2448,6 +2452,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, hipMemset(w.vcount.p, 0, 4 * sizeof(uint32_t)));
     }
     HIP_TRY(c, c->trav_off.alloc(R));
+    if (c->lean) HIP_TRY(c, c->lean_stk.alloc((size_t)R * 4));
     HIP_TRY(c, c->ovf_cnt.alloc(kOvfShards + 2));
     if (int rc = alloc_ovf(c, c->kn.small_buffers ? 2u : std::max<uint32_t>(256, R / kOvfShards / 4))) return rc;
     // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)

@@ -5,9 +5,9 @@
 namespace groot {
 
 // ---------------------------------------------------------------------------------------------
-// K3, first pass: the reads whose whole graphMinion loop (graphminion.go:46-102) is ONE seed window and whose walks never have a
-// second neighbour to come back to -- five reads in six of an error-free batch.  A thread per read, in the processing order of the
-// seed stage (neighbouring lanes hold reads of the same window: they walk the same nodes in step), no phase scheduling, no stack:
+// K3, first pass: the reads with at most four seed windows whose walks have at most two neighbours pending at a time -- all but a
+// few in a hundred of an error-free batch.  A thread per read, in the processing order of the seed stage (neighbouring lanes hold
+// reads of the same window: they walk the same nodes in step), no phase scheduling among the lanes of a wavefront:
 //   * the read is staged in the lane's LDS slice at 2 bits per base (A=0 C=1 T=2 G=3, the code of the signature kernel), one strand
 //     at a time (the slice is reverse-complemented in place when AlignRead's forward hierarchy has failed: graphminion.go:94);
 //     32 bases of the current view come out of it with three ds_read_b32 and two v_alignbit;
@@ -17,13 +17,19 @@ namespace groot {
 //   * AlignRead's hierarchy (alignment.go:13-110) is followed candidate by candidate exactly as align_kernel does it (same filters:
 //     the seed stage's verdicts, the first min(8, ...) bases inside the node, the 8-mer set of the start position), so a read that
 //     finishes here produces, bit for bit, what align_kernel would have produced for it;
-//   * whatever does not fit -- more than one seed window, a byte other than ACGT, a node with an 'N', two neighbours that both take
-//     the next base (dfsRecursive would come back to the second: alignment.go:242-252) -- is left UNTOUCHED: the read's slot is
-//     flagged, a stream compaction keeps the flagged slots in processing order, and align_kernel walks them as before.
+//   * the graphMinion loop (graphminion.go:46-102) over the read's windows in ascending order, a graph done after its first alignment;
+//     a node where two neighbours take the next base (dfsRecursive comes back to the second: alignment.go:242-252) leaves the second
+//     on a stack of two entries per read in HBM;
+//   * whatever does not fit -- more than four seed windows, a byte other than ACGT, an 'N' in the graph, three neighbours that take
+//     the next base, a third pending neighbour -- is left to align_kernel: the read's slot is flagged, a stream compaction keeps the
+//     flagged slots in processing order, and align_kernel handles the read from scratch.  What the first pass has written for such a
+//     read by then are traversal records that align_kernel writes again, bit for bit, to the same places (ord 0: the read's own
+//     slot; ord >= 1: the overflow list, placed by (read, ord)); everything that counts -- IncrementSubPath calls, mapped /
+//     multimapped / alignments -- is kept in registers until the read is finished here.
 // ---------------------------------------------------------------------------------------------
 
 #ifndef GROOT_LEAN_WAVES
-#define GROOT_LEAN_WAVES 6
+#define GROOT_LEAN_WAVES 5
 #endif
 constexpr int kLeanWaves = GROOT_LEAN_WAVES;
 
@@ -55,8 +61,9 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
     extern __shared__ __attribute__((aligned(16))) uint32_t lean_lds[];
     __shared__ unsigned long long red[4];
     uint32_t *my = lean_lds + (size_t)threadIdx.x * a.lds_stride_dw;
-    uint32_t *W = my + (a.lds_stride_dw - 7u);                 // seed, OffSet, l1_hi, cn_begin, cn_end, seed_s0, seed_len of the read's window
-    enum : int { W_SEED, W_OFF0, W_L1HI, W_CNB, W_CNE, W_S0, W_SLEN };
+    // behind the read: the current window's seed, OffSet, l1_hi, cn_begin, cn_end, seed_s0, seed_len; the read's seed windows, ascending
+    uint32_t *W = my + (a.lds_stride_dw - 11u);
+    enum : int { W_SEED, W_OFF0, W_L1HI, W_CNB, W_CNE, W_S0, W_SLEN, W_WIN };
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_todo = min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads));
     // the seed stage ran out of slots or rows: the host grows them and runs the batch again (align_kernel returns at once, too)
@@ -64,25 +71,39 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 4
     const unsigned long long lw_t0 = wall_clock64();
 #endif
-    enum : uint32_t { ST_ADV, ST_GEN, ST_WALK, ST_DONE, ST_DEFER, ST_IDLE };
+    enum : uint32_t { ST_ADV, ST_GEN, ST_WALK, ST_SEED, ST_DONE, ST_DEFER, ST_IDLE };
     uint32_t st = ST_IDLE;
-    uint32_t r = 0, len = 0, w = 0, vbits = 0;
+#if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 4
+    uint32_t why = 0;          // why the read was left to align_kernel: 1 more than four seeds, 3 byte > 'T' / length, 4 a byte other than ACGT, 5 a window with an 'N', 6 a node with an 'N', 7 an 'N' ahead, 8 three neighbours, 9 a third pending neighbour
+#define LEAN_WHY(x) (why = (x))
+#else
+#define LEAN_WHY(x) ((void)0)
+#endif
+    uint32_t r = 0, len = 0, cnt = 0, vbits = 0;
+    uint32_t g = kEmpty;          // graph of the current window
     if (slot < n_todo && !stale) {
         r = a.perm[slot];
         uint4 ra, rb;
         load32(a.read_rec + r, ra, rb);
         const uint32_t sc = ra.w;
         len = ra.z & ~kRecPacked;
-        w = rb.x;
+        cnt = sc & (kRecSplit - 1u);
         vbits = (sc >> 24) & 0x3Fu;
         st = ST_ADV;
-        // one seed window, no byte > 'T' (RevComplement would panic on it: align_kernel counts that), a read the slice holds
-        if ((sc & kRecCountMask) != 1u || (sc >> 31) || len > a.max_len || len < 12u) st = ST_DEFER;
+        // at most four seed windows (they travel in the record), no byte > 'T' (RevComplement would panic on it: align_kernel counts that), a read the slice holds
+        if (cnt == 0u || cnt > 4u || (sc & kRecSplit) || (sc >> 31) || len > a.max_len || len < 12u) { st = ST_DEFER; LEAN_WHY(cnt > 4u ? 1 : 3); }
         else {
+            // the windows in ascending order (graphminion.go:50 sorts the seeds; the build's canonical order is the window id)
+            uint32_t s0 = rb.x, s1 = cnt > 1u ? rb.y : kEmpty, s2 = cnt > 2u ? rb.z : kEmpty, s3 = cnt > 3u ? rb.w : kEmpty;
+            { uint32_t t; if (s0 > s1) { t = s0; s0 = s1; s1 = t; } if (s2 > s3) { t = s2; s2 = s3; s3 = t; } if (s0 > s2) { t = s0; s0 = s2; s2 = t; }
+              if (s1 > s3) { t = s1; s1 = s3; s3 = t; } if (s1 > s2) { t = s1; s1 = s2; s2 = t; } }
             const uint8_t *p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
             uint4 wa, wb;
-            load32(a.win_rec + w, wa, wb);
-            const uint32_t ok = a.win_ok[w];
+            load32(a.win_rec + s0, wa, wb);
+            uint32_t ok = a.win_ok[s0];
+            if (cnt > 1u) ok &= a.win_ok[s1];
+            if (cnt > 2u) ok &= a.win_ok[s2];
+            if (cnt > 3u) ok &= a.win_ok[s3];
             // ---- stage the read at 16 bases per dword ----
             my[0] = 0; my[1] = 0;
             uint32_t bad = 0;
@@ -117,17 +138,33 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
                 my[2 + i] = codes;
             }
             my[2 + nd] = 0; my[3 + nd] = 0;
+            g = wa.x;
             W[W_SEED] = wa.y; W[W_OFF0] = wa.z; W[W_L1HI] = wa.w;
             W[W_CNB] = wb.x; W[W_CNE] = wb.y; W[W_S0] = wb.z; W[W_SLEN] = wb.w;
-            if (bad || !ok) st = ST_DEFER;
+            W[W_WIN] = s0; W[W_WIN + 1] = s1; W[W_WIN + 2] = s2; W[W_WIN + 3] = s3;
+            if (bad || !ok) { st = ST_DEFER; LEAN_WHY(bad ? 4 : 5); }
         }
     }
 
+    // ---- graphMinion loop (graphminion.go:46-102) ----
+    uint32_t si = 1;              // seed windows taken so far (the first one's record came with the read)
+    uint32_t done_graph = kEmpty, n_graphs = 1, ord = 0, calls = 1;   // calls: bit i = IncrementSubPath was called for window i (:67)
+    uint32_t alns = 0;
     // ---- the view of the read a hierarchy level works on: orientation, clip, effective length (alignment.go:72-103) ----
     uint32_t rc = 0, level = 0, eff = len;
     uint32_t sbit = 64;           // bit of the slice where the view's first base sits
     // view bases [d, d + 32) at 2 bits each (bits past the view's end are don't-care)
     auto chunk = [&](uint32_t d) -> uint64_t { return lean_bits64(my, sbit + 2u * d); };
+    // the slice becomes the reverse complement of what it holds, padded to whole dwords at the other end: dword k <- revcomp16(dword nd-1-k)
+    auto flip = [&]() {
+        const uint32_t nd = (len + 15u) >> 4;
+        for (uint32_t k2 = 0; 2u * k2 < nd; k2++) {
+            const uint32_t x = my[2 + k2], y = my[1 + nd - k2];
+            my[2 + k2] = lean_revcomp16(y);
+            my[1 + nd - k2] = lean_revcomp16(x);
+        }
+        rc ^= 1u;
+    };
     uint32_t p16 = 0;             // first eight bases of the view
     uint64_t need = 0;            // their two bits in a start position's 8-mer set
     // candidate cursor: level 1 -- pos = next offset of the seed node, lim = l1_hi; level 2 -- pos = ContainedNodes entry, lim = cn_end,
@@ -137,11 +174,12 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
     uint32_t node0 = 0, noff0 = 0, cur = 0, cur_s0 = 0, coff = 0, dist = 0;
     bool cur_long = false;
     uint64_t cur64 = 0, m0 = 0, m1 = 0, m2 = 0;
-    bool emitted = false;
+    uint32_t emitted = 0, sp = 0; // traversals of this AlignRead call; pending neighbours on the read's stack
+    uint4 *stk = a.stk + (size_t)slot * 4;
 
-    // verdict of the seed stage on the read's (only) seed window, current orientation: bit 0 levels 1-2, bit 1 level 3, bit 2 level 4
-    auto verdict = [&](uint32_t bit) -> bool { return ((vbits >> (rc ? 3 : 0)) >> bit) & 1u; };
-    // move to level lv / the next one that has a candidate range / the other orientation; ST_DONE when nothing is left
+    // verdict of the seed stage on the read's FIRST seed window, current orientation: bit 0 levels 1-2, bit 1 level 3, bit 2 level 4
+    auto verdict = [&](uint32_t bit) -> bool { return si == 1u && (((vbits >> (rc ? 3 : 0)) >> bit) & 1u); };
+    // move to level lv / the next one that has a candidate range / the other orientation; ST_SEED when AlignRead found nothing for the window
     auto enter = [&](uint32_t lv) {
         const uint32_t off0 = W[W_OFF0], seed_len = W[W_SLEN];
         bool view = false;
@@ -172,18 +210,8 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
                 break;
             }
             // AlignRead found nothing in this orientation: graphminion.go:94 RevComplement
-            if (rc == 0) {
-                rc = 1; lv = 1;
-                // the slice becomes the reverse complement, padded to whole dwords in FRONT: dword k <- revcomp16(dword nd-1-k)
-                const uint32_t nd = (len + 15u) >> 4;
-                for (uint32_t k2 = 0; 2u * k2 < nd; k2++) {
-                    const uint32_t x = my[2 + k2], y = my[1 + nd - k2];
-                    my[2 + k2] = lean_revcomp16(y);
-                    my[1 + nd - k2] = lean_revcomp16(x);
-                }
-                continue;
-            }
-            st = ST_DONE;
+            if (rc == 0) { flip(); lv = 1; continue; }
+            st = ST_SEED;                                          // neither orientation: the read's next window (the slice is flipped back there)
             return;
         }
         st = ST_GEN;
@@ -202,11 +230,30 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
 #else
 #define LEAN_EV(i, pred) ((void)0)
 #endif
-
 #ifdef GROOT_LEAN_PROBE      // (tools: 1 = every read is left to align_kernel right after staging: what the prologue costs)
-    if (GROOT_LEAN_PROBE == 1 && st <= ST_WALK) st = ST_DEFER;
+    if (GROOT_LEAN_PROBE == 1 && st <= ST_SEED) st = ST_DEFER;
 #endif
-    while (__ballot(st <= ST_WALK)) {
+
+    while (__ballot(st <= ST_SEED)) {
+        if (st == ST_SEED) {
+            // ---- the read's next seed window, if any (graphminion.go:52-100) ----
+            if (si >= cnt) st = ST_DONE;
+            else {
+                const uint32_t w = W[W_WIN + si];
+                uint4 wa, wb;
+                load32(a.win_rec + w, wa, wb);
+                si++;
+                if (wa.x != g) { g = wa.x; n_graphs++; }
+                if (g != done_graph) {                             // :96-98 a graph is done after its first alignment
+                    calls |= 1u << (si - 1u);                      // :67 IncrementSubPath
+                    W[W_SEED] = wa.y; W[W_OFF0] = wa.z; W[W_L1HI] = wa.w;
+                    W[W_CNB] = wb.x; W[W_CNE] = wb.y; W[W_S0] = wb.z; W[W_SLEN] = wb.w;
+                    if (rc) flip();                                // the minion's copy of the read is forward again (two flips, :94)
+                    level = 0; emitted = 0;
+                    st = ST_ADV;
+                }
+            }
+        }
         if (st == ST_ADV) enter(level + 1u);
 #if defined(GROOT_WORK_COUNTERS) && GROOT_WORK_COUNTERS == 4
         lw[8]++;
@@ -251,7 +298,7 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
                 st = ST_WALK;
             } else if (pos >= lim) st = ST_ADV;
         } else if (st == ST_WALK) {
-            // ---- one node of the walk (dfsRecursive, alignment.go:196-254, for a read that never has two neighbours to choose from) ----
+            // ---- one node of the walk (dfsRecursive, alignment.go:196-254) ----
             // everything the step may need is asked for at once: the record; for a walk that starts inside its node the graph bases from
             // `bases2`, else the extension of a long node; for a start position at offset <= 10 its 8-mer set
             const uint4 *q = reinterpret_cast<const uint4 *>(a.nodes + cur);
@@ -276,9 +323,9 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
             }
             const uint32_t seq_len = q0.y, dk = q0.z;
             if (coff == 0u) gch[0] = (uint64_t)q2.x | ((uint64_t)q2.y << 32);
-            bool fail = (l2b & need) != need;                     // the start position cannot spell the view's first eight bases
-            if (dk & kLeanNo) st = ST_DEFER;
-            else if (!fail) {
+            bool over = (l2b & need) != need;                     // this branch of the walk is over (here: the start position cannot spell the view's first eight bases)
+            if (dk & kLeanNo) { st = ST_DEFER; LEAN_WHY(6); }
+            else if (!over) {
                 const uint32_t take = min(seq_len - coff, eff - dist);
                 uint64_t diff = (gch[0] ^ cur64) & lean_lowmask((int)take);
                 if (__ballot(take > 32u)) {
@@ -286,8 +333,8 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
                     for (int c = 1; c < NCH; c++)
                         if (take > 32u * c) diff |= (gch[c] ^ chunk(dist + 32u * c)) & lean_lowmask((int)take - 32 * c);
                 }
-                fail = diff != 0ull;
-                if (!fail) {
+                over = diff != 0ull;
+                if (!over) {
                     dist += take;
                     m0 &= (uint64_t)q2.z | ((uint64_t)q2.w << 32);
                     m1 &= (uint64_t)q3.x | ((uint64_t)q3.y << 32);
@@ -295,30 +342,73 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
                     const bool any = (m0 | m1 | m2) != 0ull;
                     const uint32_t deg = dk & 7u;
                     if (dist == eff || deg == 0u) {               // :229-236 report the traversal
-                        if (any) { emitted = true; st = ST_DONE; }
-                        else fail = true;
-                    } else if (!any) fail = true;                 // no path left: descendants cannot yield ids
+                        if (any) {
+                            groot_trav t;
+                            t.read_id = a.first_read_id + r; t.graph_id = g; t.node = node0; t.offset = noff0;
+                            t.ord = (uint16_t)ord;
+                            t.flags = (uint8_t)((rc ? GROOT_TRAV_RC : 0u) | (level == 3u ? GROOT_TRAV_START_CLIP : level == 4u ? GROOT_TRAV_END_CLIP : 0u) | (emitted == 0u ? GROOT_TRAV_FIRST : 0u));
+                            t.reserved = 0;
+                            if (ord == 0u) {
+                                a.trav_first[r] = t;
+                                a.mask_first[(size_t)r * PW] = m0; a.mask_first[(size_t)r * PW + 1] = m1; a.mask_first[(size_t)r * PW + 2] = m2;
+                            } else {
+                                const uint32_t shard = blockIdx.x & (kOvfShards - 1);
+                                const uint32_t at = atomicAdd(&a.ovf_cnt[shard], 1u);
+                                if (at < a.ovf_cap) {
+                                    const size_t o = (size_t)shard * a.ovf_cap + at;
+                                    a.ovf_trav[o] = t;
+                                    a.ovf_mask[o * PW] = m0; a.ovf_mask[o * PW + 1] = m1; a.ovf_mask[o * PW + 2] = m2;
+                                } else atomicOr(&a.ctr->flags, kFlagOvfOverflow);
+                            }
+                            ord++; emitted++;
+                            alns += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2));
+                        }
+                        over = true;
+                    } else if (!any) over = true;                 // no path left: descendants cannot yield ids
                     else {
+                        // :242-252 neighbours in OutEdges order; one whose first base differs from the read's next base dies in its first comparison
                         cur64 = chunk(dist);
                         const uint32_t nextb = (uint32_t)cur64 & 3u;
                         const uint32_t ed[4] = {q1.x, q1.y, q1.z, q1.w};
-                        uint32_t hits = 0, pick = 0;
-                        bool wild = false, plong = false;
+                        uint32_t hits = 0, pick = 0, alt = 0;
+                        bool wild = false;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             const uint32_t code = (dk >> (8 + 4 * e)) & 15u;
                             if ((uint32_t)e < deg) {
                                 wild |= code == 4u;
-                                if (code == nextb) { hits++; pick = ed[e]; plong = (dk >> (24 + e)) & 1u; }
+                                if (code == nextb) {
+                                    const uint32_t nx = ed[e] | (((dk >> (24 + e)) & 1u) << 31);    // bit 31: a long node
+                                    if (hits == 0u) pick = nx; else alt = nx;
+                                    hits++;
+                                }
                             }
                         }
-                        if (wild || hits > 1u) st = ST_DEFER;   // an 'N' ahead, or a second neighbour to come back to: align_kernel's business
-                        else if (hits == 0u) fail = true;
-                        else { cur = pick; coff = 0; cur_long = plong; }
+                        if (wild || hits > 2u || (hits == 2u && sp == 2u)) { st = ST_DEFER; LEAN_WHY(wild ? 7 : hits > 2u ? 8 : 9); }   // align_kernel's business
+                        else if (hits == 0u) over = true;
+                        else {
+                            if (hits == 2u) {                      // the second neighbour stays pending
+                                stk[2 * sp] = make_uint4(alt, dist, (uint32_t)m0, (uint32_t)(m0 >> 32));
+                                stk[2 * sp + 1] = make_uint4((uint32_t)m1, (uint32_t)(m1 >> 32), (uint32_t)m2, (uint32_t)(m2 >> 32));
+                                sp++;
+                            }
+                            cur = pick & 0x7FFFFFFFu; coff = 0; cur_long = pick >> 31;
+                        }
                     }
                 }
             }
-            if (fail && st == ST_WALK) st = pos >= lim ? ST_ADV : ST_GEN;   // the start position yields nothing: on with the hierarchy
+            if (over && st == ST_WALK) {
+                if (sp) {                                          // resume at the newest pending neighbour
+                    sp--;
+                    const uint4 h0 = stk[2 * sp], h1 = stk[2 * sp + 1];
+                    cur = h0.x & 0x7FFFFFFFu; cur_long = h0.x >> 31; coff = 0; dist = h0.y;
+                    m0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32);
+                    m1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32);
+                    m2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
+                    cur64 = chunk(dist);
+                } else if (emitted) { done_graph = g; st = ST_SEED; }      // performAlignment is over with an alignment for (read, graph)
+                else st = pos >= lim ? ST_ADV : ST_GEN;                    // the start position yields nothing: on with the hierarchy
+            }
         }
     }
 
@@ -330,28 +420,26 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
         atomicAdd(&a.ctr->dbg[150], t2 - lw_t1);
         atomicAdd(&a.ctr->dbg[151], 1ull);
     }
+    for (uint32_t y = 1; y <= 9; y++) {
+        const unsigned long long b = __ballot(st == ST_DEFER && why == y);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(&a.ctr->dbg[160 + y], (unsigned long long)__popcll(b));
+    }
+    { const unsigned long long b = __ballot(st == ST_DONE && !ord); if (b && (threadIdx.x & 63) == 0) atomicAdd(&a.ctr->dbg[160], (unsigned long long)__popcll(b)); }
 #endif
     // ---- what the read leaves behind ----
     const bool fin = st == ST_DONE;
     if (slot < a.n_reads) a.defer[slot] = st == ST_DEFER ? 1 : 0;
-    unsigned long long alns = 0, mapped = 0;
+    unsigned long long n_alns = 0, mapped = 0, multimapped = 0;
     if (fin) {
-        a.trav_cnt[r] = emitted ? 1u : 0u;
+        a.trav_cnt[r] = ord;
         mapped = 1;                                               // boss.go:195-200
-        if (emitted) {
-            groot_trav t;
-            t.read_id = a.first_read_id + r; t.graph_id = a.win_rec[w].graph; t.node = node0; t.offset = noff0;
-            t.ord = 0;
-            t.flags = (uint8_t)((rc ? GROOT_TRAV_RC : 0u) | (level == 3u ? GROOT_TRAV_START_CLIP : level == 4u ? GROOT_TRAV_END_CLIP : 0u) | GROOT_TRAV_FIRST);
-            t.reserved = 0;
-            a.trav_first[r] = t;
-            a.mask_first[(size_t)r * PW] = m0; a.mask_first[(size_t)r * PW + 1] = m1; a.mask_first[(size_t)r * PW + 2] = m2;
-            alns = (unsigned long long)(__popcll(m0) + __popcll(m1) + __popcll(m2));
-        }
+        multimapped = n_graphs > 1u ? 1 : 0;
+        n_alns = alns;
     }
-    if (a.update_weights) {                                       // graphminion.go:67 IncrementSubPath, once: the read's only seed window
-        // neighbouring lanes mostly hold reads of the same window: one atomic per RUN of equal cells among the lanes that finished here
-        const uint64_t cell = (uint64_t)(fin ? a.q_row[len - a.k + 1u] : 0u) * a.n_windows + w;
+    if (a.update_weights) {                                       // graphminion.go:67 IncrementSubPath for the windows it was called on
+        // neighbouring lanes mostly hold reads of the same first window: one atomic per RUN of equal cells among the lanes that finished here
+        const uint32_t qrow = fin ? a.q_row[len - a.k + 1u] : 0u;
+        const uint64_t cell = (uint64_t)qrow * a.n_windows + (fin ? W[W_WIN] : 0u);
         const unsigned long long here = __ballot(fin);
         const unsigned lane_ = threadIdx.x & 63u;
         const unsigned long long below = here & ((1ull << lane_) - 1ull);
@@ -364,12 +452,17 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
             const unsigned long long run = here & ~((1ull << lane_) - 1ull) & (after ? ((1ull << (__ffsll(after) - 1)) - 1ull) : ~0ull);
             atomicAdd(&a.attempts[cell], (uint32_t)__popcll(run));
         }
+        if (fin && (calls >> 1))                                  // (the first window is always called: bit 0)
+            for (uint32_t i = 1; i < cnt; i++)
+                if ((calls >> i) & 1u) atomicAdd(&a.attempts[(uint64_t)qrow * a.n_windows + W[W_WIN + i]], 1u);
     }
-    alns = block_sum(alns, red);
+    n_alns = block_sum(n_alns, red);
     mapped = block_sum(mapped, red);
+    multimapped = block_sum(multimapped, red);
     if (threadIdx.x == 0) {
-        if (alns) atomicAdd(&a.ctr->alignments, alns);
+        if (n_alns) atomicAdd(&a.ctr->alignments, n_alns);
         if (a.update_weights && mapped) atomicAdd(&a.ctr->mapped, mapped);
+        if (a.update_weights && multimapped) atomicAdd(&a.ctr->multimapped, multimapped);
         if (mapped) atomicAdd(&a.ctr->lean_reads, (unsigned int)mapped);
     }
 }
