@@ -238,6 +238,8 @@ struct groot_ctx {
     uint64_t next_ticket = 1;
     Slot *waited = nullptr;                // the batch groot_hip_wait collected (released by the next submit / wait)
     double todo_frac = 1.0;                // share of the latest finished batch's reads that the first seed kernel left to the list pass
+    double lean_left_frac = 1.0;           // share of the latest finished batch's reads that the first pass of the align stage left to the second
+    uint32_t n_cu = 256;
     double dfs_frac = 1.0;                 // share of the latest finished batch's reads that needed the align stage's graph walk (the rest: no seeds / tabulated outcomes)
     double trav_per_read = 1.25;           // traversal records per read of the latest finished batch: sizes the next copy-out
     double bytes_per_trav = 0;             // compact path-set bytes per traversal, likewise (0 = not seen yet: 8 * path_words)
@@ -690,6 +692,12 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     // next batch are the longer stage, and a persistent grid of two workgroups per CU leaves them half the registers: configs[2] with 1 % substitutions
     // 2 345 -> 2 680 Mreads/s; no difference on mixed-length batches; on error-free reads, where every read is walked, the full grid is 4 % faster)
     else if (c->dfs_frac >= kSparseBelow && c->dfs_frac < 0.6 && !s->mixed_len && blocks >= 4) blocks /= 2;
+    // (the first pass takes most reads: what it left in the latest batch sizes the persistent grid of the second -- a wavefront per 64 reads left,
+    // at least one workgroup per CU; the registers it does not hold go to the next batch's hashing kernels)
+    if (c->lean && !c->tab_capture && c->lean_left_frac < 0.25) {
+        uint32_t want = (uint32_t)(c->lean_left_frac * 1.25 * (double)s->n_reads / 64.0 / (kBlock / 64)) + 1u;
+        blocks = std::max(1u, std::min(blocks, std::max(want, c->n_cu)));
+    }
     a.n_threads = blocks * kBlock;
     a.stk_depth = c->stk_depth;
     // stage reads in LDS when 256 lanes x (longest read + slack) stays within 64 KB
@@ -1188,6 +1196,7 @@ static int finish_counters(groot_ctx *c, Slot *s)
     // the records were copied out by copy_out_kernel right behind the kernels; after a redo they are fetched again here
     if (s->n_reads) c->trav_per_read = (double)s->n_trav / (double)s->n_reads;
     if (s->n_reads && !c->tab_capture) c->dfs_frac = (double)h.seeded_reads / (double)s->n_reads;
+    if (s->n_reads && !c->tab_capture && s->lean_used) c->lean_left_frac = (double)(h.seeded_reads - std::min(h.seeded_reads, h.lean_reads)) / (double)s->n_reads;
     if (s->n_reads && (s->sig_used || s->text_used)) c->todo_frac = (double)h.todo_reads / (double)s->n_reads;
     if (s->n_reads && !c->tab_capture && c->dix.text_tab) {
         c->text_hit_frac = s->text_used ? 1.0 - (double)h.todo_reads / (double)s->n_reads : (double)h.tab_reads / (double)s->n_reads;
@@ -2458,6 +2467,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
     // the align kernel is persistent: exactly the workgroups that are resident at once (GROOT_ALIGN_WAVES per SIMD = per CU)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    c->n_cu = (uint32_t)std::max(n_cu, 1);
     uint32_t per_cu = c->pw > 3 ? kAlignWavesWide : kAlignWaves;
     // (3 or 2 workgroups of the persistent grid per CU instead of 4, so that the next batch's hashing kernels find free registers from the start: measured in
     // round 4 -- 3: no difference on any kernel-path workload, 2: mixed 8 M 1 022 -> 983, configs[2] through the kernels 1 861 -> 1 740 Mreads/s)

@@ -83,6 +83,13 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
     uint32_t g = kEmpty;          // graph of the current window
     if (slot < n_todo && !stale) {
         r = a.perm[slot];
+        // (asked for together with the record: the read's codes, if the signature kernel left them)
+        uint4 pk0 = make_uint4(0, 0, 0, 0), pk1 = pk0, pk2 = pk0, pk3 = pk0;
+        if (a.packed) {
+            const uint4 *pk = a.packed + (size_t)r * a.packed_q;
+            pk0 = pk[0]; pk1 = pk[1];
+            if (a.packed_q > 2u) { pk2 = pk[2]; pk3 = pk[3]; }
+        }
         uint4 ra, rb;
         load32(a.read_rec + r, ra, rb);
         const uint32_t sc = ra.w;
@@ -100,23 +107,17 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
             const uint8_t *p = a.seq + ((uint64_t)ra.x | ((uint64_t)ra.y << 32));
             uint4 wa, wb;
             load32(a.win_rec + s0, wa, wb);
-            uint32_t ok = a.win_ok[s0];
-            if (cnt > 1u) ok &= a.win_ok[s1];
-            if (cnt > 2u) ok &= a.win_ok[s2];
-            if (cnt > 3u) ok &= a.win_ok[s3];
+            // (one trip: the first window's record and every window's flag)
+            const uint32_t ok = (uint32_t)a.win_ok[s0] & a.win_ok[cnt > 1u ? s1 : s0] & a.win_ok[cnt > 2u ? s2 : s0] & a.win_ok[cnt > 3u ? s3 : s0];
             // ---- stage the read at 16 bases per dword ----
             my[0] = 0; my[1] = 0;
             uint32_t bad = 0;
             const uint32_t nd = (len + 15u) >> 4;
-            if ((ra.z & kRecPacked) && a.packed) {             // the signature kernel left its codes (all ACGT): packed_q 16-byte loads
-                const uint4 *pk = a.packed + (size_t)r * a.packed_q;
-                for (uint32_t i = 0; 4u * i < nd; i++) {
-                    const uint4 v = pk[i];
-                    my[2 + 4 * i] = v.x;
-                    if (4u * i + 1u < nd) my[3 + 4 * i] = v.y;
-                    if (4u * i + 2u < nd) my[4 + 4 * i] = v.z;
-                    if (4u * i + 3u < nd) my[5 + 4 * i] = v.w;
-                }
+            if ((ra.z & kRecPacked) && a.packed) {             // the signature kernel left its codes (all ACGT)
+                const uint32_t c[16] = {pk0.x, pk0.y, pk0.z, pk0.w, pk1.x, pk1.y, pk1.z, pk1.w, pk2.x, pk2.y, pk2.z, pk2.w, pk3.x, pk3.y, pk3.z, pk3.w};
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if ((uint32_t)i < nd) my[2 + i] = c[i];
             } else
             for (uint32_t i = 0; i < nd; i++) {                // 16 bases = one 16-byte load (at most 15 bytes past the read's end) = one dword of codes
                 uint4 v;
@@ -297,12 +298,17 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
                 m0 = m1 = m2 = ~0ull;
                 st = ST_WALK;
             } else if (pos >= lim) st = ST_ADV;
-        } else if (st == ST_WALK) {
+        }
+        if (st == ST_WALK) {
             // ---- one node of the walk (dfsRecursive, alignment.go:196-254) ----
             // everything the step may need is asked for at once: the record; for a walk that starts inside its node the graph bases from
             // `bases2`, else the extension of a long node; for a start position at offset <= 10 its 8-mer set
             const uint4 *q = reinterpret_cast<const uint4 *>(a.nodes + cur);
+#if defined(GROOT_LEAN_PROBE) && GROOT_LEAN_PROBE == 2   // (tools: one 16-byte load of four less per step -- what do the loads cost?  wrong results on graphs of more than 64 paths)
+            const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = make_uint4(~0u, ~0u, ~0u, ~0u);
+#else
             const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+#endif
             uint64_t gch[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) gch[c] = 0;

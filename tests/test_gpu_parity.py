@@ -529,17 +529,19 @@ def _per_read(t, m, R):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("workload", ["c2", "sub1", "mixed99"])
+@pytest.mark.parametrize("workload", ["c2", "sub1", "mixed99", "mixed90"])
 def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypatch, workload):
     """The hashing and graph-walk kernels at the size bench.py times them (memo off: GROOT_MEMO_OFF), read by read: the product -- signature
     kernel on a few slots of the sketch, list pass, align kernel -- against the same library with GROOT_NO_SIG=1 (every read through the
     full-width kernel: all S slots at 64 bits, exact table / LSH Forest: an independent seeding path), on 10 M error-free 100 bp reads
-    (configs[2]), the same with 1 % substitutions, and 8 M reads of 75..150 bases on resfinder.90 (configs[4]); then the oracle on 20 000 of
-    them.  A kernel that is wrong on one read in a million is invisible to oracle comparisons on 10^4..10^5 reads (round 4 had one): at this
+    (configs[2]), the same with 1 % substitutions, and 8 M reads of 75..150 bases on resfinder.90 (configs[4]) at t = 0.99 and at t = 0.90 (the
+    LSH-Forest branch: lsh_heavy_kernel, the longest list pass); against the same library with GROOT_NO_LEAN=1 (the align stage without its
+    first pass: every record, path set and call count must be the same); then the oracle on 20 000 of them.  A kernel that is wrong on one read in a million is invisible to oracle comparisons on 10^4..10^5 reads (round 4 had one): at this
     size it shows.  khf.go:35-55, lshe.go:153-175, graphminion.go:46-102, alignment.go:13-254."""
     import torch
 
-    mixed = workload == "mixed99"
+    mixed = workload.startswith("mixed")
+    threshold = 0.90 if workload == "mixed90" else 0.99
     index = resfinder_index if mixed else argannot_index
     dev = torch.device("cuda", 0)
     cat, o, lens = synth.reference_sequences(index)
@@ -571,15 +573,16 @@ def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypa
                 other = acgt[(cur + 1 + torch.randint(0, 3, blk.shape, generator=g, device=dev)) % 4]
                 rows[c0:c0 + 1_000_000] = torch.where(hit & torch.isin(blk, acgt), other, blk)
     torch.cuda.synchronize()
-    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG"):
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG", "GROOT_NO_LEAN"):
         monkeypatch.delenv(v, raising=False)
 
-    def run(no_sig):
-        if no_sig:
-            monkeypatch.setenv("GROOT_NO_SIG", "1")
-        else:
-            monkeypatch.delenv("GROOT_NO_SIG", raising=False)
-        al = device.Aligner(index, max_batch_reads=R, max_read_len=256, max_batch_bases=total + 64, memo_budget_mb=device.MEMO_OFF)
+    def run(no_sig, no_lean=False):
+        for var, on in (("GROOT_NO_SIG", no_sig), ("GROOT_NO_LEAN", no_lean)):
+            if on:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        al = device.Aligner(index, threshold=threshold, max_batch_reads=R, max_read_len=256, max_batch_bases=total + 64, memo_budget_mb=device.MEMO_OFF)
         out = []
         for rep in range(2):                               # twice: the second run must repeat the first
             al.attempts_reset()
@@ -593,8 +596,14 @@ def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypa
         return c0, n0, a0, att0, t, m
 
     c, n, a, att, t, m = run(False)
+    # the align stage without its first pass (align_kernel alone): the same records, path sets, call counts
+    cl, _, _, attl, tl, ml = run(False, no_lean=True)
+    assert cl["lean_reads"] == 0 and c["lean_reads"] > (0.3 if mixed else 0.8 if workload == "c2" else 0.3) * c["walked_reads"], (c, cl)
+    assert np.array_equal(t, tl) and np.array_equal(m, ml) and np.array_equal(att, attl)
+    assert {k: v for k, v in c.items() if k != "lean_reads"} == {k: v for k, v in cl.items() if k != "lean_reads"}
+    del tl, ml
     cf, nf, af, attf, _, _ = run(True)
-    assert cf["full_sketch_reads"] == R and c["full_sketch_reads"] < (0.5 if mixed else 0.2) * R
+    assert cf["full_sketch_reads"] == R and (c["full_sketch_reads"] < (0.5 if mixed else 0.2) * R or threshold < 0.99)
     assert c["walked_reads"] == c["mapped"] or mixed or workload == "sub1"     # memo off: nothing is answered from a table
     bad = np.flatnonzero((n != nf) | (a != af))
     assert len(bad) == 0, "%d of %d reads differ between the signature path and the full-width path, first: %s" % (len(bad), R, bad[:10])
@@ -608,7 +617,7 @@ def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypa
     lens_h = (off_h[pick + 1] - off_h[pick])
     idx = (np.repeat(off_h[pick], lens_h) + (np.arange(int(lens_h.sum())) - np.repeat(np.cumsum(lens_h) - lens_h, lens_h)))
     host_seq = d_seq[torch.from_numpy(idx).to(dev)].cpu().numpy()
-    orun = O.Run(index)
+    orun = O.Run(index, threshold)
     orun.batch(host_seq, np.concatenate([[0], np.cumsum(lens_h)]).astype(np.uint64))
     oal = orun.alns()
     sel = np.isin(t["read_id"], pick)
