@@ -74,7 +74,7 @@ template <class T> struct PinBuf {
 // compare the tiers with each other and with the CPU checker); TEST_SMALL_BUFFERS starts every growable buffer and list too small, so that
 // a test batch walks the grow-and-redo and the fall-back paths; OPEN_STATS prints where groot_hip_open spent its time.
 struct Knobs {
-    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false, poison = false, no_lean = false;
+    bool no_outcome_table = false, no_text_table = false, no_sig = false, force_rccl = false, small_buffers = false, open_stats = false, poison = false, lean = false;
     static Knobs read()
     {
         Knobs k;
@@ -82,7 +82,7 @@ struct Knobs {
         k.no_sig = getenv("GROOT_NO_SIG") != nullptr;                     k.force_rccl = getenv("GROOT_FORCE_RCCL") != nullptr;
         k.small_buffers = getenv("GROOT_TEST_SMALL_BUFFERS") != nullptr;  k.open_stats = getenv("GROOT_OPEN_STATS") != nullptr;
         k.poison = getenv("GROOT_TEST_POISON") != nullptr;
-        k.no_lean = getenv("GROOT_NO_LEAN") != nullptr;                   // the align stage without its first pass (tests compare the two)
+        k.lean = getenv("GROOT_LEAN") != nullptr;                         // the align stage WITH its first pass (kernels_lean.hpp; off by default: DESIGN.md section 3)
         return k;
     }
 };
@@ -169,6 +169,7 @@ struct groot_ctx {
     Knobs kn;
     uint32_t s = 0, k = 0, max_k = 0, l_max = 0, pw_view = 0, pw = 0, n_windows = 0, max_q = 0, band_hash_bits = 0;
     hipEvent_t h2d_last = nullptr;         // the copy-in of the newest host-fed batch (its slot's event)
+    Slot *newest = nullptr;                // the newest submitted batch (groot_hip_redo_status)
     hipEvent_t last_compute = nullptr;     // behind the order stage of the newest batch (groot_hip_stream_join)
     hipStream_t own_stream = nullptr, stream = nullptr, astream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;   // stream: seed stage (the caller's, if given); astream: align + order stage
     bool profiling = false;
@@ -591,7 +592,7 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
         // (the reads it decides it also leaves as 2-bit codes for the first pass of the align stage)
         if (c->lean && !c->tab_capture && w->packed.p) { a.packed = w->packed.p; a.packed_q = s->max_len <= 128 ? 2u : 4u; }
         s->packed_q = a.packed ? a.packed_q : 0;
-        launch_sig(c->s, a, s->max_len, false, c->stream);
+        launch_sig(c->s, a, s->max_len, c->stream);
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[8], c->stream));
         launch_list(c->s, a, dim3(std::min<uint32_t>(grid.x, list_blocks)), c->stream);
@@ -653,6 +654,15 @@ static int launch_seed_stage(groot_ctx *c, Slot *s, bool update_weights)
                                          s->n_reads, begin_bit, end_bit, c->stream));
     return GROOT_OK;
 }
+
+// which slots of the processing order does align_kernel take after the first pass?  Those the first pass flagged, and those it did not get to
+// (its grid is sized by the latest batch: slots beyond it)
+struct LeanLeft {
+    const uint8_t *defer;
+    const DeviceCounters *ctr;
+    uint32_t lean_slots;
+    __device__ uint8_t operator()(uint32_t i) const { return i < ctr->seeded_reads && (i >= lean_slots || defer[i]) ? 1 : 0; }
+};
 
 static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
 {
@@ -730,7 +740,10 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
     // First pass (kernels_lean.hpp): a thread per read in processing order finishes the reads of one seed window whose walks never branch;
     // the slots it leaves are flagged, a stream compaction keeps them in processing order, and align_kernel takes that list.
     const uint32_t lean_stride = lean_stride_dw(s->max_len);
-    s->lean_used = c->lean && !c->tab_capture && s->n_reads && s->max_len <= kLeanMaxLen;
+    // (GROOT_LEAN=1: every batch that has reads to walk.  Measured, DESIGN.md section 3: alone on the chip the two passes take 2.2 + 0.7 ms where align_kernel
+    // takes 3.0 on configs[2]; beside the next batch's hashing kernels the step is between 1.5 % shorter and 8 % longer from box to box, and batches of
+    // mixed lengths or of reads with errors are slower -- hence off by default.)
+    s->lean_used = c->lean && !c->tab_capture && s->n_reads && s->max_len <= kLeanMaxLen && c->dfs_frac >= 0.02;
     if (s->lean_used) {
         LeanArgs l{};
         l.nodes = c->lean_nodes.p; l.ext = c->lean_ext.p; l.bases2 = c->bases2.p; l.cn_pre2 = c->cn_pre2.p; l.win_ok = c->win_ok.p;
@@ -743,15 +756,20 @@ static int launch_align_stage(groot_ctx *c, Slot *s, bool update_weights)
         l.trav_first = w->trav_first.p; l.mask_first = w->mask_first.p; l.trav_cnt = w->trav_cnt.p;
         l.defer = w->defer.p; l.ctr = s->d_ctr.p;
         l.stk = c->lean_stk.p; l.ovf_trav = c->ovf_trav.p; l.ovf_mask = c->ovf_mask.p; l.ovf_cnt = c->ovf_cnt.p; l.ovf_cap = c->ovf_cap;
-        launch_align_lean(c->pw, l, dim3((s->n_reads + kBlock - 1) / kBlock), c->astream);
+        // workgroups for the reads expected to have seeds (the latest batch says how many: they come first in the processing order); the slots
+        // beyond them, if the batch has more, go to align_kernel like the flagged ones
+        const uint32_t lean_blocks = std::min<uint32_t>((s->n_reads + kBlock - 1) / kBlock, (uint32_t)(c->dfs_frac * 1.05 * (double)s->n_reads / kBlock) + 64u);
+        launch_align_lean(c->pw, l, dim3(lean_blocks), c->astream);
         HIP_TRY(c, hipGetLastError());
         size_t tb = 0;
-        HIP_TRY(c, rocprim::select(nullptr, tb, w->perm.p, w->defer.p, w->perm2.p, w->perm2_count.p, (size_t)s->n_reads, c->astream));
+        rocprim::counting_iterator<uint32_t> ids(0u);
+        auto flags = rocprim::make_transform_iterator(ids, LeanLeft{w->defer.p, s->d_ctr.p, lean_blocks * (uint32_t)kBlock});
+        HIP_TRY(c, rocprim::select(nullptr, tb, w->perm.p, flags, w->perm2.p, w->perm2_count.p, (size_t)s->n_reads, c->astream));
         if (tb > c->scan_tmp.n) {
             HIP_TRY(c, hipStreamSynchronize(c->astream));
             HIP_TRY(c, c->scan_tmp.alloc(tb + tb / 4));
         }
-        HIP_TRY(c, rocprim::select(c->scan_tmp.p, tb, w->perm.p, w->defer.p, w->perm2.p, w->perm2_count.p, (size_t)s->n_reads, c->astream));
+        HIP_TRY(c, rocprim::select(c->scan_tmp.p, tb, w->perm.p, flags, w->perm2.p, w->perm2_count.p, (size_t)s->n_reads, c->astream));
         a.perm = w->perm2.p;
         a.n_perm = w->perm2_count.p;
         if (c->profiling) HIP_TRY(c, hipEventRecord(s->ev[13], c->astream));
@@ -1004,6 +1022,7 @@ static int enqueue(groot_ctx *c, Slot *s)
     if (int rc = run_batch_async(c, s, true)) return rc;
     HIP_TRY(c, hipEventRecord(s->ev_compute, c->astream));
     c->last_compute = s->ev_compute;
+    c->newest = s;
     // Copy-out on its own stream with no host in between.  The record count is only known on the device, and asking for it
     // would put a host round trip between the last kernel and the copy; so the copy engine is given a PREDICTED count now
     // -- records per read of the latest finished batch, plus a margin -- and collect fetches the rest in the rare batch
@@ -1169,8 +1188,8 @@ static int finish_counters(groot_ctx *c, Slot *s)
         fprintf(stderr, "[groot lean] wavefronts %llu; per wavefront: %.1f iterations (with a level-1 / level-2 / level-3-4 / walk lane: %.1f / %.1f / %.1f / %.1f); lane-steps per wavefront: %.0f / %.0f / %.0f / %.0f; staging %.2f us, loop %.2f us\n",
                 h.dbg[151], (double)h.dbg[148] / nw, (double)h.dbg[140] / nw, (double)h.dbg[141] / nw, (double)h.dbg[142] / nw, (double)h.dbg[143] / nw,
                 (double)h.dbg[144] / nw, (double)h.dbg[145] / nw, (double)h.dbg[146] / nw, (double)h.dbg[147] / nw, (double)h.dbg[149] / nw / 100.0, (double)h.dbg[150] / nw / 100.0);
-        fprintf(stderr, "[groot lean] finished without an alignment %llu; left to align_kernel: seeds > 4: %llu, 2..4 (or none): %llu, byte > T / length: %llu, byte other than ACGT: %llu, window with an N: %llu, node with an N: %llu, N ahead: %llu, two neighbours: %llu\n",
-                h.dbg[160], h.dbg[161], h.dbg[162], h.dbg[163], h.dbg[164], h.dbg[165], h.dbg[166], h.dbg[167], h.dbg[168]);
+        fprintf(stderr, "[groot lean] finished without an alignment %llu; left to align_kernel: seeds > 4: %llu, byte > T / length: %llu, byte other than ACGT: %llu, window with an N: %llu, node with an N: %llu, N ahead: %llu, three neighbours: %llu, third pending: %llu, too many steps: %llu\n",
+                h.dbg[160], h.dbg[161], h.dbg[163], h.dbg[164], h.dbg[165], h.dbg[166], h.dbg[167], h.dbg[168], h.dbg[169], h.dbg[170]);
     }
 #elif defined(GROOT_WORK_COUNTERS)
     for (int e = 0; e < 32; e++)
@@ -2102,7 +2121,7 @@ static int open_impl(groot_ctx *c, int device_id, const groot_index_view *v, con
         HIP_TRY(c, upload(c->node_rec, recs.data(), recs.size()));
     }
     // ---- first pass of the align stage (kernels_lean.hpp): everything at 2 bits per base ----
-    c->lean = c->pw == 3 && !c->kn.no_lean && !c->prm.no_exact_align;
+    c->lean = c->pw == 3 && c->kn.lean && !c->prm.no_exact_align;
     if (c->lean) {
         auto code_of = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'T' ? 2 : b == 'G' ? 3 : -1; };
         std::vector<uint32_t> b2((size_t)(v->n_bases + 15) / 16 + 20, 0);
@@ -2611,6 +2630,15 @@ int groot_hip_stream_join(groot_ctx *c, void *hip_stream)
     // batches run in submission order on the align stream: the newest batch's event covers the ones before it
     // (the newest batch's event: a slot's event is recorded anew only by a newer batch still, and a finished one makes the wait a no-op)
     if (c->last_compute) HIP_TRY(c, hipStreamWaitEvent(st, c->last_compute, 0));
+    return GROOT_OK;
+}
+
+int groot_hip_redo_status(groot_ctx *c, const uint32_t **d_status, uint32_t *redo_mask)
+{
+    if (!c || !d_status || !redo_mask) return GROOT_E_INVALID;
+    if (!c->newest) return fail(c, GROOT_E_STATE, "no batch submitted");
+    *d_status = &c->newest->d_ctr.p->flags;
+    *redo_mask = kFlagSeedOverflow | kFlagTravOverflow | kFlagOvfOverflow | kFlagQOverflow;    // what finish_counters grows and redoes
     return GROOT_OK;
 }
 

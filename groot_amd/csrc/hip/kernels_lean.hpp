@@ -32,6 +32,10 @@ namespace groot {
 #define GROOT_LEAN_WAVES 5
 #endif
 constexpr int kLeanWaves = GROOT_LEAN_WAVES;
+#ifndef GROOT_LEAN_MAX_ITER
+#define GROOT_LEAN_MAX_ITER 96
+#endif
+constexpr uint32_t kLeanMaxIter = GROOT_LEAN_MAX_ITER;   // steps (candidate ranges, walk nodes) a read may take in the first pass
 
 __device__ __forceinline__ uint64_t lean_lowmask(int n) { return n <= 0 ? 0ull : (n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1ull)); }
 // order of the 16 two-bit fields reversed, every base complemented (A<->T = 0<->2, C<->G = 1<->3: code ^ 2)
@@ -64,6 +68,14 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
     // behind the read: the current window's seed, OffSet, l1_hi, cn_begin, cn_end, seed_s0, seed_len; the read's seed windows, ascending
     uint32_t *W = my + (a.lds_stride_dw - 11u);
     enum : int { W_SEED, W_OFF0, W_L1HI, W_CNB, W_CNE, W_S0, W_SLEN, W_WIN };
+    // (a chain of dependent trips to memory with a few dozen instructions between two of them, beside the next batch's hashing kernels, which keep the
+    // issue ports busy: raised, a walking wavefront goes first when it can go at all -- as in align_kernel)
+#ifndef GROOT_LEAN_PRIO
+#define GROOT_LEAN_PRIO -1
+#endif
+#if GROOT_LEAN_PRIO >= 0
+    __builtin_amdgcn_s_setprio(GROOT_LEAN_PRIO);
+#endif
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_todo = min(a.n_reads, (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ctr->seeded_reads));
     // the seed stage ran out of slots or rows: the host grows them and runs the batch again (align_kernel returns at once, too)
@@ -235,7 +247,11 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
     if (GROOT_LEAN_PROBE == 1 && st <= ST_SEED) st = ST_DEFER;
 #endif
 
+    uint32_t iters = 0;
     while (__ballot(st <= ST_SEED)) {
+        // a read that is still at it after kLeanMaxIter steps is one of the hard ones (it fails through the hierarchy, candidate after candidate, a trip
+        // to memory each): align_kernel has the means for those (cooperative scans, fork / join) and a wavefront here would wait for it
+        if (st <= ST_SEED && ++iters > kLeanMaxIter) { st = ST_DEFER; LEAN_WHY(10); }
         if (st == ST_SEED) {
             // ---- the read's next seed window, if any (graphminion.go:52-100) ----
             if (si >= cnt) st = ST_DONE;
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
         atomicAdd(&a.ctr->dbg[150], t2 - lw_t1);
         atomicAdd(&a.ctr->dbg[151], 1ull);
     }
-    for (uint32_t y = 1; y <= 9; y++) {
+    for (uint32_t y = 1; y <= 10; y++) {
         const unsigned long long b = __ballot(st == ST_DEFER && why == y);
         if (b && (threadIdx.x & 63) == 0) atomicAdd(&a.ctr->dbg[160 + y], (unsigned long long)__popcll(b));
     }
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(kBlock, kLeanWaves) void align_lean_kernel(LeanArgs
 #endif
     // ---- what the read leaves behind ----
     const bool fin = st == ST_DONE;
-    if (slot < a.n_reads) a.defer[slot] = st == ST_DEFER ? 1 : 0;
+    if (slot < n_todo) a.defer[slot] = st == ST_DEFER ? 1 : 0;   // (slots from n_todo on hold reads without seeds: LeanLeft)
     unsigned long long n_alns = 0, mapped = 0, multimapped = 0;
     if (fin) {
         a.trav_cnt[r] = ord;

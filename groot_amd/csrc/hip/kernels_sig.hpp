@@ -85,6 +85,9 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
     static_assert(S >= 1 && S <= 32 && M5 >= 0 && M5 < 32, "slots i < 32 with a compile-time (k * multiSeed) & 31 only");
     static_assert(TW >= 1 && 16 * TW <= (int)kTextMax, "a read cannot be longer than a window text");
     static_assert(G >= 1 && (G == 1 || sig_step(G - 1, S, M5) >= 0), "the sketch has fewer slots than the signature wants");
+#ifdef GROOT_SIG_PRIO
+    __builtin_amdgcn_s_setprio(GROOT_SIG_PRIO);
+#endif
     constexpr int kTextWords = TW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ __attribute__((aligned(512))) unsigned char tab[512];
@@ -132,7 +135,15 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
     // whether anybody hashes them or not: 100+ bytes per read from HBM, and on a batch of mixed read lengths -- 2-3 % window-sized reads, one or two
     // to a wavefront -- nobody does.  The reads are therefore classified by LENGTH first, and a workgroup none of whose wavefronts will hash
     // stages nothing (round 5; the barrier that follows the table set-up carries the vote).
+#ifdef GROOT_REP_BAD_LIST
+    // The arrangement of round 4's c6ce697 (python __graft_entry__.py rep; tools/rep_bad_list.sh): the wavefront's vote is taken BEFORE the staging and
+    // not again behind the bad-base check.  In that variant a dozen reads per 10 M that take the late push (todo_push below) got a slot of the list
+    // that was never written; tests/test_signature_path.py::test_no_read_is_left_out_by_the_seed_stage is the guard that sees it.
+    if ((uint32_t)__popcll(__ballot(fast)) < kSigMinLanes) fast = false;
+    const bool stage = __syncthreads_or(fast ? 1 : 0) != 0;
+#else
     const bool stage = __syncthreads_or((uint32_t)__popcll(__ballot(fast)) >= kSigMinLanes) != 0;
+#endif
     if (stage && in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + base16);
         const uint32_t n16 = (uint32_t)((span_bytes + 15) >> 4);
@@ -164,7 +175,9 @@ __global__ __launch_bounds__(BS, (TW > 8 ? GROOT_SIG_WAVES_LONG : GROOT_SIG_WAVE
     // A wavefront hashes at the price of 64 reads however few of its lanes take part: in a batch of mixed read lengths 2-3 % of the reads are
     // window-sized, four in five wavefronts hold one or two of them, and the kernel cost 1.1 ms per 8 M reads (2.9 beside the align stage) to
     // answer 0.2 M.  Below kSigMinLanes such lanes the wavefront leaves its reads to the list pass, which takes them packed 64 to a wavefront.
+#ifndef GROOT_REP_BAD_LIST
     if ((uint32_t)__popcll(__ballot(fast)) < kSigMinLanes) fast = false;
+#endif
     {
         // the reads left to the list pass (other lengths, bytes other than ACGT, the LSH-Forest branch): counted per workgroup -- one
         // LDS atomic per wavefront, ONE global atomic per workgroup.  (One global atomic per wavefront on the single counter cost

@@ -13,8 +13,7 @@ void launch_seed(uint32_t s, uint32_t max_k, const SeedArgs &a, bool dump, dim3 
 
 // signature kernel; the list pass of the full-width kernel (behind it, or behind the text lookup); the text lookup
 bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k);
-// (one_wave: workgroups of one wavefront -- batches of one read length; else of four)
-void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, bool one_wave, hipStream_t st);
+void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, hipStream_t st);
 void launch_list(uint32_t s, const SeedArgs &a, dim3 list_grid, hipStream_t st);
 void launch_text_lookup(uint32_t key_dwords, const SeedArgs &a, dim3 grid, size_t lds, hipStream_t st);
 

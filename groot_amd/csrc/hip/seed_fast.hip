@@ -16,12 +16,11 @@ template <int S, int M5> static void launch_list_sm(const SeedArgs &a, dim3 list
 {
     hipLaunchKernelGGL((sketch_seed_kernel<S, 4, false, M5, true>), list_grid, dim3(kBlock), kLdsReads + (size_t)kBlock * a.list_stride_dw * 4, st, a);
 }
-template <int S, int M5> static void launch_sig_sm(const SeedArgs &a0, uint32_t max_len, bool one_wave, hipStream_t st)
+template <int S, int M5> static void launch_sig_sm(const SeedArgs &a0, uint32_t max_len, hipStream_t st)
 {
     // (reads of up to 128 bases: half the registers and instructions in the text comparison)
     // LDS: bad-chunk bits, then one dword of codes per 16 bases of the workgroup's span (+: the kernel reads whole register rows past a read)
     SeedArgs a = a0;
-    (void)one_wave;   // (workgroups of one wavefront were measured in round 5: no difference on any workload -- the kernel is bound by instruction issue, not by a workgroup waiting for its slowest wavefront)
     const uint32_t bs = (uint32_t)kBlock;
     a.lds_read_bytes = (uint32_t)std::min<uint64_t>((uint64_t)bs * max_len + 32, 64 * 1024);
     const size_t lds = kSigCodes + (size_t)((a.lds_read_bytes + 15) / 16) * 4 + 96;
@@ -45,15 +44,15 @@ bool sig_supported(uint32_t s, uint32_t max_k, uint32_t k)
     if (max_k != 4) return false;
     return (s == 21 && (m5 == 6 || m5 == 10 || m5 == 14 || m5 == 2)) || (s == 20 && m5 == 6) || (s == 30 && m5 == 14);
 }
-void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, bool one_wave, hipStream_t st)
+void launch_sig(uint32_t s, const SeedArgs &a, uint32_t max_len, hipStream_t st)
 {
     const uint32_t m5 = (uint32_t)(((uint64_t)a.ix.k * GROOT_MULTI_SEED) & 31u);
-    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, max_len, one_wave, st);
-    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, max_len, one_wave, st);
-    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, max_len, one_wave, st);
-    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, max_len, one_wave, st);
-    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, max_len, one_wave, st);
-    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, max_len, one_wave, st);
+    if (s == 21 && m5 == 6) return launch_sig_sm<21, 6>(a, max_len, st);
+    if (s == 21 && m5 == 10) return launch_sig_sm<21, 10>(a, max_len, st);
+    if (s == 21 && m5 == 14) return launch_sig_sm<21, 14>(a, max_len, st);
+    if (s == 21 && m5 == 2) return launch_sig_sm<21, 2>(a, max_len, st);
+    if (s == 20 && m5 == 6) return launch_sig_sm<20, 6>(a, max_len, st);
+    if (s == 30 && m5 == 14) return launch_sig_sm<30, 14>(a, max_len, st);
 }
 
 void launch_text_lookup(uint32_t key_dwords, const SeedArgs &a, dim3 grid, size_t lds, hipStream_t st)

@@ -347,15 +347,17 @@ private:
     bool header()
     {
         // (byte-aligned here: at the start of the file, or behind a trailer)
+        // Behind a member, the input may end, or go on with bytes that are not a gzip header (ignored, as gzread does).  Once the magic has matched, a
+        // member HAS begun: input that ends inside its header is a truncated file (a bgzip FASTQ cut inside a block header), and an error -- zlib's
+        // gzread reports "unexpected end of file" there and Go's gzip.Reader (the reference: sketch.go:175-238) io.ErrUnexpectedEOF.
         uint8_t h[10];
-        if (!need(8)) {
-            if (bc_ == 0 && any_member_) { st_ = ST_DONE; return true; }   // the clean end
-            if (any_member_) { st_ = ST_DONE; return true; }               // a few stray bytes behind the last member: ignored, as gzread does
-            return fail("not a gzip stream");
-        }
-        for (int i = 0; i < 10; i++)
-            if (!byte(h[i])) { if (any_member_) { st_ = ST_DONE; return true; } return fail("gzip input ends inside a header"); }
-        if (h[0] != 0x1f || h[1] != 0x8b) { if (any_member_) { st_ = ST_DONE; return true; } return fail("not a gzip stream"); }
+        for (int i = 0; i < 2; i++)
+            if (!byte(h[i]) || h[i] != (i ? 0x8b : 0x1f)) {
+                if (any_member_) { st_ = ST_DONE; return true; }
+                return fail("not a gzip stream");
+            }
+        for (int i = 2; i < 10; i++)
+            if (!byte(h[i])) return fail("gzip input ends inside a header");
         if (h[2] != 8 || (h[3] & 0xE0)) return fail("gzip input: unsupported header");
         uint8_t b;
         if (h[3] & 4) {                                        // FEXTRA
@@ -502,15 +504,8 @@ private:
             int used = 0;
             if (type_of(e) == T_SUB) { used = kLitBits; e = lt[(e >> 16) + ((bb_ >> kLitBits) & ((1u << ((e >> 8) & 15)) - 1))]; }
             const uint32_t type = type_of(e);
-            if (type == T_LIT && (int)(e & 15) + used > bc_ && ((e >> 4) & 3)) {
-                // a run of literals reaches past the bits that are left: the single literal then (the run's first code fits if any of it does)
-                uint32_t l1 = 1;
-                while (l1 < 15 && ((lt[bb_ & ((1u << l1) - 1)] & 15) != l1 || type_of(lt[bb_ & ((1u << l1) - 1)]) != T_LIT || ((lt[bb_ & ((1u << l1) - 1)] >> 4) & 3))) l1++;
-                if ((int)l1 > bc_ || l1 >= 15) return fail("gzip input ends inside a block");
-                take((int)l1);
-                out[opos_++] = (uint8_t)(e >> 8);
-                continue;
-            }
+            // (a run of literals that reaches past the bits that are left: in a whole stream the end-of-block code follows the last literal, and
+            // an entry describes literals only -- so the input was cut inside the block, as when a single code does not fit: the check below)
             used += (int)(e & 15);
             if (type == T_BASE) used += (int)((e >> 8) & 15);
             if (used > bc_) return fail("gzip input ends inside a block");

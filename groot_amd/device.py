@@ -161,6 +161,12 @@ class Aligner:
         """device-side: `hip_stream` (None = the stream of set_stream) waits for the results of every batch submitted so far"""
         self._check(lib().groot_hip_stream_join(self._h, C.c_void_p(hip_stream)))
 
+    def redo_status(self):
+        """(device address of the newest batch's status word, mask of its bits that mean `collect will redo the batch`)"""
+        p, m = C.c_void_p(), C.c_uint32()
+        self._check(lib().groot_hip_redo_status(self._h, C.byref(p), C.byref(m)))
+        return p.value, m.value
+
     def set_profiling(self, on=True):
         self._check(lib().groot_hip_set_profiling(self._h, C.c_int(1 if on else 0)))
 

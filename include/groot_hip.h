@@ -154,10 +154,19 @@ int groot_hip_open_stats(const groot_ctx *ctx, groot_open_stats *out);
  * groot_hip_collect (host side), or groot_hip_stream_join (device side, no host wait). */
 int groot_hip_set_stream(groot_ctx *ctx, void *hip_stream);
 /* Make `hip_stream` (NULL = the stream given to groot_hip_set_stream) wait -- on the device, the call returns at once --
- * until every batch submitted so far has its results in place (records, path sets, counters, call counts) and no longer
- * reads its inputs.  For callers that consume results_on_device buffers or recycle groot_hip_submit_device inputs from
- * kernels of their own. */
+ * until every batch submitted so far is through its kernels: records, path sets, counters and call counts of its FIRST PASS
+ * are in place and that pass no longer reads the batch's inputs.  For callers that consume results_on_device buffers or
+ * recycle groot_hip_submit_device inputs from kernels of their own.
+ * The first pass is the only one unless a growable buffer of the ctx was too small for the batch (more seeds per read,
+ * traversals, overflow records or kmerCount rows than it had room for): then groot_hip_wait / groot_hip_collect grow the
+ * buffer on the HOST and run the batch again -- reading its inputs again, rewriting (possibly reallocating) its results.  A
+ * consumer that is ordered by the join alone must therefore look at the batch's status word first (groot_hip_redo_status):
+ * non-zero = this batch will be redone at collect, its device results are not final and its inputs are still needed. */
 int groot_hip_stream_join(groot_ctx *ctx, void *hip_stream);
+/* *d_status = device address of the newest submitted batch's status word (valid until that batch is released), *redo_mask = the bits of it
+ * that mean "a buffer overflowed: collect will redo the batch".  A kernel (or a 4-byte copy) ordered behind groot_hip_stream_join reads
+ * `*d_status & redo_mask`: zero = the results the join made visible are final.  GROOT_E_STATE when nothing has been submitted. */
+int groot_hip_redo_status(groot_ctx *ctx, const uint32_t **d_status, uint32_t *redo_mask);
 int groot_hip_set_profiling(groot_ctx *ctx, int enable);
 
 /* ---- submitting batches ------------------------------------------------------------------------------------------

@@ -13,6 +13,19 @@ from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True, params=["align_kernel", "lean_first"])
+def align_stage(request, monkeypatch):
+    """every test of this module twice: the align stage as shipped (align_kernel alone), and with its first pass in front (GROOT_LEAN=1,
+    kernels_lean.hpp) -- the results must not depend on it"""
+    if request.param == "lean_first":
+        if request.node.name.startswith("test_kernel_path_at_benchmark_size") or "background" in request.node.name:
+            pytest.skip("compares the two itself / not about the align stage")
+        monkeypatch.setenv("GROOT_LEAN", "1")
+    else:
+        monkeypatch.delenv("GROOT_LEAN", raising=False)
+    return request.param
+
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")
 
 
@@ -535,8 +548,8 @@ def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypa
     kernel on a few slots of the sketch, list pass, align kernel -- against the same library with GROOT_NO_SIG=1 (every read through the
     full-width kernel: all S slots at 64 bits, exact table / LSH Forest: an independent seeding path), on 10 M error-free 100 bp reads
     (configs[2]), the same with 1 % substitutions, and 8 M reads of 75..150 bases on resfinder.90 (configs[4]) at t = 0.99 and at t = 0.90 (the
-    LSH-Forest branch: lsh_heavy_kernel, the longest list pass); against the same library with GROOT_NO_LEAN=1 (the align stage without its
-    first pass: every record, path set and call count must be the same); then the oracle on 20 000 of them.  A kernel that is wrong on one read in a million is invisible to oracle comparisons on 10^4..10^5 reads (round 4 had one): at this
+    LSH-Forest branch: lsh_heavy_kernel, the longest list pass); against the same library with GROOT_LEAN=1 (the align stage with its first
+    pass, kernels_lean.hpp: every record, path set and call count must be the same); then the oracle on 20 000 of them.  A kernel that is wrong on one read in a million is invisible to oracle comparisons on 10^4..10^5 reads (round 4 had one): at this
     size it shows.  khf.go:35-55, lshe.go:153-175, graphminion.go:46-102, alignment.go:13-254."""
     import torch
 
@@ -573,11 +586,11 @@ def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypa
                 other = acgt[(cur + 1 + torch.randint(0, 3, blk.shape, generator=g, device=dev)) % 4]
                 rows[c0:c0 + 1_000_000] = torch.where(hit & torch.isin(blk, acgt), other, blk)
     torch.cuda.synchronize()
-    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG", "GROOT_NO_LEAN"):
+    for v in ("GROOT_NO_TEXT_TABLE", "GROOT_NO_OUTCOME_TABLE", "GROOT_NO_SIG", "GROOT_LEAN"):
         monkeypatch.delenv(v, raising=False)
 
-    def run(no_sig, no_lean=False):
-        for var, on in (("GROOT_NO_SIG", no_sig), ("GROOT_NO_LEAN", no_lean)):
+    def run(no_sig, lean=False):
+        for var, on in (("GROOT_NO_SIG", no_sig), ("GROOT_LEAN", lean)):
             if on:
                 monkeypatch.setenv(var, "1")
             else:
@@ -596,9 +609,10 @@ def test_kernel_path_at_benchmark_size(argannot_index, resfinder_index, monkeypa
         return c0, n0, a0, att0, t, m
 
     c, n, a, att, t, m = run(False)
-    # the align stage without its first pass (align_kernel alone): the same records, path sets, call counts
-    cl, _, _, attl, tl, ml = run(False, no_lean=True)
-    assert cl["lean_reads"] == 0 and c["lean_reads"] > (0.3 if mixed else 0.8 if workload == "c2" else 0.3) * c["walked_reads"], (c, cl)
+    # the align stage with its first pass (align_lean_kernel in front of align_kernel; it takes batches of one read length most of whose reads are
+    # walked): the same records, path sets, call counts
+    cl, _, _, attl, tl, ml = run(False, lean=True)
+    assert c["lean_reads"] == 0 and (cl["lean_reads"] > 0.9 * cl["walked_reads"] if workload == "c2" else True), (c, cl)
     assert np.array_equal(t, tl) and np.array_equal(m, ml) and np.array_equal(att, attl)
     assert {k: v for k, v in c.items() if k != "lean_reads"} == {k: v for k, v in cl.items() if k != "lean_reads"}
     del tl, ml

@@ -21,6 +21,18 @@ def checker(tmp_path_factory):
     return exe
 
 
+@pytest.fixture(scope="module")
+def checker_san(tmp_path_factory):
+    """the same tool under AddressSanitizer + UBSan: the decoder works with slack (4-byte literal stores, 16-byte match copies, 8-byte loads past
+    the input's end) -- an access outside its buffers that stays inside the heap would go unnoticed in the plain build"""
+    exe = str(tmp_path_factory.mktemp("gz") / "gz_check_san")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                        os.path.join(REPO, "tools", "gz_check.cpp"), "-lz"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime in this image: " + r.stderr[-200:])
+    return exe
+
+
 def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, memlevel=8):
     c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
     return c.compress(data) + c.flush()
@@ -98,6 +110,63 @@ def test_corrupt_and_truncated_streams_end_in_an_error(checker, tmp_path):
         p.write_bytes(bytes(b))
         out = run(checker, p, [1 << 20, 4099, 13][it % 3])
         assert out.startswith("error:") or out.startswith("same"), (it, out)
+
+
+def test_input_that_ends_inside_a_later_members_header_is_an_error(checker, tmp_path):
+    """behind a member the input may end, or go on with bytes that are not a gzip header; once the 1f 8b of another member has matched, the file
+    is truncated if it ends before that member's header does (a bgzip FASTQ cut inside a block header) -- gzread and Go's gzip.Reader (the
+    reference's reader, sketch.go:175-238) report an error there, and so does this one"""
+    text = fastq_text(2000)
+    a, b = gz(text[:50000]), gz(text[50000:])
+    fextra = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0"
+    fname = bytearray(b[:10]); fname[3] |= 8
+    cases = {"magic_only": a + b[:2], "nine_bytes": a + b[:9], "inside_fextra": a + fextra[:14], "inside_fname": a + bytes(fname) + b"reads.fq"}
+    for name, data in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(data)
+        out = run(checker, p)
+        assert out.startswith("error:") and "header" in out, (name, out)
+    # ... while stray bytes that are not a header are still ignored, and a lone 0x1f is such a byte
+    for name, data in {"stray": a + b"\0\0garbage", "lone_1f": a + b"\x1f", "not_magic": a + b"\x1f\x8c\x08"}.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(data)
+        assert run(checker, p).startswith("same 50000"), name
+
+
+def test_damaged_streams_of_every_block_type_under_the_sanitizers(checker_san, tmp_path):
+    """stored, fixed, dynamic and BGZF streams -- one of them with more than 2 MiB of compressed data, so that the decoder's refill of its 1 MiB
+    input buffer and its end-of-input path run under mutation too -- damaged a few hundred times: an error or the right bytes, and no report
+    from AddressSanitizer / UBSan (a report ends the tool with a non-zero status: check=True)"""
+    text = fastq_text(3000, seed=21)
+    rng = np.random.default_rng(23)
+
+    def bgzf_member(d):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = co.compress(d) + co.flush()
+        return b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(c) + 25) + c + struct.pack("<II", zlib.crc32(d), len(d))
+
+    big = rng.integers(0, 256, 2_600_000, dtype=np.uint8).tobytes()        # incompressible: > 2 MiB of deflate data
+    streams = {"stored": gz(text[:200000], 0), "fixed": gz(text, 6, zlib.Z_FIXED), "dynamic": gz(text, 6),
+               "bgzf": b"".join(bgzf_member(text[i:i + 30000]) for i in range(0, 300000, 30000)) + bgzf_member(b""),
+               "big": gz(big[:1_300_000], 6) + gz(big[1_300_000:], 1)}
+    for name, good in streams.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(good)
+        assert run(checker_san, p, 4099 if len(good) < 400_000 else 1 << 20).startswith("same"), name
+        n_it = 25 if name == "big" else 90
+        for it in range(n_it):
+            b = bytearray(good)
+            kind = it % 3
+            if kind == 0:                                  # cut somewhere (block headers and the refill boundary included)
+                b = b[: int(rng.integers(1, len(b)))]
+            elif kind == 1:                                # damage near the start of a block / member header
+                at = int(rng.integers(0, min(len(b), 64)))
+                b[at] ^= 1 << int(rng.integers(0, 8))
+            for _ in range(int(rng.integers(0, 3))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            p.write_bytes(bytes(b))
+            out = run(checker_san, p, [1 << 20, 4099, 13][it % 3] if len(b) < 400_000 else 1 << 20)
+            assert out.startswith("error:") or out.startswith("same"), (name, it, out)
 
 
 def test_reader_on_gzip_fastq(tmp_path):

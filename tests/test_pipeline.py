@@ -244,6 +244,47 @@ def test_stream_join_orders_a_caller_stream_behind_the_results(small_index):
     al.close()
 
 
+@pytest.mark.parametrize("small", [False, True])
+def test_stream_join_covers_the_first_pass_only_and_says_so(small_index, monkeypatch, small):
+    """groot_hip_stream_join orders a caller's stream behind a batch's KERNELS.  A batch for which a growable buffer was too small is redone by
+    wait / collect on the host (it reads its inputs again, rewrites its results): a consumer ordered by the join alone reads the batch's status word
+    (groot_hip_redo_status) behind the join -- non-zero under the mask = not final.  GROOT_TEST_SMALL_BUFFERS makes every buffer start too small."""
+    import torch
+
+    monkeypatch.delenv("GROOT_TEST_SMALL_BUFFERS", raising=False)
+    if small:
+        monkeypatch.setenv("GROOT_TEST_SMALL_BUFFERS", "1")
+    batches = make_batches(small_index, 1, 3000)
+    _, per = oracle_of(small_index, batches)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    seq, off = batches[0]
+    d_seq = torch.zeros(len(seq) + 64, dtype=torch.uint8, device=dev)
+    d_seq[: len(seq)] = torch.from_numpy(np.ascontiguousarray(seq)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(off).astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    al = device.Aligner(small_index, max_batch_reads=4096, results_on_device=True)
+    al.set_stream(st.cuda_stream)
+    with pytest.raises(Exception):
+        al.redo_status()                               # nothing submitted yet
+    al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), len(off) - 1, first_read_id=0, max_len=int(np.diff(off).max()))
+    al.stream_join()
+    ptr, mask = al.redo_status()
+
+    class Word:                                        # the status word as a CUDA array: read on the caller's stream, behind the join
+        __cuda_array_interface__ = {"shape": (1,), "typestr": "<u4", "data": (ptr, True), "version": 2}
+
+    with torch.cuda.stream(st):
+        status = torch.as_tensor(Word(), device=dev).clone()
+    st.synchronize()
+    redo = int(status.item()) & mask
+    assert (redo != 0) == small, (hex(int(status.item())), hex(mask))
+    c = al.wait()                                      # ... which grows what was too small and runs the batch again
+    recs = al.alns()
+    assert len(recs) == len(per[0]) and all(np.array_equal(recs[f], per[0][f]) for f in per[0].dtype.names) and c["received"] == len(off) - 1
+    al.close()
+
+
 def test_corrupt_view_is_refused(small_index):
     """groot_hip_open runs the consistency pass before uploading anything"""
     import ctypes as C

@@ -11,6 +11,19 @@ from oracle import oracle_py as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["align_kernel", "lean_first"])
+def align_stage(request, monkeypatch):
+    """every test of this module twice: the align stage as shipped (align_kernel alone), and with its first pass in front (GROOT_LEAN=1,
+    kernels_lean.hpp) -- the results must not depend on it"""
+    if request.param == "lean_first":
+        if request.node.name.startswith("test_kernel_path_at_benchmark_size") or "background" in request.node.name:
+            pytest.skip("compares the two itself / not about the align stage")
+        monkeypatch.setenv("GROOT_LEAN", "1")
+    else:
+        monkeypatch.delenv("GROOT_LEAN", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module", autouse=True)
 def need_gpu(hip_lib):
     assert device.device_count() > 0, "no MI355X visible: the HIP path has no CPU fallback"
