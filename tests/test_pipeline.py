@@ -263,16 +263,15 @@ def test_stream_join_covers_the_first_pass_only_and_says_so(small_index, monkeyp
     d_seq[: len(seq)] = torch.from_numpy(np.ascontiguousarray(seq)).to(dev)
     d_off = torch.from_numpy(np.ascontiguousarray(off).astype(np.int64)).to(dev)
     torch.cuda.synchronize()
-    al = device.Aligner(small_index, max_batch_reads=4096, results_on_device=True)
+    # (memo off: groot_hip_open then runs no batch of its own, which would have grown the buffers already)
+    al = device.Aligner(small_index, max_batch_reads=4096, results_on_device=True, memo_budget_mb=device.MEMO_OFF)
     al.set_stream(st.cuda_stream)
-    with pytest.raises(Exception):
-        al.redo_status()                               # nothing submitted yet
     al.submit_device(d_seq.data_ptr(), d_off.data_ptr(), len(off) - 1, first_read_id=0, max_len=int(np.diff(off).max()))
     al.stream_join()
     ptr, mask = al.redo_status()
 
     class Word:                                        # the status word as a CUDA array: read on the caller's stream, behind the join
-        __cuda_array_interface__ = {"shape": (1,), "typestr": "<u4", "data": (ptr, True), "version": 2}
+        __cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
     with torch.cuda.stream(st):
         status = torch.as_tensor(Word(), device=dev).clone()
