@@ -550,7 +550,7 @@ def compact_line(full):
         if isinstance(cb.get("single_core"), dict):
             c["single_core"] = _r(cb["single_core"].get("value"))
         line["cpu_baseline"] = c
-    for k in ("host_fed", "cli_e2e", "mixed", "memo_tier", "thresholds", "kernel_path"):
+    for k in ("host_fed", "cli_e2e", "mixed", "memo_tier", "thresholds", "kernel_path", "lean_first"):
         if isinstance(full.get(k), dict) and "error" in full[k]:
             line.setdefault("leg_errors", {})[k] = str(full[k]["error"])[:110]
     s = json.dumps(line, separators=(",", ":"))
@@ -809,6 +809,25 @@ def main():
                     line["kernel_path"] = {"error": repr(e)}
             al.close()
             al = None
+            if not args.no_legs and args.background == 0:
+                # the `value` workload with the align stage's first pass in front of align_kernel (GROOT_LEAN=1, kernels_lean.hpp; opt-in: DESIGN.md section 3)
+                try:
+                    os.environ["GROOT_LEAN"] = "1"
+                    all_ = device.Aligner(index, device=local_rank, max_batch_reads=R, max_read_len=256, max_batch_bases=R * READ_LEN + 64,
+                                          results_on_device=True, pipeline_depth=2, memo_budget_mb=device.MEMO_OFF)
+                    all_.set_profiling(True)
+                    v, ms, c = resident_rate(all_, d_seq.data_ptr(), d_off.data_ptr(), R, READ_LEN, args.leg_steps, 3)
+                    all_.close()
+                    line["lean_first"] = {"value": v, "unit": "Mreads/s", "stage_ms": ms, "lean_reads": c.get("lean_reads"), "walked_reads": c["walked_reads"],
+                                          "alignments": c["alignments"], "what": "configs[2], memo off, GROOT_LEAN=1: align_lean_kernel + compaction in front of align_kernel"}
+                    rf["lean_first_mreads"] = v
+                    rf["lean_pass_ms"] = ms.get("lean_pass")
+                    rf["lean_first_align_ms"] = ms.get("align")
+                    rf["lean_reads_frac"] = (c.get("lean_reads") or 0) / max(1, c["walked_reads"])
+                except Exception as e:
+                    line["lean_first"] = {"error": repr(e)}
+                finally:
+                    os.environ.pop("GROOT_LEAN", None)
             if not args.no_legs and args.background == 0:
                 # the library's default ctx: the memo of groot_hip_open answers reads that equal an indexed WindowSize-mer
                 try:
