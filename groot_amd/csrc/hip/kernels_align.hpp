@@ -102,7 +102,9 @@ __global__ __launch_bounds__(kBlock, PW > 3 ? kAlignWavesWide : kAlignWaves) voi
     // batch's hashing kernels, which keep every SIMD's issue port busy: at equal priority each instruction of a walking wavefront waits its turn
     // behind five hashing wavefronts.  Raised, the walking wavefronts -- mostly waiting for memory anyway -- go first when they can go at all
     // (worth a few per cent: the 5-6 us a wave iteration takes are its own dependent instructions and trips to memory).
+#if GROOT_ALIGN_PRIO >= 0
     __builtin_amdgcn_s_setprio(GROOT_ALIGN_PRIO);
+#endif
     unsigned long long alns = 0, mapped = 0, multimapped = 0, panics = 0;
 #ifdef GROOT_WORK_COUNTERS
     uint32_t ev = 0;                                       // events of this lane in the current wave iteration
