@@ -824,6 +824,11 @@ def main():
                     rf["lean_pass_ms"] = ms.get("lean_pass")
                     rf["lean_first_align_ms"] = ms.get("align")
                     rf["lean_reads_frac"] = (c.get("lean_reads") or 0) / max(1, c["walked_reads"])
+                    try:   # VALU wave-instructions of that batch's hashing + both align passes, from the committed PMC passes taken with GROOT_LEAN=1
+                        lp = json.load(open(os.path.join(REPO, "profiles", "r06_lean_pmc.json"))).get("c2_nomemo", {})
+                        rf["lean_valu_wave_insts_per_batch"] = sum(lp.get(k_, {}).get("per_launch", {}).get("SQ_INSTS_VALU", 0.0) for k_ in ("sketch_sig_kernel", "align_lean_kernel", "align_kernel")) or None
+                    except Exception:
+                        pass
                 except Exception as e:
                     line["lean_first"] = {"error": repr(e)}
                 finally:
